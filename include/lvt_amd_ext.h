@@ -1,0 +1,103 @@
+/*
+ * lvt_amd_ext.h -- ADDITIVE entry points of the MI355X-native library (nothing here is required of an
+ * existing lvt_c caller).  They expose (a) the reference's C++-only API surface over the C-ABI
+ * (lvt_system::create with an in-memory lvt_parameters, reset, RGB-D track), (b) zero-copy tracking on
+ * images already resident in HBM, (c) read-back of per-frame intermediate results for stage-by-stage
+ * parity tests, (d) the batched Hamming matcher micro-benchmark.
+ */
+#ifndef LVT_AMD_EXT_H__
+#define LVT_AMD_EXT_H__
+
+#include "lvt_c.h"
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* mirrors struct lvt_parameters (reference lvt/src/lvt_parameters.h:29-64), hot-path fields only */
+typedef struct lvt_amd_params {
+    float fx, fy, cx, cy;
+    float baseline;
+    int img_width, img_height;
+    float k1, k2, p1, p2, k3;
+    float near_plane_distance, far_plane_distance;
+    float triangulation_ratio_test_threshold;
+    float tracking_ratio_test_threshold;
+    float descriptor_matching_threshold;
+    int min_num_matches_for_tracking;
+    int tracking_radius;
+    int detection_cell_size;
+    int max_keypoints_per_cell;
+    int agast_threshold;
+    int untracked_threshold;
+    int staged_threshold;
+    int triangulation_policy;
+} lvt_amd_params;
+
+/* reference lvt_parameters.cpp:29-52 */
+LVT_API void lvt_amd_default_params(lvt_amd_params *p);
+/* reference lvt_parameters.cpp:54-93; returns 1 on success, 0 if the file cannot be opened */
+LVT_API int lvt_amd_params_from_file(const char *config_file_name, lvt_amd_params *p);
+/* reference lvt_system::create (lvt_system.cpp:70-127): the path the example binaries use, where the
+ * intrinsics are filled in after the YAML is read (kitti_example.cpp:98-106) */
+LVT_API lvt_handle lvt_amd_create(const lvt_amd_params *p, int sensor_type);
+/* reference lvt_system::reset (lvt_system.cpp:44-68) */
+LVT_API void lvt_amd_reset(lvt_handle h);
+/* reference lvt_system::track, RGB-D branch (lvt_system.cpp:177-183): gray u8 + depth f32 (metres),
+ * both tightly packed host buffers.  (Unreachable through the reference's own C-ABI) */
+LVT_API void lvt_amd_track_rgbd(lvt_handle h, const unsigned char *gray, const float *depth, int n_rows,
+                                int n_cols, double R[3][3], double t[3]);
+/* lvt_track on images already resident in HBM (device pointers, row pitch in bytes, pitch % 16 == 0,
+ * pointers 16-byte aligned).  No host<->device image traffic. */
+LVT_API void lvt_amd_track_device(lvt_handle h, const void *d_left, const void *d_right, int n_rows,
+                                  int n_cols, int pitch_bytes, double R[3][3], double t[3]);
+/* asynchronous form: enqueue the frame on the handle's stream and return; the pose is fetched with
+ * lvt_amd_wait().  Lets one host thread keep several sequences/GPUs busy. */
+LVT_API void lvt_amd_track_device_async(lvt_handle h, const void *d_left, const void *d_right, int n_rows,
+                                        int n_cols, int pitch_bytes);
+LVT_API void lvt_amd_wait(lvt_handle h, double R[3][3], double t[3]);
+/* run all work of this handle on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream) */
+LVT_API void lvt_amd_set_stream(lvt_handle h, void *hip_stream);
+/* last HIP error string seen by this handle ("" if none); overflow / capacity diagnostics too */
+LVT_API const char *lvt_amd_last_error(lvt_handle h);
+
+/* ---- per-frame introspection (same slots as the oracle's LVTO_C_*; see oracle/lvt_oracle.h) ---- */
+enum {
+    LVT_AMD_C_N_LEFT = 0, LVT_AMD_C_N_RIGHT, LVT_AMD_C_MAP_SIZE, LVT_AMD_C_STAGED_SIZE, LVT_AMD_C_N_MATCHES,
+    LVT_AMD_C_SECOND_PASS, LVT_AMD_C_N_ROW_MATCHES, LVT_AMD_C_N_TRIANGULATED, LVT_AMD_C_TRIANGULATED,
+    LVT_AMD_C_RETRY_LEFT, LVT_AMD_C_RETRY_RIGHT, LVT_AMD_C_PNP_ITERS, LVT_AMD_C_PNP_INLIERS,
+    LVT_AMD_C_MAP_SIZE_AT_MATCH, LVT_AMD_C_N_STAGED_ERASED, LVT_AMD_C_N_STAGED_PROMOTED, LVT_AMD_C_N_CULLED,
+    LVT_AMD_C_FRAME, LVT_AMD_C_OVERFLOW /* bitmask of capacity overflows, 0 = none */,
+    LVT_AMD_C__COUNT = 32
+};
+LVT_API void lvt_amd_get_counts(lvt_handle h, int out[LVT_AMD_C__COUNT]);
+LVT_API int lvt_amd_get_features(lvt_handle h, int eye, float *xy, float *resp, uint8_t *desc, int cap);
+LVT_API int lvt_amd_get_matches(lvt_handle h, int *feat_idx, double *xyz, int cap);
+LVT_API int lvt_amd_get_row_matches(lvt_handle h, int *pairs, int cap);
+LVT_API int lvt_amd_get_map(lvt_handle h, double *xyz, int *counter, int *age, uint8_t *desc, int cap);
+LVT_API int lvt_amd_get_staged(lvt_handle h, double *xyz, int *counter, uint8_t *desc, int cap);
+LVT_API void lvt_amd_get_pose(lvt_handle h, double q_wxyz[4], double p[3]);
+LVT_API void lvt_amd_get_predicted_pose(lvt_handle h, double q_wxyz[4], double p[3]);
+/* raw per-pixel intermediates of the last frame: what = 0 score map (u8, rows x pitch),
+ * 1 box-sum map (u16, rows x pitch).  returns bytes written, pitch via *pitch_out (in elements). */
+LVT_API int lvt_amd_get_plane(lvt_handle h, int eye, int what, void *dst, int cap_bytes, int *pitch_out);
+
+/* ---- stage entry points on caller-provided data (differential tests vs the oracle) ---- */
+/* motion-only BA alone (reference lvt_pnp_solver.cpp:60-128): pts n x 3 f64, obs n x 2 f32 (host) */
+LVT_API int lvt_amd_pnp(const lvt_amd_params *p, const double q_in[4], const double p_in[3], const double *pts,
+                        const float *obs, int n, double q_out[4], double p_out[3], int *n_solve_calls);
+/* batched masked 2-NN Hamming (reference lvt_image_features_struct.cpp:68-120 + cv::BFMatcher knnMatch k=2):
+ * B independent problems; per problem M queries (desc 32 B, xy f32) against N train (desc, xy, flag u8);
+ * candidate iff !flag && dx*dx+dy*dy < r2 (f32, strict) [mode 0] or |band| row test [mode 1].
+ * All pointers are DEVICE pointers; out: B x M x 4 int32 (idx1,d1,idx2,d2; -1/INT_MAX when absent).
+ * Returns the kernel's elapsed time in microseconds (HIP events on `stream`), <0 on error. */
+LVT_API float lvt_amd_hamming_match_batched(const void *q_desc, const void *q_xy, const void *t_desc,
+                                            const void *t_xy, const void *t_flag, int B, int M, int N,
+                                            float r2, int mode, int img_rows, int img_cols, void *out,
+                                            void *hip_stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

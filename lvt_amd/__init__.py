@@ -1,0 +1,269 @@
+"""lvt_amd -- MI355X-native drop-in for the per-frame tracking hot path of SAR-Research-Lab/lvt.
+
+The product is the C-ABI shared library `lvt_amd/lib/liblvt_c.so` (hand-written gfx950 HIP kernels
+behind the reference's own `lvt_c` boundary, see include/lvt_c.h).  This module is the thin Python
+mirror of the reference's `lvt_system` interface (lvt/src/lvt_system.h:57-70) used by the tests and
+bench harness: same operation names, same argument meaning, same "silent failure" semantics.
+
+There is NO CPU fallback: importing works anywhere (so the CPU test tier can check the exported symbols),
+but creating a system without the HIP library or without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .params import LvtParameters, ParamsPOD, kitti_params, euroc_params, tum_params  # noqa: F401
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblvt_c.so")
+
+# every symbol include/lvt_c.h and include/lvt_amd_ext.h declare
+ABI_SYMBOLS = [
+    "lvt_create", "lvt_destroy", "lvt_track", "lvt_track_with_external_corners", "lvt_get_status",
+    "lvt_amd_default_params", "lvt_amd_params_from_file", "lvt_amd_create", "lvt_amd_reset",
+    "lvt_amd_track_rgbd", "lvt_amd_track_device", "lvt_amd_track_device_async", "lvt_amd_wait",
+    "lvt_amd_set_stream", "lvt_amd_last_error", "lvt_amd_get_counts", "lvt_amd_get_features",
+    "lvt_amd_get_matches", "lvt_amd_get_row_matches", "lvt_amd_get_map", "lvt_amd_get_staged",
+    "lvt_amd_get_pose", "lvt_amd_get_predicted_pose", "lvt_amd_get_plane", "lvt_amd_pnp",
+    "lvt_amd_hamming_match_batched",
+]
+
+N_COUNTS = 32
+COUNT_NAMES = ["n_left", "n_right", "map_size", "staged_size", "n_matches", "second_pass", "n_row_matches",
+               "n_triangulated", "triangulated", "retry_left", "retry_right", "pnp_iters", "pnp_inliers",
+               "map_size_at_match", "n_staged_erased", "n_staged_promoted", "n_culled", "frame", "overflow"]
+
+eState_NOT_INITIALIZED, eState_TRACKING, eState_LOST = 1, 2, 3
+eSensor_STEREO, eSensor_RGBD = 1, 2
+
+_lib = None
+
+
+def load_library():
+    """dlopen the HIP library; raises (loudly) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C lvt_amd/csrc` "
+                           "(there is no CPU fallback for the tracking path)")
+    L = C.CDLL(LIB_PATH)
+    vp = C.c_void_p
+    L.lvt_create.restype = vp
+    L.lvt_create.argtypes = [C.c_char_p, C.c_int]
+    L.lvt_amd_create.restype = vp
+    L.lvt_amd_create.argtypes = [vp, C.c_int]
+    L.lvt_destroy.argtypes = [vp]
+    L.lvt_amd_reset.argtypes = [vp]
+    L.lvt_track.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
+    L.lvt_track_with_external_corners.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, C.c_int, vp, C.c_int, vp, vp]
+    L.lvt_get_status.argtypes = [vp]
+    L.lvt_amd_params_from_file.argtypes = [C.c_char_p, vp]
+    L.lvt_amd_default_params.argtypes = [vp]
+    L.lvt_amd_track_rgbd.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
+    L.lvt_amd_track_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.lvt_amd_track_device_async.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int]
+    L.lvt_amd_wait.argtypes = [vp, vp, vp]
+    L.lvt_amd_set_stream.argtypes = [vp, vp]
+    L.lvt_amd_last_error.restype = C.c_char_p
+    L.lvt_amd_last_error.argtypes = [vp]
+    L.lvt_amd_get_counts.argtypes = [vp, vp]
+    L.lvt_amd_get_features.argtypes = [vp, C.c_int, vp, vp, vp, C.c_int]
+    L.lvt_amd_get_matches.argtypes = [vp, vp, vp, C.c_int]
+    L.lvt_amd_get_row_matches.argtypes = [vp, vp, C.c_int]
+    L.lvt_amd_get_map.argtypes = [vp, vp, vp, vp, vp, C.c_int]
+    L.lvt_amd_get_staged.argtypes = [vp, vp, vp, vp, C.c_int]
+    L.lvt_amd_get_pose.argtypes = [vp, vp, vp]
+    L.lvt_amd_get_predicted_pose.argtypes = [vp, vp, vp]
+    L.lvt_amd_get_plane.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp]
+    L.lvt_amd_pnp.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]
+    L.lvt_amd_hamming_match_batched.restype = C.c_float
+    L.lvt_amd_hamming_match_batched.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp]
+    _lib = L
+    return L
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _u8(img):
+    a = np.ascontiguousarray(img, dtype=np.uint8)
+    assert a.ndim == 2
+    return a
+
+
+class LvtSystem:
+    """Mirror of `lvt_system` (reference lvt/src/lvt_system.h:41-109) over the HIP C-ABI."""
+
+    def __init__(self, handle, sensor_type):
+        self._h = handle
+        self._sensor = sensor_type
+
+    # lvt_system::create(const lvt_parameters&, eSensor)  -- lvt_system.cpp:70-127
+    @classmethod
+    def create(cls, params: LvtParameters, sensor_type: int = eSensor_STEREO) -> "LvtSystem":
+        L = load_library()
+        pod = params.to_pod()
+        h = L.lvt_amd_create(C.byref(pod), sensor_type)
+        if not h:
+            raise RuntimeError("lvt_amd_create failed (bad parameters, or no usable HIP device -- no CPU fallback)")
+        return cls(h, sensor_type)
+
+    # lvt_create(config_file, sensor)  -- lvt_c.cpp:33-48
+    @classmethod
+    def create_from_file(cls, config_file: str, sensor_type: int = eSensor_STEREO) -> "LvtSystem":
+        L = load_library()
+        h = L.lvt_create(config_file.encode(), sensor_type)
+        if not h:
+            raise RuntimeError("lvt_create returned NULL")
+        return cls(h, sensor_type)
+
+    @staticmethod
+    def destroy(system: "LvtSystem"):
+        system.close()
+
+    def close(self):
+        if self._h:
+            load_library().lvt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def reset(self):
+        load_library().lvt_amd_reset(self._h)
+
+    def get_sensor_type(self):
+        return self._sensor
+
+    def get_state(self):
+        return load_library().lvt_get_status(self._h)
+
+    def last_error(self) -> str:
+        return load_library().lvt_amd_last_error(self._h).decode()
+
+    # lvt_system::track(img1, img2)  -- lvt_system.cpp:157-207
+    def track(self, img1, img2):
+        R = np.zeros((3, 3)); t = np.zeros(3)
+        a = _u8(img1)
+        if self._sensor == eSensor_STEREO:
+            b = _u8(img2)
+            load_library().lvt_track(self._h, _p(a), _p(b), a.shape[0], a.shape[1], _p(R), _p(t))
+        else:
+            d = np.ascontiguousarray(img2, dtype=np.float32)
+            load_library().lvt_amd_track_rgbd(self._h, _p(a), _p(d), a.shape[0], a.shape[1], _p(R), _p(t))
+        return R, t
+
+    # lvt_system::track_with_external_corners  -- lvt_system.cpp:209-250
+    def track_with_external_corners(self, left, right, corners_left, corners_right):
+        R = np.zeros((3, 3)); t = np.zeros(3)
+        a, b = _u8(left), _u8(right)
+        cl = np.ascontiguousarray(corners_left, dtype=np.float64).reshape(-1, 2)
+        cr = np.ascontiguousarray(corners_right, dtype=np.float64).reshape(-1, 2)
+        load_library().lvt_track_with_external_corners(self._h, _p(a), _p(b), a.shape[0], a.shape[1], _p(cl), len(cl),
+                                                       _p(cr), len(cr), _p(R), _p(t))
+        return R, t
+
+    # zero-copy: images already resident in HBM (torch uint8 CUDA tensors or raw device pointers)
+    def track_device(self, d_left: int, d_right: int, rows: int, cols: int, pitch: int):
+        R = np.zeros((3, 3)); t = np.zeros(3)
+        load_library().lvt_amd_track_device(self._h, C.c_void_p(d_left), C.c_void_p(d_right), rows, cols, pitch, _p(R), _p(t))
+        return R, t
+
+    def track_device_async(self, d_left: int, d_right: int, rows: int, cols: int, pitch: int):
+        load_library().lvt_amd_track_device_async(self._h, C.c_void_p(d_left), C.c_void_p(d_right), rows, cols, pitch)
+
+    def wait(self):
+        R = np.zeros((3, 3)); t = np.zeros(3)
+        load_library().lvt_amd_wait(self._h, _p(R), _p(t))
+        return R, t
+
+    def set_stream(self, hip_stream: int):
+        load_library().lvt_amd_set_stream(self._h, C.c_void_p(hip_stream))
+
+    # ---- introspection (same shapes as oracle.pyoracle.Oracle) ----
+    def counts(self):
+        a = np.zeros(N_COUNTS, dtype=np.int32)
+        load_library().lvt_amd_get_counts(self._h, _p(a))
+        return {n: int(a[i]) for i, n in enumerate(COUNT_NAMES)}
+
+    def features(self, eye=0, cap=16384):
+        xy = np.zeros((cap, 2), np.float32); resp = np.zeros(cap, np.float32); desc = np.zeros((cap, 32), np.uint8)
+        n = load_library().lvt_amd_get_features(self._h, eye, _p(xy), _p(resp), _p(desc), cap)
+        return xy[:n].copy(), resp[:n].copy(), desc[:n].copy()
+
+    def matches(self, cap=65536):
+        fi = np.zeros(cap, np.int32); xyz = np.zeros((cap, 3), np.float64)
+        n = load_library().lvt_amd_get_matches(self._h, _p(fi), _p(xyz), cap)
+        return fi[:n].copy(), xyz[:n].copy()
+
+    def row_matches(self, cap=16384):
+        pr = np.zeros((cap, 2), np.int32)
+        n = load_library().lvt_amd_get_row_matches(self._h, _p(pr), cap)
+        return pr[:n].copy()
+
+    def map(self, cap=65536):
+        xyz = np.zeros((cap, 3)); cnt = np.zeros(cap, np.int32); age = np.zeros(cap, np.int32); desc = np.zeros((cap, 32), np.uint8)
+        n = load_library().lvt_amd_get_map(self._h, _p(xyz), _p(cnt), _p(age), _p(desc), cap)
+        return xyz[:n].copy(), cnt[:n].copy(), age[:n].copy(), desc[:n].copy()
+
+    def staged(self, cap=65536):
+        xyz = np.zeros((cap, 3)); cnt = np.zeros(cap, np.int32); desc = np.zeros((cap, 32), np.uint8)
+        n = load_library().lvt_amd_get_staged(self._h, _p(xyz), _p(cnt), _p(desc), cap)
+        return xyz[:n].copy(), cnt[:n].copy(), desc[:n].copy()
+
+    def pose(self):
+        q = np.zeros(4); p = np.zeros(3)
+        load_library().lvt_amd_get_pose(self._h, _p(q), _p(p))
+        return q, p
+
+    def predicted_pose(self):
+        q = np.zeros(4); p = np.zeros(3)
+        load_library().lvt_amd_get_predicted_pose(self._h, _p(q), _p(p))
+        return q, p
+
+    def plane(self, eye=0, what=0):
+        """what=0: corner score map (u8), what=1: 9x9 box sums (u16); returns (rows, pitch) array"""
+        cap = 64 << 20
+        buf = np.zeros(cap // 8, dtype=np.uint64)
+        pitch = C.c_int(0)
+        nbytes = load_library().lvt_amd_get_plane(self._h, eye, what, _p(buf), cap, C.byref(pitch))
+        if nbytes < 0:
+            raise RuntimeError("lvt_amd_get_plane failed")
+        raw = buf.view(np.uint8)[:nbytes]
+        a = raw.view(np.uint8 if what == 0 else np.uint16)
+        return a.reshape(-1, pitch.value).copy()
+
+
+def pnp(params: LvtParameters, q_in, p_in, pts, obs):
+    """stage entry: motion-only BA on caller data (reference lvt_pnp_solver.cpp:60-128)"""
+    L = load_library()
+    pod = params.to_pod()
+    q_in = np.ascontiguousarray(q_in, np.float64); p_in = np.ascontiguousarray(p_in, np.float64)
+    pts = np.ascontiguousarray(pts, np.float64); obs = np.ascontiguousarray(obs, np.float32)
+    q = np.zeros(4); p = np.zeros(3); calls = C.c_int(0)
+    inl = L.lvt_amd_pnp(C.byref(pod), _p(q_in), _p(p_in), _p(pts), _p(obs), len(pts), _p(q), _p(p), C.byref(calls))
+    if inl < 0:
+        raise RuntimeError("lvt_amd_pnp failed")
+    return q, p, inl, calls.value
+
+
+def hamming_match_batched(q_desc, q_xy, t_desc, t_xy, t_flag, r2: float, mode: int, img_rows: int, img_cols: int, out, stream: int = 0):
+    """Batched masked 2-NN Hamming matcher on DEVICE tensors (torch): q_desc (B,M,32) u8, q_xy (B,M,2) f32,
+    t_desc (B,N,32) u8, t_xy (B,N,2) f32, t_flag (B,N) u8, out (B,M,4) i32.  Returns kernel time in us."""
+    L = load_library()
+    B, M = q_desc.shape[0], q_desc.shape[1]
+    N = t_desc.shape[1]
+    us = L.lvt_amd_hamming_match_batched(C.c_void_p(q_desc.data_ptr()), C.c_void_p(q_xy.data_ptr()), C.c_void_p(t_desc.data_ptr()),
+                                         C.c_void_p(t_xy.data_ptr()), C.c_void_p(t_flag.data_ptr()), B, M, N, float(r2), int(mode),
+                                         int(img_rows), int(img_cols), C.c_void_p(out.data_ptr()), C.c_void_p(stream))
+    if us < 0:
+        raise RuntimeError("lvt_amd_hamming_match_batched failed")
+    return us

@@ -1,0 +1,802 @@
+// k_features.hip -- per-frame feature extraction on gfx950:
+//   k_begin   : frame prologue + device-side state machine head (lvt_system.cpp:157-167,196-197)
+//   k_score   : OAST-9/16 corner score map + 9x9 box-sum map, one coalesced pass over the image rows
+//   k_cells   : per detection cell: raster compaction, AGAST NMS, LVT's ANMS (handler.cpp:34-83,131-154)
+//   k_gather  : concatenate cells, BRIEF border filter, RGB-D depth filter (handler.cpp:156-176,227-300)
+//   k_brief   : BRIEF-256, one wavefront per key point
+// Integer stages are bit-exact restatements; see DESIGN.md for the layout and roofline of each kernel.
+#include "lvt_dev.h"
+#include "lvt_math.h"
+
+namespace lvt {
+
+__constant__ signed char c_brief[256][4] = {
+#include "../../include/lvt_brief256_pattern.inc"
+};
+
+// =================================================================================================
+// k_begin
+// =================================================================================================
+__global__ void k_begin(Seq *seqs, int ext_corners, int n_ext_l, int n_ext_r) {
+    Seq &S = seqs[blockIdx.x];
+    if (threadIdx.x != 0) return;
+    Ctl &c = *S.ctl;
+    for (int i = 0; i < N_COUNTS; i++) c.counts[i] = 0;
+    c.counts[C_FRAME] = c.frame_number;
+    c.frame_number++;
+    c.active = (c.state != 3);
+    c.first_frame = (c.state == 1);
+    c.ext_corners = ext_corners;
+    c.n_ext[0] = n_ext_l;
+    c.n_ext[1] = n_ext_r;
+    c.n_detected[0] = c.n_detected[1] = 0;
+    c.retry[0] = c.retry[1] = 0;
+    c.do_pass2 = 0;
+    c.n_pass1 = c.n_pass2 = 0;
+    c.n_matches = 0;
+    c.lost_now = 0;
+    c.need_tri = 0;
+    c.dont_stage = 0;
+    c.n_pairs = 0;
+    c.overflow = 0;
+    if (!c.active) {  // LOST: return the last pose forever (lvt_system.cpp:161-166)
+        pose_to_Rt(c.last_pose, c.out_R, c.out_t);
+        c.out_status = 3;
+        return;
+    }
+    if (!c.first_frame) {  // lvt_system.cpp:197 -> lvt_motion_model.cpp:42-65
+        motion_predict(c, c.last_pose, c.predicted);
+    }
+}
+
+// =================================================================================================
+// k_score : OAST-9/16 score + 9x9 box sums, tile 64x16, halo 4
+// =================================================================================================
+constexpr int TS_W = 64, TS_H = 16, HALO = 4;
+constexpr int TILE_W = TS_W + 2 * HALO;   // 72
+constexpr int TILE_H = TS_H + 2 * HALO;   // 24
+
+__device__ __forceinline__ int oast9_score(int p, const int r[16]) {
+    // score = max{b : 9 contiguous ring pixels all > p+b or all < p-b} = max_arc min(+-d) - 1
+    int d[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) d[i] = r[i] - p;
+    int mn2[16], mx2[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        mn2[i] = min(d[i], d[(i + 1) & 15]);
+        mx2[i] = max(d[i], d[(i + 1) & 15]);
+    }
+    int mn4[16], mx4[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        mn4[i] = min(mn2[i], mn2[(i + 2) & 15]);
+        mx4[i] = max(mx2[i], mx2[(i + 2) & 15]);
+    }
+    int best_b = -1000, best_d = 1000;  // best_d = min over arcs of max(d)  (dark score = -best_d)
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        int mn9 = min(min(mn4[i], mn4[(i + 4) & 15]), d[(i + 8) & 15]);
+        int mx9 = max(max(mx4[i], mx4[(i + 4) & 15]), d[(i + 8) & 15]);
+        best_b = max(best_b, mn9);
+        best_d = min(best_d, mx9);
+    }
+    int best = max(max(best_b, -best_d), 0);
+    return best - 1;
+}
+
+__global__ __launch_bounds__(256) void k_score(Seq *seqs) {
+    const int seq = blockIdx.z >> 1, eye = blockIdx.z & 1;
+    Seq &S = seqs[seq];
+    if (!S.ctl->active) return;
+    if (eye == 1 && S.prm.sensor == 2) return;
+    const int W = S.prm.W, H = S.prm.H;
+    const int x0 = blockIdx.x * TS_W, y0 = blockIdx.y * TS_H;
+    if (x0 >= W || y0 >= H) return;
+    const uint8_t *img = S.img[eye];
+    const int pitch = S.img_pitch;
+
+    __shared__ __attribute__((aligned(16))) uint8_t tile[TILE_H][TILE_W];
+    __shared__ uint16_t hs[TILE_H][TS_W];
+
+    const int tid = threadIdx.x;
+    // ---- load tile + halo as 32-bit words (rows are 4-byte aligned: x0 % 64 == 0, pitch % 16 == 0)
+    for (int idx = tid; idx < TILE_H * (TILE_W / 4); idx += 256) {
+        const int r = idx / (TILE_W / 4), wc = idx % (TILE_W / 4);
+        const int gy = y0 - HALO + r, gx = x0 - HALO + 4 * wc;
+        uint32_t v = 0;
+        if (gy >= 0 && gy < H && gx >= 0 && gx < W) {
+            if (gx + 3 < pitch) {
+                v = *reinterpret_cast<const uint32_t *>(img + (size_t)gy * pitch + gx);
+            } else {
+                for (int b = 0; b < 4; b++)
+                    if (gx + b < pitch) v |= (uint32_t)img[(size_t)gy * pitch + gx + b] << (8 * b);
+            }
+            // zero everything right of the image (row padding is not image content)
+            if (gx + 3 >= W) {
+                const int keep = W - gx;  // 1..3 valid bytes
+                v &= (keep >= 4) ? 0xFFFFFFFFu : ((1u << (8 * keep)) - 1u);
+            }
+        }
+        *reinterpret_cast<uint32_t *>(&tile[r][4 * wc]) = v;
+    }
+    __syncthreads();
+    // ---- horizontal 9-sums
+    for (int idx = tid; idx < TILE_H * TS_W; idx += 256) {
+        const int r = idx >> 6, c = idx & 63;
+        int s = 0;
+#pragma unroll
+        for (int d = 0; d < 9; d++) s += tile[r][c + d];
+        hs[r][c] = (uint16_t)s;
+    }
+    // ---- corner score of 4 horizontally adjacent pixels per thread
+    const int tx = tid & 15, ty = tid >> 4;
+    const int gy = y0 + ty;
+    const int cs = S.prm.cell_size;
+    const int t_low = S.prm.agast_th_low;
+    uint32_t packed = 0;
+    if (gy < H) {
+        const int cy = gy / cs, ly = gy - cy * cs, ch = min(cs, H - cy * cs);
+        const bool vy = (ly >= 3) && (ly <= ch - 4);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int gx = x0 + 4 * tx + k;
+            int sc = 0;
+            if (vy && gx < W) {
+                const int cx = gx / cs, lx = gx - cx * cs, cw = min(cs, W - cx * cs);
+                if (lx >= 3 && lx <= cw - 4) {
+                    const int r0 = ty + HALO, c0 = 4 * tx + k + HALO;
+                    const int p = tile[r0][c0];
+                    // quick reject: every 9-arc contains one pixel of each opposite pair
+                    const int a0 = tile[r0][c0 - 3], a8 = tile[r0][c0 + 3];
+                    const int a4 = tile[r0 - 3][c0], a12 = tile[r0 + 3][c0];
+                    const int cb = p + t_low, c_b = p - t_low;
+                    const bool br = (a0 > cb || a8 > cb) && (a4 > cb || a12 > cb);
+                    const bool dk = (a0 < c_b || a8 < c_b) && (a4 < c_b || a12 < c_b);
+                    if (br || dk) {
+                        int r[16];
+                        r[0] = a0;
+                        r[1] = tile[r0 - 1][c0 - 3];
+                        r[2] = tile[r0 - 2][c0 - 2];
+                        r[3] = tile[r0 - 3][c0 - 1];
+                        r[4] = a4;
+                        r[5] = tile[r0 - 3][c0 + 1];
+                        r[6] = tile[r0 - 2][c0 + 2];
+                        r[7] = tile[r0 - 1][c0 + 3];
+                        r[8] = a8;
+                        r[9] = tile[r0 + 1][c0 + 3];
+                        r[10] = tile[r0 + 2][c0 + 2];
+                        r[11] = tile[r0 + 3][c0 + 1];
+                        r[12] = a12;
+                        r[13] = tile[r0 + 3][c0 - 1];
+                        r[14] = tile[r0 + 2][c0 - 2];
+                        r[15] = tile[r0 + 1][c0 - 3];
+                        const int s = oast9_score(p, r);
+                        sc = (s >= t_low) ? s : 0;
+                    }
+                }
+            }
+            packed |= (uint32_t)sc << (8 * k);
+        }
+    }
+    __syncthreads();  // hs complete
+    if (gy < H) {
+        const int pp = S.plane_pitch;
+        *reinterpret_cast<uint32_t *>(S.score[eye] + (size_t)gy * pp + x0 + 4 * tx) = packed;
+        uint16_t b[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int s = 0;
+#pragma unroll
+            for (int d = 0; d < 9; d++) s += hs[ty + d][4 * tx + k];
+            b[k] = (uint16_t)s;
+        }
+        uint2 o;
+        o.x = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
+        o.y = (uint32_t)b[2] | ((uint32_t)b[3] << 16);
+        *reinterpret_cast<uint2 *>(S.boxsum[eye] + (size_t)gy * pp + x0 + 4 * tx) = o;
+    }
+}
+
+// =================================================================================================
+// k_cells : one 1024-thread workgroup per (cell, eye, sequence)
+// =================================================================================================
+// raw-corner key: (ly << 18) | (lx << 8) | score    (cell-local coords < 1024, score <= 254)
+__device__ __forceinline__ uint32_t mk_key(int ly, int lx, int s) { return ((uint32_t)ly << 18) | ((uint32_t)lx << 8) | (uint32_t)s; }
+__device__ __forceinline__ int key_y(uint32_t k) { return (int)(k >> 18); }
+__device__ __forceinline__ int key_x(uint32_t k) { return (int)((k >> 8) & 1023); }
+__device__ __forceinline__ int key_r(uint32_t k) { return (int)(k & 255); }
+__device__ __forceinline__ uint32_t key_pos(uint32_t k) { return k >> 8; }
+
+constexpr uint32_t NONE14 = 0x3FFFu;
+constexpr uint16_t NMS_MAX = 0xFFFFu;  // "is a maximum" (== -1 of the reference's nmsFlags)
+
+// ---- libstdc++ std::sort emulation pieces (comp(a,b) := resp(a) > resp(b); handler.cpp:38-41) ----
+__device__ __forceinline__ bool scomp(uint32_t a, uint32_t b) { return key_r(a) > key_r(b); }
+
+// heap fallback of introsort (std::__partial_sort(first,last,last)), sequential, one lane
+__device__ void heap_adjust(uint32_t *f, int hole, int len, uint32_t value) {
+    const int top = hole;
+    int child = hole;
+    while (child < (len - 1) / 2) {
+        child = 2 * (child + 1);
+        if (scomp(f[child], f[child - 1])) child--;
+        f[hole] = f[child];
+        hole = child;
+    }
+    if ((len & 1) == 0 && child == (len - 2) / 2) {
+        child = 2 * (child + 1);
+        f[hole] = f[child - 1];
+        hole = child - 1;
+    }
+    int parent = (hole - 1) / 2;
+    while (hole > top && scomp(f[parent], value)) {
+        f[hole] = f[parent];
+        hole = parent;
+        parent = (hole - 1) / 2;
+    }
+    f[hole] = value;
+}
+__device__ void heap_sort_seq(uint32_t *f, int len) {
+    if (len >= 2) {
+        int parent = (len - 2) / 2;
+        while (true) {
+            uint32_t v = f[parent];
+            heap_adjust(f, parent, len, v);
+            if (parent == 0) break;
+            parent--;
+        }
+    }
+    int last = len;
+    while (last > 1) {
+        --last;
+        uint32_t v = f[last];
+        f[last] = f[0];
+        heap_adjust(f, 0, last, v);
+    }
+}
+
+// std::__unguarded_partition_pivot on arr[first,last) executed by ONE full wavefront.
+// Hoare partition evaluated with ballots: the k-th "left stop" (ascending) swaps with the k-th
+// "right stop" (descending) while they have not crossed (see DESIGN.md "std::sort emulation").
+__device__ int wave_partition_pivot(uint32_t *arr, int first, int last, uint16_t *posL, uint16_t *posR) {
+    const int lane = lane_id();
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const int mid = first + (last - first) / 2;
+    if (lane == 0) {  // std::__move_median_to_first(first, first+1, mid, last-1)
+        const int a = first + 1, b = mid, c = last - 1;
+        const uint32_t va = arr[a], vb = arr[b], vc = arr[c];
+        int pick;
+        if (scomp(va, vb)) {
+            if (scomp(vb, vc)) pick = b;
+            else if (scomp(va, vc)) pick = c;
+            else pick = a;
+        } else if (scomp(va, vc)) pick = a;
+        else if (scomp(vb, vc)) pick = c;
+        else pick = b;
+        const uint32_t t = arr[first];
+        arr[first] = arr[pick];
+        arr[pick] = t;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    const int piv = key_r(arr[first]);
+    const int lo = first + 1, hi = last;
+    int cntL = 0, cntR = 0;
+    for (int base = lo; base < hi; base += 64) {
+        const int p = base + lane;
+        const bool isL = (p < hi) && !(key_r(arr[p]) > piv);
+        const uint64_t m = __ballot(isL);
+        if (isL) posL[first + cntL + __popcll(m & lt_mask)] = (uint16_t)p;
+        cntL += __popcll(m);
+    }
+    for (int top = hi; top > lo; top -= 64) {
+        const int q = top - 1 - lane;
+        const bool isR = (q >= lo) && !(piv > key_r(arr[q]));
+        const uint64_t m = __ballot(isR);
+        if (isR) posR[first + cntR + __popcll(m & lt_mask)] = (uint16_t)q;
+        cntR += __popcll(m);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    const int K = min(cntL, cntR);
+    int m = 0;
+    for (int base = 0; base < K; base += 64) {
+        const int k = base + lane;
+        const bool ok = (k < K) && (posL[first + k] < posR[first + k]);
+        const uint64_t b = __ballot(ok);
+        m += __popcll(b);
+        if (b != ~0ull) break;  // monotone: once a pair has crossed, all later ones have
+    }
+    for (int k = lane; k < m; k += 64) {
+        const int p = posL[first + k], q = posR[first + k];
+        const uint32_t t = arr[p];
+        arr[p] = arr[q];
+        arr[q] = t;
+    }
+    const int pm = (m < cntL) ? (int)posL[first + m] : 0x7FFFFFFF;
+    const int qm1 = (m > 0) ? (int)posR[first + m - 1] : last;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    return min(pm, qm1);
+}
+
+// std::__introsort_loop on arr[0,n): partitions only; the final insertion sort is a stable sort and
+// is done afterwards by ranking.  ONE wavefront; `stack` = 3*64 ints of LDS.
+__device__ void wave_introsort_partitions(uint32_t *arr, int n, uint16_t *posL, uint16_t *posR, int *stack) {
+    if (n <= 16) return;
+    int depth0 = 0;
+    for (int v = n; v > 1; v >>= 1) depth0++;
+    depth0 *= 2;
+    int sp = 0;
+    int first = 0, last = n, depth = depth0;
+    while (true) {
+        while (last - first > 16) {
+            if (depth == 0) {
+                if (lane_id() == 0) heap_sort_seq(arr + first, last - first);
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                break;
+            }
+            --depth;
+            const int cut = wave_partition_pivot(arr, first, last, posL, posR);
+            if (last - cut > 16) {  // the recursive call introsort_loop(cut, last, depth)
+                if (lane_id() == 0) {
+                    stack[3 * sp] = cut;
+                    stack[3 * sp + 1] = last;
+                    stack[3 * sp + 2] = depth;
+                }
+                sp++;
+            }
+            last = cut;
+        }
+        if (sp == 0) break;
+        sp--;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        first = stack[3 * sp];
+        last = stack[3 * sp + 1];
+        depth = stack[3 * sp + 2];
+    }
+}
+
+// LDS carve (bytes): keys 4*RAW | uf 4*RAW | root16 2*RAW | abv16 2*RAW | nms16 2*RAW | misc
+constexpr int CELLS_LDS_BYTES = RAW_CAP * 14 + 2 * 1024 * 2 + 64 * 4 + 3 * 64 * 4 + 64;
+
+__device__ __forceinline__ int uf_find(volatile uint32_t *parent, int i) {
+    while (true) {
+        const int p = (int)parent[i];
+        if (p == i) return i;
+        i = p;
+    }
+}
+
+__global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass) {
+    Seq &S = seqs[blockIdx.z];
+    const int eye = blockIdx.y, cell = blockIdx.x;
+    const Ctl &ctl = *S.ctl;
+    if (!ctl.active || ctl.ext_corners) return;
+    if (eye == 1 && S.prm.sensor == 2) return;
+    if (cell >= S.prm.n_cells) return;
+    int threshold = S.prm.agast_th;
+    if (pass == 1) {
+        if (ctl.n_detected[eye] >= CORNERS_LOW_TH) return;  // handler.cpp:161
+        threshold = S.prm.agast_th_low;
+    }
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *keys = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *uf = keys + RAW_CAP;
+    uint16_t *root16 = reinterpret_cast<uint16_t *>(uf + RAW_CAP);
+    uint16_t *abv16 = root16 + RAW_CAP;
+    uint16_t *nms16 = abv16 + RAW_CAP;
+    uint16_t *row_first = nms16 + RAW_CAP;   // [1024]
+    uint16_t *row_end = row_first + 1024;    // [1024]
+    int *scan = reinterpret_cast<int *>(row_end + 1024);  // [64]
+    int *stack = scan + 64;                  // [192]
+    int *misc = stack + 192;                 // [16]
+
+    const int tid = threadIdx.x;
+    const int cs = S.prm.cell_size;
+    const int cxi = cell % S.prm.cells_x, cyi = cell / S.prm.cells_x;
+    const int X0 = cxi * cs, Y0 = cyi * cs;
+    const int cw = min(cs, S.prm.W - X0), ch = min(cs, S.prm.H - Y0);
+    const uint8_t *score = S.score[eye];
+    const int pp = S.plane_pitch;
+
+    // ---------------- phase 1: raster-order compaction of raw corners (score >= threshold)
+    for (int i = tid; i < 1024; i += 1024) {
+        row_first[i] = 0xFFFF;
+        row_end[i] = 0;
+    }
+    int n_raw = 0;
+    bool ovf = false;
+    if (cw >= 7 && ch >= 7 && cw <= 1024 && ch <= 1024) {
+        const int xa = X0 + 3, xb = X0 + cw - 4;  // inclusive pixel range
+        const int c0 = xa >> 4, c1 = xb >> 4;
+        const int nchunk = c1 - c0 + 1;
+        const int nrows = ch - 6;
+        const int items = nrows * nchunk;
+        for (int base = 0; base < items; base += 1024) {
+            const int it = base + tid;
+            uint4 v = make_uint4(0, 0, 0, 0);
+            int ly = 0, gx0 = 0;
+            if (it < items) {
+                ly = 3 + it / nchunk;
+                gx0 = (c0 + it % nchunk) << 4;
+                v = *reinterpret_cast<const uint4 *>(score + (size_t)(Y0 + ly) * pp + gx0);
+            }
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            int cnt = 0;
+            if (it < items) {
+#pragma unroll
+                for (int b = 0; b < 16; b++) {
+                    const int s = (w[b >> 2] >> (8 * (b & 3))) & 255;
+                    const int gx = gx0 + b;
+                    cnt += (s >= threshold && gx >= xa && gx <= xb) ? 1 : 0;
+                }
+            }
+            int total;
+            int off = n_raw + block_excl_scan(cnt, scan, &total);
+            if (it < items && cnt) {
+#pragma unroll
+                for (int b = 0; b < 16; b++) {
+                    const int s = (w[b >> 2] >> (8 * (b & 3))) & 255;
+                    const int gx = gx0 + b;
+                    if (s >= threshold && gx >= xa && gx <= xb) {
+                        if (off < RAW_CAP) keys[off] = mk_key(ly, gx - X0, s);
+                        off++;
+                    }
+                }
+            }
+            n_raw += total;
+        }
+        if (n_raw > RAW_CAP) {
+            ovf = true;
+            n_raw = RAW_CAP;
+        }
+    } else if (cw > 1024 || ch > 1024) {
+        if (tid == 0) atomicOr(&S.ctl->overflow, OVF_CELL_DIM);
+    }
+    if (ovf && tid == 0) atomicOr(&S.ctl->overflow, OVF_RAW);
+    __syncthreads();
+
+    // ---------------- phase 2: neighbour links, union-find over 4-connected corner pixels
+    for (int i = tid; i < n_raw; i += 1024) {
+        const int y = key_y(keys[i]);
+        if (i == 0 || key_y(keys[i - 1]) != y) row_first[y] = (uint16_t)i;
+        if (i == n_raw - 1 || key_y(keys[i + 1]) != y) row_end[y] = (uint16_t)(i + 1);
+        uf[i] = (uint32_t)i;
+        nms16[i] = NMS_MAX;
+    }
+    __syncthreads();
+    for (int i = tid; i < n_raw; i += 1024) {
+        const uint32_t k = keys[i];
+        const int y = key_y(k), x = key_x(k);
+        const bool left = (i > 0) && (key_pos(keys[i - 1]) + 1 == key_pos(k));
+        uint32_t above = NONE14;
+        if (y > 0 && row_first[y - 1] != 0xFFFF) {
+            int lo = row_first[y - 1], hi = row_end[y - 1];  // [lo,hi)
+            while (lo < hi) {
+                const int m = (lo + hi) >> 1;
+                const int mx = key_x(keys[m]);
+                if (mx < x) lo = m + 1;
+                else hi = m;
+            }
+            if (lo < (int)row_end[y - 1] && key_x(keys[lo]) == x) above = (uint32_t)lo;
+        }
+        abv16[i] = (uint16_t)(above | (left ? 0x8000u : 0u));
+    }
+    __syncthreads();
+    for (int i = tid; i < n_raw; i += 1024) {
+        const uint16_t a = abv16[i];
+        int nb[2];
+        int nn = 0;
+        if (a & 0x8000u) nb[nn++] = i - 1;
+        if ((a & NONE14) != NONE14) nb[nn++] = (int)(a & NONE14);
+        for (int e = 0; e < nn; e++) {
+            int u = i, v = nb[e];
+            while (true) {
+                u = uf_find(uf, u);
+                v = uf_find(uf, v);
+                if (u == v) break;
+                if (u < v) {
+                    const int t = u;
+                    u = v;
+                    v = t;
+                }  // u > v : hang u under v
+                const uint32_t old = atomicMin(&uf[u], (uint32_t)v);
+                if (old == (uint32_t)u) break;
+                u = (int)old;
+            }
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n_raw; i += 1024) root16[i] = (uint16_t)uf_find(uf, i);
+    __syncthreads();
+    for (int i = tid; i < n_raw; i += 1024) uf[i] = (uint32_t)i;  // uf := "last member" per root
+    __syncthreads();
+    for (int i = tid; i < n_raw; i += 1024) {
+        const int r = root16[i];
+        if (r != i) atomicMax(&uf[r], (uint32_t)i);
+    }
+    __syncthreads();
+
+    // ---------------- phase 3: exact replay of AGAST's NMS sweep inside every multi-pixel component
+    for (int i = tid; i < n_raw; i += 1024) {
+        if (root16[i] != i) continue;
+        const int lastm = (int)uf[i];
+        if (lastm == i) continue;  // singleton: stays a maximum
+        for (int cur = i; cur <= lastm; cur++) {
+            if (root16[cur] != i) continue;
+            const uint16_t a = abv16[cur];
+            const int rc = key_r(keys[cur]);
+            if ((a & NONE14) != NONE14) {
+                int w = a & NONE14;
+                while (nms16[w] != NMS_MAX) w = nms16[w];
+                if (rc < key_r(keys[w])) nms16[cur] = (uint16_t)w;
+                else nms16[w] = (uint16_t)cur;
+            }
+            if (a & 0x8000u) {
+                int t = cur - 1;
+                const uint16_t above_root = nms16[cur];
+                while (nms16[t] != NMS_MAX) t = nms16[t];
+                if (above_root == NMS_MAX) {
+                    if (t != cur) {
+                        if (rc < key_r(keys[t])) nms16[cur] = (uint16_t)t;
+                        else nms16[t] = (uint16_t)cur;
+                    }
+                } else if (t != (int)above_root) {
+                    if (key_r(keys[above_root]) < key_r(keys[t])) {
+                        nms16[above_root] = (uint16_t)t;
+                        nms16[cur] = (uint16_t)t;
+                    } else {
+                        nms16[t] = above_root;
+                        nms16[cur] = above_root;
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+
+    // ---------------- phase 4: survivors, raster order -> arr (aliases uf)
+    uint32_t *arr = uf;
+    int n_kp = 0;
+    for (int base = 0; base < n_raw; base += 1024) {
+        const int i = base + tid;
+        const bool keep = (i < n_raw) && (nms16[i] == NMS_MAX);
+        const uint32_t k = keep ? keys[i] : 0;
+        int total;
+        const int off = n_kp + block_excl_scan(keep ? 1 : 0, scan, &total);
+        // arr aliases uf; every uf[] read of this round happened before the scan's barriers
+        if (keep) arr[off] = k;
+        n_kp += total;
+    }
+    __syncthreads();
+
+    // ---------------- phase 5: ANMS when the cell is too dense (handler.cpp:140-143, 34-83)
+    const int max_kp = S.prm.max_kp_cell;
+    float *out = S.cell_kp[eye] + (size_t)cell * CELL_OUT_CAP * 3;
+    int n_out = 0;
+    if (n_kp > max_kp) {
+        uint16_t *posL = root16;  // free after NMS
+        uint16_t *posR = abv16;
+        if (wave_id() == 0) wave_introsort_partitions(arr, n_kp, posL, posR, stack);
+        __syncthreads();
+        // final insertion sort == stable sort by response (descending): rank every element
+        uint32_t *sorted = keys;  // raw keys no longer needed
+        for (int i = tid; i < n_kp; i += 1024) {
+            const uint32_t k = arr[i];
+            const int r = key_r(k);
+            int rank = 0;
+            for (int j = 0; j < n_kp; j++) {
+                const int rj = key_r(arr[j]);
+                rank += (rj > r || (rj == r && j < i)) ? 1 : 0;
+            }
+            sorted[rank] = k;
+        }
+        __syncthreads();
+        // suppression radius^2 (integers: exact in the reference's float arithmetic too)
+        uint32_t *r2 = arr;  // arr consumed
+        for (int i = tid; i < n_kp; i += 1024) {
+            const uint32_t k = sorted[i];
+            const float response = (float)key_r(k) * 1.11f;
+            const int yi = key_y(k), xi = key_x(k);
+            uint32_t best = 0xFFFFFFFFu;
+            for (int j = 0; j < i; j++) {
+                const uint32_t kj = sorted[j];
+                if (!((float)key_r(kj) > response)) break;
+                const int dx = xi - key_x(kj), dy = yi - key_y(kj);
+                best = min(best, (uint32_t)(dx * dx + dy * dy));
+            }
+            r2[i] = best;
+        }
+        __syncthreads();
+        // decisionRadius = (max_kp)-th element (0-based) of the radii sorted descending
+        if (tid == 0) misc[0] = 0;
+        __syncthreads();
+        for (int i = tid; i < n_kp; i += 1024) {
+            const uint32_t v = r2[i];
+            int gt = 0, ge = 0;
+            for (int j = 0; j < n_kp; j++) {
+                const uint32_t vj = r2[j];
+                gt += (vj > v) ? 1 : 0;
+                ge += (vj >= v) ? 1 : 0;
+            }
+            if (gt <= max_kp && max_kp < ge) misc[0] = (int)v;  // all writers hold the same value
+        }
+        __syncthreads();
+        const uint32_t decision = (uint32_t)misc[0];
+        __syncthreads();
+        for (int base = 0; base < n_kp; base += 1024) {
+            const int i = base + tid;
+            const bool keep = (i < n_kp) && (r2[i] >= decision);
+            int total;
+            const int off = n_out + block_excl_scan(keep ? 1 : 0, scan, &total);
+            if (keep && off < CELL_OUT_CAP) {
+                const uint32_t k = sorted[i];
+                out[3 * off] = (float)key_x(k) + (float)X0;
+                out[3 * off + 1] = (float)key_y(k) + (float)Y0;
+                out[3 * off + 2] = (float)key_r(k);
+            }
+            n_out += total;
+        }
+    } else {
+        for (int i = tid; i < n_kp; i += 1024) {
+            if (i < CELL_OUT_CAP) {
+                const uint32_t k = arr[i];
+                out[3 * i] = (float)key_x(k) + (float)X0;
+                out[3 * i + 1] = (float)key_y(k) + (float)Y0;
+                out[3 * i + 2] = (float)key_r(k);
+            }
+        }
+        n_out = n_kp;
+    }
+    if (tid == 0) {
+        if (n_out > CELL_OUT_CAP) {
+            atomicOr(&S.ctl->overflow, OVF_CELL_OUT);
+            n_out = CELL_OUT_CAP;
+        }
+        S.cell_n[eye][cell] = n_out;
+        if (pass == 0) atomicAdd(&S.ctl->n_detected[eye], n_out);
+        else if (cell == 0) {
+            S.ctl->retry[eye] = 1;
+            S.ctl->counts[eye ? C_RETRY_RIGHT : C_RETRY_LEFT] = 1;
+        }
+    }
+}
+
+// =================================================================================================
+// k_gather : cells (rect order) -> feature struct, BRIEF border filter, RGB-D depth filter + undistort
+// =================================================================================================
+__device__ __forceinline__ bool brief_border_keep(float x, float y, int rows, int cols) {
+    const int B = 28;
+    if (rows <= 2 * B || cols <= 2 * B) return false;
+    const int ix = __float2int_rn(x), iy = __float2int_rn(y);  // cvRound
+    return ix >= B && ix < cols - B && iy >= B && iy < rows - B;
+}
+
+__global__ __launch_bounds__(1024) void k_gather(Seq *seqs) {
+    Seq &S = seqs[blockIdx.z];
+    const int eye = blockIdx.y;
+    Ctl &ctl = *S.ctl;
+    if (!ctl.active) return;
+    __shared__ int cell_off[CELLS_MAX + 1];
+    __shared__ int scan[32];
+    const int tid = threadIdx.x;
+    Feat &F = S.feat[eye];
+    if (eye == 1 && S.prm.sensor == 2) {
+        if (tid == 0) {
+            *F.n = 0;
+            ctl.counts[C_N_RIGHT] = 0;
+        }
+        return;
+    }
+    const int nc = ctl.ext_corners ? 1 : S.prm.n_cells;
+    if (tid == 0) {
+        int acc = 0;
+        for (int c = 0; c < nc; c++) {
+            cell_off[c] = acc;
+            acc += ctl.ext_corners ? ctl.n_ext[eye] : S.cell_n[eye][c];
+        }
+        cell_off[nc] = acc;
+    }
+    __syncthreads();
+    const int total_in = cell_off[nc];
+    const int W = S.prm.W, H = S.prm.H;
+    const bool rgbd = (S.prm.sensor == 2);
+    int n_out = 0;
+    for (int base = 0; base < total_in; base += 1024) {
+        const int g = base + tid;
+        bool keep = false;
+        float x = 0, y = 0, r = 0, ox = 0, oy = 0, dep = 0;
+        if (g < total_in) {
+            if (ctl.ext_corners) {
+                x = S.ext_xy[eye][2 * g];
+                y = S.ext_xy[eye][2 * g + 1];
+            } else {
+                int c = 0;
+                while (g >= cell_off[c + 1]) c++;
+                const float *kp = S.cell_kp[eye] + ((size_t)c * CELL_OUT_CAP + (g - cell_off[c])) * 3;
+                x = kp[0];
+                y = kp[1];
+                r = kp[2];
+            }
+            ox = x;
+            oy = y;
+            keep = brief_border_keep(x, y, H, W);
+            if (keep && rgbd) {  // handler.cpp:255-265 (depth at the distorted pixel), :268-294
+                dep = S.depth_img[(size_t)((int)y) * S.depth_pitch + (int)x];
+                keep = (dep >= S.prm.near_plane && dep <= S.prm.far_plane);
+                if (keep && S.prm.undistort) {
+                    undistort_point(S.prm, x, y, x, y);
+                    const int hy = (int)floorf(y / (float)HASH_CELL), hx = (int)floorf(x / (float)HASH_CELL);
+                    if (hy < 0 || hy >= S.prm.hash_ccy || hx < 0 || hx >= S.prm.hash_ccx) keep = false;
+                }
+            }
+        }
+        int total;
+        const int off = n_out + block_excl_scan(keep ? 1 : 0, scan, &total);
+        if (keep && off < NF_MAX) {
+            F.x[off] = x;
+            F.y[off] = y;
+            F.resp[off] = r;
+            F.bx[off] = ox;
+            F.by[off] = oy;
+            F.depth[off] = dep;
+            F.flag[off] = 0;
+            F.hcy[off] = (int16_t)floorf(y / (float)HASH_CELL);
+            F.hcx[off] = (int16_t)floorf(x / (float)HASH_CELL);
+        }
+        n_out += total;
+    }
+    if (tid == 0) {
+        if (n_out > NF_MAX) {
+            atomicOr(&ctl.overflow, OVF_FEATURES);
+            n_out = NF_MAX;
+        }
+        *F.n = n_out;
+        ctl.counts[eye ? C_N_RIGHT : C_N_LEFT] = n_out;
+    }
+}
+
+// =================================================================================================
+// k_brief : one wavefront per key point, lane l evaluates tests 4l..4l+3
+// =================================================================================================
+__device__ __forceinline__ int box_at(const Seq &S, int eye, int iy, int ix) {
+    const int W = S.prm.W, H = S.prm.H;
+    if (ix >= 0 && ix < W && iy >= 0 && iy < H) return S.boxsum[eye][(size_t)iy * S.plane_pitch + ix];
+    // centre outside the image (fractional external corners at the border only): clipped window
+    int s = 0;
+    for (int y = max(iy - 4, 0); y <= min(iy + 4, H - 1); y++)
+        for (int x = max(ix - 4, 0); x <= min(ix + 4, W - 1); x++) s += S.img[eye][(size_t)y * S.img_pitch + x];
+    return s;
+}
+
+__global__ __launch_bounds__(256) void k_brief(Seq *seqs) {
+    Seq &S = seqs[blockIdx.z];
+    const int eye = blockIdx.y;
+    if (!S.ctl->active) return;
+    Feat &F = S.feat[eye];
+    const int n = *F.n;
+    const int lane = lane_id();
+    const int wpb = blockDim.x >> 6;
+    for (int i = blockIdx.x * wpb + wave_id(); i < n; i += gridDim.x * wpb) {
+        const int cy = (int)((double)F.by[i] + 0.5), cx = (int)((double)F.bx[i] + 0.5);
+        int nib = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const signed char *t = c_brief[4 * lane + k];
+            const int a = box_at(S, eye, cy + t[0], cx + t[1]);
+            const int b = box_at(S, eye, cy + t[2], cx + t[3]);
+            nib |= (a < b ? 1 : 0) << (3 - k);
+        }
+        // byte j = nibble(lane 2j) << 4 | nibble(lane 2j+1); gather 8 bytes into one u64 per 16 lanes
+        const int hi = __shfl(nib, lane & ~1, 64), lo = __shfl(nib, lane | 1, 64);
+        const uint32_t byte = (uint32_t)((hi << 4) | lo);  // valid on every lane for byte index lane>>1
+        uint64_t word = 0;
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            const uint32_t v = __shfl(byte, ((lane >> 4) << 4) + 2 * b, 64);
+            word |= (uint64_t)(v & 255u) << (8 * b);
+        }
+        if ((lane & 15) == 0) F.desc[(size_t)i * 4 + (lane >> 4)] = word;
+    }
+}
+
+}  // namespace lvt

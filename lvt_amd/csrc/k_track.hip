@@ -1,0 +1,1098 @@
+// k_track.hip -- map<->frame matching, motion-only BA, map maintenance, stereo triangulation (gfx950).
+//
+//   k_project    : is_point_visible + projection of map / staged points        (lvt_local_map.cpp:62-82,152)
+//   k_candidates : masked Hamming candidate lists, one wavefront per query      (lvt_image_features_struct.cpp:68-148)
+//   k_resolve    : the order-dependent accept/mark pass of find_matches and row_match
+//                                                                               (lvt_local_map.cpp:146-199, handler.cpp:302-323)
+//   k_bookkeep   : counters / ages / PnP input, LOST decision                   (lvt_local_map.cpp:201-224, lvt_system.cpp:267-274)
+//   k_pnp        : g2o Levenberg-Marquardt, 2 passes x optimize(5), on device   (lvt_pnp_solver.cpp:60-128)
+//   k_cull       : clean_untracked_points                                       (lvt_local_map.cpp:393-413)
+//   k_staged     : update_staged_map_points + triangulation policy              (lvt_local_map.cpp:355-391, lvt_system.cpp:308-334)
+//   k_triangulate: linear-LS triangulation + gates, append to map / staged      (lvt_local_map.cpp:231-353)
+//   k_finalize   : first-frame epilogue, result record                          (lvt_system.cpp:185-193)
+//
+// The Hamming distance evaluation is parallel (k_candidates); only the accept/mark scan is sequential,
+// and it walks pre-sorted candidate lists so it touches a few words per query.
+#include "lvt_dev.h"
+#include "lvt_math.h"
+
+namespace lvt {
+
+enum : int { MODE_MAP = 0, MODE_STAGED = 1, MODE_ROW = 2 };
+
+// =================================================================================================
+// k_project
+// =================================================================================================
+__global__ __launch_bounds__(256) void k_project(Seq *seqs, int mode) {
+    Seq &S = seqs[blockIdx.z];
+    Ctl &ctl = *S.ctl;
+    if (!ctl.active || ctl.first_frame) return;
+    if (mode == MODE_STAGED && (ctl.lost_now || S.prm.staged_th <= 0)) return;
+    __shared__ double w2c[12];
+    if (threadIdx.x == 0) world_to_camera(mode == MODE_MAP ? ctl.predicted : ctl.optimized, w2c);
+    __syncthreads();
+    const int cur = (mode == MODE_MAP) ? *S.map_cur : *S.staged_cur;
+    const int M = (mode == MODE_MAP) ? *S.map_n : *S.staged_n;
+    MapSoA &P = (mode == MODE_MAP) ? S.map[cur] : S.staged[cur];
+    float *proj = (mode == MODE_MAP) ? S.proj : S.sproj;
+    int8_t *vis = (mode == MODE_MAP) ? S.vis : S.svis;
+    if (mode == MODE_MAP && blockIdx.x == 0 && threadIdx.x == 0) ctl.counts[C_MAP_SIZE_AT_MATCH] = M;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
+        const double X[3] = {P.pos[3 * i], P.pos[3 * i + 1], P.pos[3 * i + 2]};
+        double u, v;
+        if (is_point_visible(X, w2c, S.prm, u, v)) {
+            proj[2 * i] = (float)u;
+            proj[2 * i + 1] = (float)v;
+            vis[i] = 1;
+            if (mode == MODE_MAP) S.match[i] = -1;
+        } else {
+            vis[i] = 0;
+            if (mode == MODE_MAP) {
+                P.counter[i] += 1;  // lvt_local_map.cpp:154
+                S.match[i] = -2;
+            }
+        }
+    }
+}
+
+// =================================================================================================
+// candidate predicate shared by k_candidates and the exact slow path of the resolvers
+// =================================================================================================
+struct Query {
+    float x, y;
+    int sy, ey, sx, ex;   // hash-cell window (tracking)  /  [sy, ey] row band (row matching)
+    float r2;
+    uint64_t d[4];
+};
+
+__device__ __forceinline__ void make_query_track(const Params &p, float x, float y, int radius, Query &q) {
+    q.x = x;
+    q.y = y;
+    const int hy = (int)floorf(y / (float)HASH_CELL), hx = (int)floorf(x / (float)HASH_CELL);
+    q.sy = max(hy - p.cell_search_radius, 0);
+    q.ey = min(hy + p.cell_search_radius + 1, p.hash_ccy);
+    q.sx = max(hx - p.cell_search_radius, 0);
+    q.ex = min(hx + p.cell_search_radius + 1, p.hash_ccx);
+    q.r2 = (float)(radius * radius);
+}
+__device__ __forceinline__ void make_query_row(const Params &p, float x, float y, Query &q) {
+    q.x = x;
+    q.y = y;
+    int s = (int)y - ROW_RADIUS;
+    if (s < 0) s = 0;
+    int e = (int)y + ROW_RADIUS;
+    if (e > p.H) e = p.H;
+    q.sy = s;
+    q.ey = e;
+    q.sx = q.ex = 0;
+    q.r2 = 0;
+}
+template <int MODE>
+__device__ __forceinline__ bool cand_pred(const Query &q, const Feat &F, int j) {
+    if (MODE == MODE_ROW) {
+        const float fy = F.y[j];
+        return fy >= (float)q.sy && fy <= (float)q.ey;
+    } else {
+        const int cy = F.hcy[j], cx = F.hcx[j];
+        if (cy < q.sy || cy >= q.ey || cx < q.sx || cx >= q.ex) return false;
+        const float dx = F.x[j] - q.x, dy = F.y[j] - q.y;
+        return (dx * dx + dy * dy) < q.r2;
+    }
+}
+
+// =================================================================================================
+// k_candidates : one wavefront per query; output sorted ascending by (distance << 16 | index)
+// =================================================================================================
+template <int MODE>
+__global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2) {
+    Seq &S = seqs[blockIdx.z];
+    const Ctl &ctl = *S.ctl;
+    if (!ctl.active) return;
+    if (MODE == MODE_MAP) {
+        if (ctl.first_frame) return;
+        if (pass2 && !ctl.do_pass2) return;
+    }
+    if (MODE == MODE_STAGED && (ctl.first_frame || ctl.lost_now || S.prm.staged_th <= 0)) return;
+    if (MODE == MODE_ROW && (!ctl.need_tri || ctl.lost_now || S.prm.sensor != 1)) return;
+
+    __shared__ uint32_t lbuf[4][KC];
+    const int lane = lane_id(), wv = wave_id();
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    const Feat &T = (MODE == MODE_ROW) ? S.feat[1] : S.feat[0];
+    const int N = *T.n;
+    int M;
+    const uint64_t *qdesc;
+    uint32_t *cand;
+    int *ncand;
+    if (MODE == MODE_MAP) {
+        M = *S.map_n;
+        qdesc = S.map[*S.map_cur].desc;
+        cand = S.cand;
+        ncand = S.ncand;
+    } else if (MODE == MODE_STAGED) {
+        M = *S.staged_n;
+        qdesc = S.staged[*S.staged_cur].desc;
+        cand = S.scand;
+        ncand = S.sncand;
+    } else {
+        M = *S.feat[0].n;
+        qdesc = S.feat[0].desc;
+        cand = S.rcand;
+        ncand = S.rncand;
+    }
+    const int radius = S.prm.tracking_radius * ((MODE == MODE_MAP && pass2) ? 2 : 1);
+    uint32_t *buf = lbuf[wv];
+    for (int i = blockIdx.x * 4 + wv; i < M; i += gridDim.x * 4) {
+        Query q;
+        if (MODE == MODE_MAP) {
+            if (!S.vis[i]) {
+                if (lane == 0) ncand[i] = 0;
+                continue;
+            }
+            make_query_track(S.prm, S.proj[2 * i], S.proj[2 * i + 1], radius, q);
+        } else if (MODE == MODE_STAGED) {
+            if (!S.svis[i]) {
+                if (lane == 0) ncand[i] = 0;
+                continue;
+            }
+            make_query_track(S.prm, S.sproj[2 * i], S.sproj[2 * i + 1], radius, q);
+        } else {
+            if (S.feat[0].flag[i]) {  // already matched by tracking (handler.cpp:307)
+                if (lane == 0) ncand[i] = 0;
+                continue;
+            }
+            make_query_row(S.prm, S.feat[0].x[i], S.feat[0].y[i], q);
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) q.d[k] = qdesc[(size_t)i * 4 + k];
+        int cnt = 0;
+        for (int base = 0; base < N; base += 64) {
+            const int j = base + lane;
+            const bool ok = (j < N) && cand_pred<MODE>(q, T, j);
+            uint32_t key = 0;
+            if (ok) {
+                uint64_t t[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) t[k] = T.desc[(size_t)j * 4 + k];
+                key = ((uint32_t)hamming256(q.d, t) << 16) | (uint32_t)j;
+            }
+            const uint64_t m = __ballot(ok);
+            if (ok) {
+                const int pos = cnt + __popcll(m & lt_mask);
+                if (pos < KC) buf[pos] = key;
+            }
+            cnt += __popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (cnt <= KC) {
+            // rank sort (keys are unique): each lane places up to KC/64 entries
+            for (int e = lane; e < cnt; e += 64) {
+                const uint32_t k = buf[e];
+                int rank = 0;
+                for (int o = 0; o < cnt; o++) rank += (buf[o] < k) ? 1 : 0;
+                cand[(size_t)i * KC + rank] = k;
+            }
+        }
+        if (lane == 0) ncand[i] = cnt;  // > KC => resolvers take the exact slow path
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    }
+}
+
+// =================================================================================================
+// exact slow path: best two unmatched candidates of one query by scanning all train features
+// =================================================================================================
+template <int MODE>
+__device__ void wave_top2_slow(const Query &q, const Feat &T, int N, const uint8_t *flag_lds, uint32_t &k1, uint32_t &k2, int &cnt) {
+    const int lane = lane_id();
+    uint32_t b1 = 0xFFFFFFFFu, b2 = 0xFFFFFFFFu;
+    int c = 0;
+    for (int base = 0; base < N; base += 64) {
+        const int j = base + lane;
+        if (j < N && !flag_lds[j] && cand_pred<MODE>(q, T, j)) {
+            uint64_t t[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) t[k] = T.desc[(size_t)j * 4 + k];
+            const uint32_t key = ((uint32_t)hamming256(q.d, t) << 16) | (uint32_t)j;
+            if (key < b1) {
+                b2 = b1;
+                b1 = key;
+            } else if (key < b2)
+                b2 = key;
+            c++;
+        }
+    }
+    // wave reduce: smallest and second smallest of all lanes' (b1,b2)
+    for (int d = 32; d >= 1; d >>= 1) {
+        const uint32_t o1 = __shfl_xor(b1, d, 64), o2 = __shfl_xor(b2, d, 64);
+        const int oc = __shfl_xor(c, d, 64);
+        const uint32_t n1 = min(b1, o1);
+        const uint32_t n2 = min(max(b1, o1), min(b2, o2));
+        b1 = n1;
+        b2 = n2;
+        c += oc;
+    }
+    k1 = b1;
+    k2 = b2;
+    cnt = c;
+}
+
+// accept test of find_match_index / row_match (lvt_image_features_struct.cpp:105-116,141-144)
+__device__ __forceinline__ bool accept_match(int cnt, uint32_t k1, uint32_t k2, float ratio_th, float desc_th) {
+    if (cnt > 1) {
+        const float d1 = (float)(k1 >> 16), d2 = (float)(k2 >> 16);
+        return (d1 / d2) < ratio_th;  // 0/0 = NaN -> false
+    }
+    if (cnt == 1) return (float)(k1 >> 16) <= desc_th;
+    return false;
+}
+
+// first two unmatched candidates of a sorted list held as buf[0..n) (LDS or registers via lambda)
+// executed by a full wavefront; KC <= 128 => two candidates per lane
+__device__ __forceinline__ void wave_first_two(uint32_t c0, uint32_t c1, bool v0, bool v1, uint32_t &k1, uint32_t &k2, int &cnt) {
+    const uint64_t m0 = __ballot(v0), m1 = __ballot(v1);
+    cnt = __popcll(m0) + __popcll(m1);
+    int s1 = -1, s2 = -1;  // slot index 0..127
+    uint64_t a = m0, b = m1;
+    if (a) {
+        s1 = __ffsll((long long)a) - 1;
+        a &= a - 1;
+    } else if (b) {
+        s1 = 64 + __ffsll((long long)b) - 1;
+        b &= b - 1;
+    }
+    if (a) s2 = __ffsll((long long)a) - 1;
+    else if (b) s2 = 64 + __ffsll((long long)b) - 1;
+    k1 = k2 = 0xFFFFFFFFu;
+    if (s1 >= 0) k1 = (s1 < 64) ? __shfl(c0, s1, 64) : __shfl(c1, s1 - 64, 64);
+    if (s2 >= 0) k2 = (s2 < 64) ? __shfl(c0, s2, 64) : __shfl(c1, s2 - 64, 64);
+}
+
+// =================================================================================================
+// k_resolve : the greedy, order-dependent part.  One 256-thread workgroup per sequence: all four
+// wavefronts stage the candidate lists of 64 queries into LDS (independent, pipelined loads), then
+// wavefront 0 walks those 64 queries in order touching LDS only.
+// =================================================================================================
+constexpr int RCHUNK = 64;
+
+// decide one query from its LDS-resident sorted list; returns accepted feature index or -1
+template <int MODE>
+__device__ __forceinline__ int decide_query(const Seq &S, const Feat &T, int N, const uint32_t *list, int n, const uint8_t *flag,
+                                            const uint64_t *qdesc, int i, float qx, float qy, int radius, float ratio, float desc_th) {
+    const int lane = lane_id();
+    uint32_t k1, k2;
+    int cnt;
+    if (n <= KC) {
+        const uint32_t c0 = (lane < n) ? list[lane] : 0u;
+        const uint32_t c1 = (lane + 64 < n) ? list[lane + 64] : 0u;
+        const bool v0 = (lane < n) && !flag[c0 & 0xFFFFu];
+        const bool v1 = (lane + 64 < n) && !flag[c1 & 0xFFFFu];
+        wave_first_two(c0, c1, v0, v1, k1, k2, cnt);
+    } else {
+        Query q;
+        if (MODE == MODE_ROW) make_query_row(S.prm, qx, qy, q);
+        else make_query_track(S.prm, qx, qy, radius, q);
+#pragma unroll
+        for (int k = 0; k < 4; k++) q.d[k] = qdesc[(size_t)i * 4 + k];
+        wave_top2_slow<MODE>(q, T, N, flag, k1, k2, cnt);
+    }
+    return accept_match(cnt, k1, k2, ratio, desc_th) ? (int)(k1 & 0xFFFFu) : -1;
+}
+
+// stage the candidate lists of queries [base, base+chunk) into LDS; all threads of the block
+__device__ __forceinline__ void stage_lists(const uint32_t *cand, const int *ncand, int base, int chunk, uint32_t *lists, int *ns) {
+    const int nw = blockDim.x >> 6, lane = lane_id();
+    for (int q = wave_id(); q < chunk; q += nw) {
+        const int n = ncand[base + q];
+        if (lane == 0) ns[q] = n;
+        if (n <= KC)
+            for (int e = lane; e < n; e += 64) lists[q * KC + e] = cand[(size_t)(base + q) * KC + e];
+    }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_resolve(Seq *seqs, int pass2) {
+    Seq &S = seqs[blockIdx.z];
+    Ctl &ctl = *S.ctl;
+    if (!ctl.active) return;
+    if (MODE == MODE_MAP) {
+        if (ctl.first_frame) return;
+        if (pass2 && !ctl.do_pass2) return;
+    }
+    if (MODE == MODE_ROW && (!ctl.need_tri || ctl.lost_now || S.prm.sensor != 1)) return;
+
+    __shared__ uint8_t flag[NF_MAX];
+    __shared__ uint32_t lists[RCHUNK * KC];
+    __shared__ int ns[RCHUNK];
+    const int tid = threadIdx.x, lane = lane_id();
+    const Feat &T = (MODE == MODE_ROW) ? S.feat[1] : S.feat[0];
+    const int N = *T.n;
+    // find_matches pass 2 starts from cleared marks (lvt_local_map.cpp:176)
+    for (int j = tid; j < N; j += blockDim.x) flag[j] = (MODE == MODE_MAP && pass2) ? 0 : T.flag[j];
+
+    int M;
+    const uint64_t *qdesc;
+    const uint32_t *cand;
+    const int *ncand;
+    if (MODE == MODE_MAP) {
+        M = *S.map_n;
+        qdesc = S.map[*S.map_cur].desc;
+        cand = S.cand;
+        ncand = S.ncand;
+    } else {
+        M = *S.feat[0].n;
+        qdesc = S.feat[0].desc;
+        cand = S.rcand;
+        ncand = S.rncand;
+    }
+    const float ratio = (MODE == MODE_ROW) ? S.prm.tri_ratio : S.prm.track_ratio;
+    const float desc_th = S.prm.desc_th;
+    const int radius = S.prm.tracking_radius * ((MODE == MODE_MAP && pass2) ? 2 : 1);
+    int accepted = 0;  // meaningful in wavefront 0
+
+    for (int base = 0; base < M; base += RCHUNK) {
+        const int chunk = min(RCHUNK, M - base);
+        __syncthreads();  // previous chunk consumed (and flag[] initialised on the first round)
+        stage_lists(cand, ncand, base, chunk, lists, ns);
+        __syncthreads();
+        if (wave_id() == 0) {
+            for (int qi = 0; qi < chunk; qi++) {
+                const int i = base + qi;
+                const int n = ns[qi];
+                if (n == 0) continue;  // invisible / already matched / nothing in range
+                float qx, qy;
+                if (MODE == MODE_MAP) {
+                    qx = S.proj[2 * i];
+                    qy = S.proj[2 * i + 1];
+                } else {
+                    qx = S.feat[0].x[i];
+                    qy = S.feat[0].y[i];
+                }
+                const int idx = decide_query<MODE>(S, T, N, lists + qi * KC, n, flag, qdesc, i, qx, qy, radius, ratio, desc_th);
+                if (MODE == MODE_MAP && lane == 0) S.match[i] = idx;
+                if (idx >= 0) {
+                    if (lane == 0) {
+                        flag[idx] = 1;
+                        if (MODE == MODE_ROW) {
+                            S.pair_l[accepted] = i;
+                            S.pair_r[accepted] = idx;
+                            S.feat[0].flag[i] = 1;  // handler.cpp:319
+                        }
+                    }
+                    accepted++;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                }
+            }
+        }
+    }
+    __syncthreads();
+    if (MODE == MODE_MAP) {
+        // a failed pass 1 (< 50) is discarded: pass 2 rebuilds the marks from scratch
+        for (int j = tid; j < N; j += blockDim.x) S.feat[0].flag[j] = flag[j];
+        if (tid == 0) {
+            if (!pass2) {
+                ctl.n_pass1 = accepted;
+                ctl.do_pass2 = (accepted < N_MATCHES_TH) ? 1 : 0;  // lvt_local_map.cpp:173
+                ctl.counts[C_SECOND_PASS] = ctl.do_pass2;
+            } else
+                ctl.n_pass2 = accepted;
+        }
+    } else {
+        for (int j = tid; j < N; j += blockDim.x) S.feat[1].flag[j] = flag[j];
+        if (tid == 0) {
+            ctl.n_pairs = accepted;
+            ctl.counts[C_N_ROW_MATCHES] = accepted;
+        }
+    }
+}
+
+// =================================================================================================
+// k_bookkeep : lvt_local_map.cpp:201-224 + lvt_system.cpp:266-274
+// =================================================================================================
+__global__ __launch_bounds__(1024) void k_bookkeep(Seq *seqs) {
+    Seq &S = seqs[blockIdx.z];
+    Ctl &ctl = *S.ctl;
+    if (!ctl.active || ctl.first_frame) return;
+    __shared__ int scan[32];
+    const int tid = threadIdx.x;
+    const int M = *S.map_n;
+    MapSoA &P = S.map[*S.map_cur];
+    const Feat &F = S.feat[0];
+    int n_out = 0;
+    for (int base = 0; base < M; base += 1024) {
+        const int i = base + tid;
+        int m = -2;
+        if (i < M) {
+            m = S.match[i];
+            P.match_idx[i] = m;
+            if (m == -1) P.counter[i] += 1;
+            else if (m >= 0) P.age[i] += 1;
+        }
+        int total;
+        const int off = n_out + block_excl_scan(m >= 0 ? 1 : 0, scan, &total);
+        if (m >= 0 && off < NF_MAX) {
+            S.pnp_X[3 * off] = P.pos[3 * i];
+            S.pnp_X[3 * off + 1] = P.pos[3 * i + 1];
+            S.pnp_X[3 * off + 2] = P.pos[3 * i + 2];
+            S.pnp_obs[2 * off] = F.x[m];
+            S.pnp_obs[2 * off + 1] = F.y[m];
+            S.pnp_feat[off] = m;
+            S.pnp_level[off] = 0;
+        }
+        n_out += total;
+    }
+    if (tid == 0) {
+        ctl.n_matches = n_out;
+        ctl.counts[C_N_MATCHES] = n_out;
+        if (n_out < S.prm.min_matches) {  // lvt_system.cpp:267-272, :199-204
+            ctl.lost_now = 1;
+            ctl.state = 3;
+            pose_to_Rt(ctl.last_pose, ctl.out_R, ctl.out_t);
+            ctl.out_status = 3;
+        } else {  // push_back / pop_front
+            ctl.last_matches[0] = ctl.last_matches[1];
+            ctl.last_matches[1] = ctl.last_matches[2];
+            ctl.last_matches[2] = n_out;
+        }
+    }
+}
+
+// =================================================================================================
+// k_pnp : motion-only bundle adjustment, one 256-thread workgroup per sequence
+// =================================================================================================
+struct SBACam {
+    double r[4], t[3];
+    double w2n[12], w2i[12];
+    double dR[3][9];
+};
+__device__ void cam_refresh(SBACam &c, double fx, double fy, double cx, double cy) {
+    double R[9];
+    q_to_R(c.r, R);
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) c.w2n[4 * i + j] = R[3 * j + i];
+    for (int i = 0; i < 3; i++) c.w2n[4 * i + 3] = -(c.w2n[4 * i] * c.t[0] + c.w2n[4 * i + 1] * c.t[1] + c.w2n[4 * i + 2] * c.t[2]);
+    for (int j = 0; j < 4; j++) {
+        c.w2i[j] = fx * c.w2n[j] + cx * c.w2n[8 + j];
+        c.w2i[4 + j] = fy * c.w2n[4 + j] + cy * c.w2n[8 + j];
+        c.w2i[8 + j] = c.w2n[8 + j];
+    }
+    for (int j = 0; j < 3; j++) {
+        c.dR[0][j] = 0, c.dR[0][3 + j] = 2.0 * c.w2n[8 + j], c.dR[0][6 + j] = -2.0 * c.w2n[4 + j];
+        c.dR[1][j] = -2.0 * c.w2n[8 + j], c.dR[1][3 + j] = 0, c.dR[1][6 + j] = 2.0 * c.w2n[j];
+        c.dR[2][j] = 2.0 * c.w2n[4 + j], c.dR[2][3 + j] = -2.0 * c.w2n[j], c.dR[2][6 + j] = 0;
+    }
+}
+__device__ bool solve6_spd(const double *H /*6x6*/, const double *b, double *x) {
+    double L[36];
+    for (int i = 0; i < 36; i++) L[i] = 0;
+    for (int j = 0; j < 6; j++) {
+        double s = H[6 * j + j];
+        for (int k = 0; k < j; k++) s -= L[6 * j + k] * L[6 * j + k];
+        if (!(s > 0) || !isfinite(s)) return false;
+        L[6 * j + j] = sqrt(s);
+        for (int i = j + 1; i < 6; i++) {
+            double v = H[6 * i + j];
+            for (int k = 0; k < j; k++) v -= L[6 * i + k] * L[6 * j + k];
+            L[6 * i + j] = v / L[6 * j + j];
+        }
+    }
+    double y[6];
+    for (int i = 0; i < 6; i++) {
+        double v = b[i];
+        for (int k = 0; k < i; k++) v -= L[6 * i + k] * y[k];
+        y[i] = v / L[6 * i + i];
+    }
+    for (int i = 5; i >= 0; i--) {
+        double v = y[i];
+        for (int k = i + 1; k < 6; k++) v -= L[6 * k + i] * x[k];
+        x[i] = v / L[6 * i + i];
+    }
+    return true;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+    for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+    return v;
+}
+
+constexpr int PNP_THREADS = 256;
+
+// block-wide sum of NV doubles per thread; result valid in all threads.  red: LDS [4][NV]
+template <int NV>
+__device__ void block_sum(double (&v)[NV], double *red) {
+    const int w = wave_id(), l = lane_id();
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = wave_sum(v[k]);
+    __syncthreads();
+    if (l == 0)
+        for (int k = 0; k < NV; k++) red[w * NV + k] = v[k];
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NV; k++) v[k] = ((red[k] + red[NV + k]) + red[2 * NV + k]) + red[3 * NV + k];
+}
+
+struct PnpShared {
+    SBACam cam, backup;
+    double H[36], b[6], dx[6];
+    double lambda, ni, currentChi, tempChi, rho;
+    int qmax, cont, ok, ok2, solve_calls;
+};
+
+__device__ void pnp_run(const Params &prm, const Pose &prior, const double *X, const float *obs, double *err, int8_t *level,
+                        int n, PnpShared &sh, double *red, Pose &result, int &inliers, int &solve_calls) {
+    const int tid = threadIdx.x;
+    const double fx = prm.fx, fy = prm.fy, cx = prm.cx, cy = prm.cy;
+    const double mono_chi = sqrt(REPROJ_TH2);
+    const double dsqr = mono_chi * mono_chi;
+    const double dsqrReci = 1.0 / dsqr;
+    if (tid == 0) {
+        for (int k = 0; k < 4; k++) sh.cam.r[k] = prior.q[k];
+        if (sh.cam.r[0] < 0)
+            for (int k = 0; k < 4; k++) sh.cam.r[k] = -sh.cam.r[k];
+        q_normalize(sh.cam.r);
+        for (int k = 0; k < 3; k++) sh.cam.t[k] = prior.p[k];
+        cam_refresh(sh.cam, fx, fy, cx, cy);
+        sh.solve_calls = 0;
+    }
+    __syncthreads();
+
+    // errors of ACTIVE edges at the current estimate + robust chi2 (computeActiveErrors / activeRobustChi2)
+    auto errors_and_chi = [&]() -> double {
+        double chi[1] = {0.0};
+        for (int i = tid; i < n; i += PNP_THREADS) {
+            if (level[i] != 0) continue;
+            const double *c = sh.cam.w2i;
+            const double x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2];
+            const double px = ((c[0] * x + c[1] * y) + c[2] * z) + c[3];
+            const double py = ((c[4] * x + c[5] * y) + c[6] * z) + c[7];
+            const double pz = ((c[8] * x + c[9] * y) + c[10] * z) + c[11];
+            const double e0 = px / pz - (double)obs[2 * i], e1 = py / pz - (double)obs[2 * i + 1];
+            err[2 * i] = e0;
+            err[2 * i + 1] = e1;
+            const double aux = dsqrReci * (e0 * e0 + e1 * e1) + 1.0;
+            chi[0] += dsqr * log(aux);
+        }
+        block_sum<1>(chi, red);
+        return chi[0];
+    };
+
+    for (int pass = 0; pass < 2; pass++) {
+        double na[1] = {0.0};
+        for (int i = tid; i < n; i += PNP_THREADS) na[0] += (level[i] == 0) ? 1.0 : 0.0;
+        block_sum<1>(na, red);
+        const bool any_active = na[0] > 0.0;
+        if (tid == 0) sh.ok = 1;
+        __syncthreads();
+        for (int iter = 0; iter < 5; iter++) {
+            if (!sh.ok || !any_active) break;  // uniform: sh.ok only changes behind barriers
+            if (tid == 0) sh.solve_calls++;
+            const double currentChi = errors_and_chi();
+            // buildSystem(): H (upper triangle, 21) and b (6)
+            double acc[27];
+#pragma unroll
+            for (int k = 0; k < 27; k++) acc[k] = 0.0;
+            for (int i = tid; i < n; i += PNP_THREADS) {
+                if (level[i] != 0) continue;
+                const double *w = sh.cam.w2n;
+                const double x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2];
+                const double pcx = ((w[0] * x + w[1] * y) + w[2] * z) + w[3];
+                const double pcy = ((w[4] * x + w[5] * y) + w[6] * z) + w[7];
+                const double pcz = ((w[8] * x + w[9] * y) + w[10] * z) + w[11];
+                const double ipz2 = 1.0 / (pcz * pcz);
+                const double ipz2fx = ipz2 * fx, ipz2fy = ipz2 * fy;
+                const double pwt[3] = {x - sh.cam.t[0], y - sh.cam.t[1], z - sh.cam.t[2]};
+                double J0[6], J1[6];
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const double *d = sh.cam.dR[c];
+                    const double dp0 = (d[0] * pwt[0] + d[1] * pwt[1]) + d[2] * pwt[2];
+                    const double dp1 = (d[3] * pwt[0] + d[4] * pwt[1]) + d[5] * pwt[2];
+                    const double dp2 = (d[6] * pwt[0] + d[7] * pwt[1]) + d[8] * pwt[2];
+                    J0[3 + c] = (pcz * dp0 - pcx * dp2) * ipz2fx;
+                    J1[3 + c] = (pcz * dp1 - pcy * dp2) * ipz2fy;
+                }
+#pragma unroll
+                for (int c = 0; c < 3; c++) {
+                    const double dp0 = -w[c], dp1 = -w[4 + c], dp2 = -w[8 + c];
+                    J0[c] = (pcz * dp0 - pcx * dp2) * ipz2fx;
+                    J1[c] = (pcz * dp1 - pcy * dp2) * ipz2fy;
+                }
+                const double e0 = err[2 * i], e1 = err[2 * i + 1];
+                const double rho1 = 1.0 / (dsqrReci * (e0 * e0 + e1 * e1) + 1.0);
+                const double wr0 = -e0 * rho1, wr1 = -e1 * rho1;
+                int k = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+#pragma unroll
+                    for (int c = a; c < 6; c++) acc[k++] += (J0[a] * rho1) * J0[c] + (J1[a] * rho1) * J1[c];
+                }
+#pragma unroll
+                for (int a = 0; a < 6; a++) acc[21 + a] += J0[a] * wr0 + J1[a] * wr1;
+            }
+            block_sum<27>(acc, red);
+            if (tid == 0) {
+                int k = 0;
+                for (int a = 0; a < 6; a++)
+                    for (int c = a; c < 6; c++) {
+                        sh.H[6 * a + c] = acc[k];
+                        sh.H[6 * c + a] = acc[k];
+                        k++;
+                    }
+                for (int a = 0; a < 6; a++) sh.b[a] = acc[21 + a];
+                if (iter == 0) {
+                    double maxDiag = 0;
+                    for (int j = 0; j < 6; j++) maxDiag = fmax(fabs(sh.H[6 * j + j]), maxDiag);
+                    sh.lambda = 1e-5 * maxDiag;
+                    sh.ni = 2;
+                }
+                sh.currentChi = currentChi;
+                sh.qmax = 0;
+                sh.rho = 0;
+            }
+            __syncthreads();
+            do {
+                if (tid == 0) {
+                    sh.backup = sh.cam;  // push()
+                    double Hl[36];
+                    for (int a = 0; a < 36; a++) Hl[a] = sh.H[a];
+                    for (int a = 0; a < 6; a++) Hl[7 * a] += sh.lambda;
+                    for (int a = 0; a < 6; a++) sh.dx[a] = 0;
+                    sh.ok2 = solve6_spd(Hl, sh.b, sh.dx) ? 1 : 0;
+                    // SBACam::update
+                    for (int k = 0; k < 3; k++) sh.cam.t[k] += sh.dx[k];
+                    double qr[4];
+                    qr[1] = sh.dx[3], qr[2] = sh.dx[4], qr[3] = sh.dx[5];
+                    qr[0] = sqrt(1.0 - (sh.dx[3] * sh.dx[3] + sh.dx[4] * sh.dx[4] + sh.dx[5] * sh.dx[5]));
+                    double nr[4];
+                    q_mul(sh.cam.r, qr, nr);
+                    q_normalize(nr);
+                    for (int k = 0; k < 4; k++) sh.cam.r[k] = nr[k];
+                    cam_refresh(sh.cam, fx, fy, cx, cy);
+                }
+                __syncthreads();
+                double tempChi = errors_and_chi();
+                if (tid == 0) {
+                    if (!sh.ok2) tempChi = 1.7976931348623157e308;
+                    double rho = sh.currentChi - tempChi;
+                    double scale = 0;
+                    for (int j = 0; j < 6; j++) scale += sh.dx[j] * (sh.lambda * sh.dx[j] + sh.b[j]);
+                    scale += 1e-3;
+                    rho /= scale;
+                    if (rho > 0 && isfinite(tempChi)) {
+                        double alpha = 1. - pow((2 * rho - 1), 3.0);
+                        alpha = fmin(alpha, 2.0 / 3.0);
+                        const double scaleFactor = fmax(1.0 / 3.0, alpha);
+                        sh.lambda *= scaleFactor;
+                        sh.ni = 2;
+                        sh.currentChi = tempChi;
+                    } else {
+                        sh.lambda *= sh.ni;
+                        sh.ni *= 2;
+                        sh.cam = sh.backup;  // pop(): edge errors stay those of the rejected trial
+                    }
+                    sh.rho = rho;
+                    sh.qmax++;
+                    sh.cont = (rho < 0 && sh.qmax < 10) ? 1 : 0;
+                    if (!sh.cont && (sh.qmax == 10 || rho == 0)) sh.ok = 0;  // Terminate
+                }
+                __syncthreads();
+            } while (sh.cont);
+        }
+        // chi2 gate on the last computed errors (lvt_pnp_solver.cpp:109-116)
+        for (int i = tid; i < n; i += PNP_THREADS) {
+            const double e0 = err[2 * i], e1 = err[2 * i + 1];
+            if ((e0 * e0 + e1 * e1) > REPROJ_TH2) level[i] = 1;
+        }
+        __syncthreads();
+    }
+    double inl[1] = {0.0};
+    for (int i = tid; i < n; i += PNP_THREADS) inl[0] += (level[i] == 0) ? 1.0 : 0.0;
+    block_sum<1>(inl, red);
+    inliers = (int)inl[0];
+    solve_calls = sh.solve_calls;
+    for (int k = 0; k < 4; k++) result.q[k] = sh.cam.r[k];
+    for (int k = 0; k < 3; k++) result.p[k] = sh.cam.t[k];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs) {
+    Seq &S = seqs[blockIdx.z];
+    Ctl &ctl = *S.ctl;
+    if (!ctl.active || ctl.first_frame || ctl.lost_now) return;
+    __shared__ PnpShared sh;
+    __shared__ double red[4 * 27];
+    Pose res;
+    int inliers, calls;
+    // err must be defined for every edge before the first gate: all edges are active in pass 1
+    pnp_run(S.prm, ctl.predicted, S.pnp_X, S.pnp_obs, S.pnp_err, S.pnp_level, ctl.n_matches, sh, red, res, inliers, calls);
+    if (threadIdx.x == 0) {
+        ctl.optimized = res;
+        ctl.last_pose = res;  // lvt_system.cpp:205
+        pose_to_Rt(res, ctl.out_R, ctl.out_t);
+        ctl.out_status = 2;
+        ctl.counts[C_PNP_ITERS] = calls;
+        ctl.counts[C_PNP_INLIERS] = inliers;
+    }
+}
+
+// stand-alone entry for differential tests (lvt_amd_pnp)
+__global__ __launch_bounds__(PNP_THREADS) void k_pnp_standalone(Params prm, Pose prior, const double *X, const float *obs, double *err,
+                                                                int8_t *level, int n, Pose *out, int *info) {
+    __shared__ PnpShared sh;
+    __shared__ double red[4 * 27];
+    for (int i = threadIdx.x; i < n; i += PNP_THREADS) level[i] = 0;
+    __syncthreads();
+    Pose res;
+    int inliers, calls;
+    pnp_run(prm, prior, X, obs, err, level, n, sh, red, res, inliers, calls);
+    if (threadIdx.x == 0) {
+        *out = res;
+        info[0] = calls;
+        info[1] = inliers;
+    }
+}
+
+// =================================================================================================
+// map SoA copy helper
+// =================================================================================================
+__device__ __forceinline__ void copy_point(const MapSoA &src, int i, MapSoA &dst, int o) {
+    dst.pos[3 * o] = src.pos[3 * i];
+    dst.pos[3 * o + 1] = src.pos[3 * i + 1];
+    dst.pos[3 * o + 2] = src.pos[3 * i + 2];
+#pragma unroll
+    for (int k = 0; k < 4; k++) dst.desc[(size_t)o * 4 + k] = src.desc[(size_t)i * 4 + k];
+    dst.counter[o] = src.counter[i];
+    dst.age[o] = src.age[i];
+    dst.match_idx[o] = src.match_idx[i];
+}
+
+// =================================================================================================
+// k_cull : clean_untracked_points (lvt_local_map.cpp:393-413), stable compaction into the other buffer
+// =================================================================================================
+__global__ __launch_bounds__(1024) void k_cull(Seq *seqs) {
+    Seq &S = seqs[blockIdx.z];
+    Ctl &ctl = *S.ctl;
+    if (!ctl.active || ctl.first_frame || ctl.lost_now) return;
+    __shared__ int scan[32];
+    const int tid = threadIdx.x;
+    const int cur = *S.map_cur, M = *S.map_n;
+    MapSoA &A = S.map[cur], &B = S.map[cur ^ 1];
+    const int th = S.prm.untracked_th;
+    int n_out = 0;
+    for (int base = 0; base < M; base += 1024) {
+        const int i = base + tid;
+        bool keep = false;
+        if (i < M) {
+            keep = A.counter[i] < th;
+            if (!keep && A.match_idx[i] >= 0) S.feat[0].flag[A.match_idx[i]] = 0;  // :402-405
+        }
+        int total;
+        const int off = n_out + block_excl_scan(keep ? 1 : 0, scan, &total);
+        if (keep) copy_point(A, i, B, off);
+        n_out += total;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ctl.counts[C_N_CULLED] = M - n_out;
+        *S.map_cur = cur ^ 1;
+        *S.map_n = n_out;
+    }
+}
+
+// =================================================================================================
+// k_staged : update_staged_map_points (lvt_local_map.cpp:355-391) then the triangulation policy
+// =================================================================================================
+__global__ __launch_bounds__(1024) void k_staged(Seq *seqs) {
+    Seq &S = seqs[blockIdx.z];
+    Ctl &ctl = *S.ctl;
+    if (!ctl.active || ctl.lost_now) return;
+    __shared__ uint8_t flag[NF_MAX];
+    __shared__ uint32_t lists[RCHUNK * KC];
+    __shared__ int ns[RCHUNK], cnt0[RCHUNK];
+    __shared__ int8_t visq[RCHUNK];
+    __shared__ int scan[32];
+    const int tid = threadIdx.x, lane = lane_id();
+    if (!ctl.first_frame && S.prm.staged_th > 0) {
+        const Feat &T = S.feat[0];
+        const int N = *T.n;
+        const int scur = *S.staged_cur, SM = *S.staged_n;
+        MapSoA &A = S.staged[scur], &B = S.staged[scur ^ 1];
+        MapSoA &MP = S.map[*S.map_cur];
+        for (int j = tid; j < N; j += 1024) flag[j] = T.flag[j];
+        __syncthreads();
+        int map_n = *S.map_n;  // wavefront 0's copy is the live one
+        int erased = 0, promoted = 0;
+        bool map_ovf = false;
+        for (int base = 0; base < SM; base += RCHUNK) {
+            const int chunk = min(RCHUNK, SM - base);
+            __syncthreads();
+            stage_lists(S.scand, S.sncand, base, chunk, lists, ns);
+            for (int q = tid; q < chunk; q += 1024) {
+                cnt0[q] = A.counter[base + q];
+                visq[q] = S.svis[base + q];
+            }
+            __syncthreads();
+            if (wave_id() == 0) {  // the order-dependent part, one wavefront
+                for (int qi = 0; qi < chunk; qi++) {
+                    const int i = base + qi;
+                    bool del = false;
+                    int idx = -1;
+                    if (!visq[qi]) {
+                        del = true;
+                        erased++;
+                    } else {
+                        const int n = ns[qi];
+                        if (n > 0)
+                            idx = decide_query<MODE_STAGED>(S, T, N, lists + qi * KC, n, flag, A.desc, i, S.sproj[2 * i], S.sproj[2 * i + 1],
+                                                            S.prm.tracking_radius, S.prm.track_ratio, S.prm.desc_th);
+                        if (idx < 0) {
+                            del = true;
+                            erased++;
+                        }
+                    }
+                    if (idx >= 0) {
+                        const int c = cnt0[qi] + 1;
+                        if (lane == 0) {
+                            flag[idx] = 1;
+                            A.counter[i] = c;
+                        }
+                        if (c == S.prm.staged_th || map_n < N_MAP_POINTS) {  // promote (:377-382)
+                            if (map_n < MAP_MAX) {
+                                if (lane == 0) {
+                                    copy_point(A, i, MP, map_n);
+                                    MP.counter[map_n] = c;
+                                    MP.match_idx[map_n] = -1;
+                                }
+                                map_n++;
+                            } else
+                                map_ovf = true;
+                            del = true;
+                            promoted++;
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    }
+                    if (lane == 0) S.sdel[i] = del ? 1 : 0;
+                }
+            }
+        }
+        if (tid == 0) {
+            *S.map_n = map_n;
+            ctl.counts[C_N_STAGED_ERASED] = erased;
+            ctl.counts[C_N_STAGED_PROMOTED] = promoted;
+            if (map_ovf) atomicOr(&ctl.overflow, OVF_MAP);
+        }
+        __syncthreads();
+        for (int j = tid; j < N; j += 1024) S.feat[0].flag[j] = flag[j];
+        // stable compaction of the staged set
+        int n_out = 0;
+        for (int base = 0; base < SM; base += 1024) {
+            const int i = base + tid;
+            const bool keep = (i < SM) && !S.sdel[i];
+            int total;
+            const int off = n_out + block_excl_scan(keep ? 1 : 0, scan, &total);
+            if (keep) copy_point(A, i, B, off);
+            n_out += total;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            *S.staged_cur = scur ^ 1;
+            *S.staged_n = n_out;
+        }
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (ctl.first_frame) {  // lvt_system.cpp:188
+            ctl.need_tri = 1;
+            ctl.dont_stage = 1;
+        } else {  // lvt_system.cpp:308-334
+            bool need;
+            if (S.prm.tri_policy == 2) need = true;
+            else if (S.prm.tri_policy == 3) need = (*S.map_n < 1000);
+            else {
+                need = true;
+                const float ratio = 0.99f;
+                for (int i = 2; i > 0; --i)
+                    if ((float)ctl.last_matches[i] > ratio * (float)ctl.last_matches[i - 1]) need = false;
+            }
+            ctl.need_tri = need ? 1 : 0;
+            ctl.dont_stage = 0;
+        }
+    }
+}
+
+// =================================================================================================
+// k_triangulate : lvt_local_map.cpp:231-353
+// =================================================================================================
+__device__ bool ls_solve_4x3(double A[4][3], double b[4], double x[3]) {
+    for (int k = 0; k < 3; k++) {
+        double norm = 0;
+        for (int i = k; i < 4; i++) norm += A[i][k] * A[i][k];
+        norm = sqrt(norm);
+        if (norm < 1e-300) return false;
+        const double alpha = (A[k][k] > 0) ? -norm : norm;
+        double v[4] = {0, 0, 0, 0};
+        for (int i = k; i < 4; i++) v[i] = A[i][k];
+        v[k] -= alpha;
+        double vnorm2 = 0;
+        for (int i = k; i < 4; i++) vnorm2 += v[i] * v[i];
+        if (vnorm2 > 0) {
+            for (int j = k; j < 3; j++) {
+                double dot = 0;
+                for (int i = k; i < 4; i++) dot += v[i] * A[i][j];
+                const double f = 2.0 * dot / vnorm2;
+                for (int i = k; i < 4; i++) A[i][j] -= f * v[i];
+            }
+            double dot = 0;
+            for (int i = k; i < 4; i++) dot += v[i] * b[i];
+            const double f = 2.0 * dot / vnorm2;
+            for (int i = k; i < 4; i++) b[i] -= f * v[i];
+        }
+    }
+    const double rmax = fmax(fabs(A[0][0]), fmax(fabs(A[1][1]), fabs(A[2][2])));
+    for (int k = 0; k < 3; k++)
+        if (!(fabs(A[k][k]) > 1e-12 * rmax)) return false;
+    x[2] = b[2] / A[2][2];
+    x[1] = (b[1] - A[1][2] * x[2]) / A[1][1];
+    x[0] = (b[0] - A[0][1] * x[1] - A[0][2] * x[2]) / A[0][0];
+    return true;
+}
+
+__device__ bool triangulate_pair(const Params &p, const double *cml, const double *cmr, float u1x, float u1y, float u2x, float u2y, double out[3]) {
+    const double cx = p.cx, cy = p.cy;
+    const double inv_fx = 1.0 / p.fx, inv_fy = 1.0 / p.fy;
+    const double a1x = (u1x - cx) * inv_fx, a1y = (u1y - cy) * inv_fy;
+    const double a2x = (u2x - cx) * inv_fx, a2y = (u2y - cy) * inv_fy;
+    double A[4][3], rhs[4];
+    for (int j = 0; j < 3; j++) {
+        A[0][j] = a1x * cml[8 + j] - cml[j];
+        A[1][j] = a1y * cml[8 + j] - cml[4 + j];
+        A[2][j] = a2x * cmr[8 + j] - cmr[j];
+        A[3][j] = a2y * cmr[8 + j] - cmr[4 + j];
+    }
+    rhs[0] = -(a1x * cml[11] - cml[3]);
+    rhs[1] = -(a1y * cml[11] - cml[7]);
+    rhs[2] = -(a2x * cmr[11] - cmr[3]);
+    rhs[3] = -(a2y * cmr[11] - cmr[7]);
+    double x[3];
+    if (!ls_solve_4x3(A, rhs, x)) return false;
+    double ul, vl, ur, vr;
+    if (!is_point_visible(x, cml, p, ul, vl) || !is_point_visible(x, cmr, p, ur, vr)) return false;
+    {
+        const double ex = ul - u1x, ey = vl - u1y;
+        if ((ex * ex + ey * ey) > REPROJ_TH2) return false;
+    }
+    {
+        const double ex = ur - u2x, ey = vr - u2y;
+        if ((ex * ex + ey * ey) > REPROJ_TH2) return false;
+    }
+    out[0] = x[0], out[1] = x[1], out[2] = x[2];
+    return true;
+}
+
+__global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs) {
+    Seq &S = seqs[blockIdx.z];
+    Ctl &ctl = *S.ctl;
+    if (!ctl.active || ctl.lost_now || !ctl.need_tri) return;
+    __shared__ double cml[12], cmr[12], R[9];
+    __shared__ Pose cam;
+    __shared__ int scan[32];
+    const int tid = threadIdx.x;
+    if (tid == 0) {
+        if (ctl.first_frame) {
+            cam.q[0] = 1, cam.q[1] = cam.q[2] = cam.q[3] = 0;
+            cam.p[0] = cam.p[1] = cam.p[2] = 0;
+        } else
+            cam = ctl.optimized;
+        Pose right;
+        right_camera_pose(cam, (double)S.prm.baseline, right);
+        world_to_camera(cam, cml);
+        world_to_camera(right, cmr);
+        q_to_R(cam.q, R);
+    }
+    __syncthreads();
+    const Feat &FL = S.feat[0], &FR = S.feat[1];
+    const bool rgbd = (S.prm.sensor == 2);
+    const int n_in = rgbd ? *FL.n : ctl.n_pairs;
+    // destination: lvt_local_map.cpp:345 (decided once, before anything is appended)
+    const bool to_map = ctl.dont_stage || S.prm.staged_th == 0 || (*S.map_n < N_MAP_POINTS);
+    MapSoA &D = to_map ? S.map[*S.map_cur] : S.staged[*S.staged_cur];
+    const int d_n0 = to_map ? *S.map_n : *S.staged_n;
+    const int d_cap = to_map ? MAP_MAX : STAGED_MAX;
+    int n_out = 0;
+    for (int base = 0; base < n_in; base += 1024) {
+        const int i = base + tid;
+        bool ok = false;
+        double X[3] = {0, 0, 0};
+        int li = 0;
+        if (i < n_in) {
+            if (rgbd) {  // triangulate_rgbd, float then double (lvt_local_map.cpp:231-256)
+                li = i;
+                const float inv_fx = 1.0f / S.prm.fx, inv_fy = 1.0f / S.prm.fy;
+                const float u = FL.x[i], v = FL.y[i], z = FL.depth[i];
+                const float x = (u - S.prm.cx) * z * inv_fx, y = (v - S.prm.cy) * z * inv_fy;
+                X[0] = ((R[0] * x + R[1] * y) + R[2] * z) + cam.p[0] * 1.0;
+                X[1] = ((R[3] * x + R[4] * y) + R[5] * z) + cam.p[1] * 1.0;
+                X[2] = ((R[6] * x + R[7] * y) + R[8] * z) + cam.p[2] * 1.0;
+                ok = true;
+            } else {
+                li = S.pair_l[i];
+                const int ri = S.pair_r[i];
+                ok = triangulate_pair(S.prm, cml, cmr, FL.x[li], FL.y[li], FR.x[ri], FR.y[ri], X);
+            }
+        }
+        int total;
+        const int off = d_n0 + n_out + block_excl_scan(ok ? 1 : 0, scan, &total);
+        if (ok && off < d_cap) {
+            D.pos[3 * off] = X[0];
+            D.pos[3 * off + 1] = X[1];
+            D.pos[3 * off + 2] = X[2];
+#pragma unroll
+            for (int k = 0; k < 4; k++) D.desc[(size_t)off * 4 + k] = FL.desc[(size_t)li * 4 + k];
+            D.counter[off] = 0;
+            D.age[off] = 0;
+            D.match_idx[off] = -1;
+        }
+        n_out += total;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        int nn = d_n0 + n_out;
+        if (nn > d_cap) {
+            atomicOr(&ctl.overflow, to_map ? OVF_MAP : OVF_STAGED);
+            nn = d_cap;
+        }
+        if (to_map) *S.map_n = nn;
+        else *S.staged_n = nn;
+        ctl.counts[C_TRIANGULATED] = 1;
+        ctl.counts[C_N_TRIANGULATED] = n_out;
+    }
+}
+
+// =================================================================================================
+// k_finalize
+// =================================================================================================
+__global__ void k_finalize(Seq *seqs) {
+    Seq &S = seqs[blockIdx.x];
+    if (threadIdx.x != 0) return;
+    Ctl &ctl = *S.ctl;
+    if (ctl.active && ctl.first_frame) {  // lvt_system.cpp:185-193
+        ctl.state = 2;
+        ctl.last_matches[0] = *S.map_n;
+        Pose id;
+        id.q[0] = 1, id.q[1] = id.q[2] = id.q[3] = 0;
+        id.p[0] = id.p[1] = id.p[2] = 0;
+        pose_to_Rt(id, ctl.out_R, ctl.out_t);
+        ctl.out_status = 2;
+    }
+    ctl.counts[C_MAP_SIZE] = *S.map_n;
+    ctl.counts[C_STAGED_SIZE] = *S.staged_n;
+    ctl.counts[C_OVERFLOW] = ctl.overflow;
+}
+
+// explicit instantiations used by the host
+template __global__ void k_candidates<MODE_MAP>(Seq *, int);
+template __global__ void k_candidates<MODE_STAGED>(Seq *, int);
+template __global__ void k_candidates<MODE_ROW>(Seq *, int);
+template __global__ void k_resolve<MODE_MAP>(Seq *, int);
+template __global__ void k_resolve<MODE_ROW>(Seq *, int);
+
+}  // namespace lvt

@@ -1,0 +1,180 @@
+// lvt_dev.h -- device-resident data layout shared by all kernels of the MI355X tracking path.
+//
+// One `Seq` per tracked sequence lives in HBM.  Every kernel is launched with gridDim.z = number of
+// sequences in the context, so B independent sequences advance in lock-step through ONE launch chain
+// (a single lvt_handle is a context with B = 1).  All per-frame control flow of the reference's
+// lvt_system::track / perform_tracking (lvt_system.cpp:157-306) is evaluated ON DEVICE from the `Ctl`
+// block; the host enqueues the same fixed chain every frame and reads back 1 small result record.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace lvt {
+
+// ---- capacities -------------------------------------------------------------------------------
+constexpr int NF_MAX = 4096;       // features per image after BRIEF's border filter
+constexpr int CELLS_MAX = 64;      // detection grid cells per image
+constexpr int CELL_OUT_CAP = 2048; // key points one cell may emit (after ANMS)
+constexpr int RAW_CAP = 10240;     // raw (pre-NMS) corners one cell may hold in LDS
+constexpr int MAP_MAX = 32768;     // local map points
+constexpr int STAGED_MAX = 16384;  // staged points
+constexpr int KC = 128;            // candidate-list capacity per query (overflow -> exact slow path)
+constexpr int N_COUNTS = 32;
+
+// overflow bits (Ctl::overflow, reported through lvt_amd_get_counts / lvt_amd_last_error)
+enum : int { OVF_RAW = 1, OVF_CELL_OUT = 2, OVF_FEATURES = 4, OVF_MAP = 8, OVF_STAGED = 16, OVF_CELL_DIM = 32 };
+
+// counts slots -- identical to the oracle's LVTO_C_* so tests can diff them 1:1
+enum : int {
+    C_N_LEFT = 0, C_N_RIGHT, C_MAP_SIZE, C_STAGED_SIZE, C_N_MATCHES, C_SECOND_PASS, C_N_ROW_MATCHES,
+    C_N_TRIANGULATED, C_TRIANGULATED, C_RETRY_LEFT, C_RETRY_RIGHT, C_PNP_ITERS, C_PNP_INLIERS,
+    C_MAP_SIZE_AT_MATCH, C_N_STAGED_ERASED, C_N_STAGED_PROMOTED, C_N_CULLED, C_FRAME, C_OVERFLOW
+};
+
+// constants of the reference -- lvt/src/lvt_definitions.h:29-34
+constexpr double REPROJ_TH2 = 5.991;
+constexpr int N_MAP_POINTS = 250;
+constexpr int ROW_RADIUS = 2;
+constexpr int HASH_CELL = 25;
+constexpr int CORNERS_LOW_TH = 200;
+constexpr int N_MATCHES_TH = 50;
+
+struct Params {  // lvt_parameters.h:29-64 + derived values
+    float fx, fy, cx, cy, baseline;
+    float k1, k2, p1, p2, k3;
+    float near_plane, far_plane;
+    float tri_ratio, track_ratio, desc_th;
+    float min_x, max_x, min_y, max_y;  // image bounds (lvt_local_map.cpp:84-123), per instance
+    int W, H;
+    int min_matches, tracking_radius, cell_size, max_kp_cell, agast_th, agast_th_low;
+    int untracked_th, staged_th, tri_policy;
+    int cells_x, cells_y, n_cells;          // detection grid (lvt_image_features_handler.cpp:95-114)
+    int hash_ccx, hash_ccy, cell_search_radius;  // lvt_image_features_struct.cpp:48-53
+    int sensor;                             // 1 stereo, 2 rgbd
+    int undistort;                          // |k1| > 1e-5 (handler.cpp:268)
+};
+
+struct Pose {  // camera-to-world, quaternion (w,x,y,z) + position
+    double q[4];
+    double p[3];
+};
+
+struct Ctl {
+    // persistent state (lvt_system.h:96-108, lvt_motion_model.h:43-46)
+    int state;          // 1 NOT_INITIALIZED, 2 TRACKING, 3 LOST
+    int frame_number;
+    int last_matches[3];
+    Pose last_pose;
+    double mm_last_q[4], mm_ang_vel[4], mm_last_p[3], mm_lin_vel[3];
+    // per-frame control, written by k_begin / later kernels
+    int active;         // 0: LOST at frame start -> every kernel exits
+    int first_frame;    // state was NOT_INITIALIZED at frame start
+    int ext_corners;    // track_with_external_corners frame
+    int n_detected[2];  // corners before BRIEF (for the <200 retry)
+    int retry[2];
+    int n_ext[2];
+    int do_pass2;       // find_matches second pass (lvt_local_map.cpp:173)
+    int n_pass1, n_pass2;
+    int n_matches;      // accepted 2D-3D matches
+    int lost_now;       // matches < min_num_matches_for_tracking
+    int need_tri;       // triangulation policy fired (or first frame)
+    int dont_stage;
+    int n_pairs;        // row matches
+    Pose predicted, optimized;
+    int counts[N_COUNTS];
+    int overflow;
+    // result record copied to the host
+    double out_R[9], out_t[3];
+    int out_status;
+};
+
+struct Feat {  // one image's lvt_image_features_struct (lvt_image_features_struct.h:62-80), SoA
+    float *x, *y, *resp;   // keypoint coords as the struct stores them (undistorted for RGB-D)
+    float *bx, *by;        // coords BRIEF samples at (== x,y except RGB-D with distortion)
+    float *depth;          // RGB-D only
+    uint64_t *desc;        // [NF_MAX][4]
+    uint8_t *flag;         // matched marks
+    int16_t *hcx, *hcy;    // 25-px hash cell of each feature
+    int *n;                // feature count (device scalar)
+};
+
+struct MapSoA {            // lvt_local_map.h:64-72 as SoA; two copies for stable compaction
+    double *pos;           // [cap][3]
+    uint64_t *desc;        // [cap][4]
+    int *counter, *age, *match_idx;
+};
+
+struct Seq {
+    Params prm;
+    Ctl *ctl;
+    // images (this frame)
+    const uint8_t *img[2];
+    const float *depth_img;     // RGB-D
+    int img_pitch, depth_pitch; // bytes / elements
+    uint8_t *score[2];          // OAST-9/16 score map (0 = below the lowered threshold / dead band)
+    uint16_t *boxsum[2];        // 9x9 box sums
+    int plane_pitch;            // elements, multiple of 64
+    // per-cell detector output
+    float *cell_kp[2];          // [CELLS_MAX][CELL_OUT_CAP][3] (x, y, response)
+    int *cell_n[2];             // [CELLS_MAX]
+    const float *ext_xy[2];     // external corners (n_ext x 2, f32) for track_with_external_corners
+    Feat feat[2];
+    // map + staged, ping-pong
+    MapSoA map[2], staged[2];
+    int *map_cur, *map_n, *staged_cur, *staged_n;   // device scalars
+    // find_matches temporaries
+    float *proj;                // [MAP_MAX][2] projected (f32) positions
+    int8_t *vis;                // [MAP_MAX]
+    int *match;                 // [MAP_MAX]  -2 invisible, -1 none, else feature index
+    uint32_t *cand;             // [MAP_MAX][KC] packed (dist << 16 | idx), ascending
+    int *ncand;                 // [MAP_MAX]  (> KC => overflow, slow path)
+    // staged temporaries
+    float *sproj; int8_t *svis; int *smatch; uint32_t *scand; int *sncand; uint8_t *sdel;
+    // pnp input
+    double *pnp_X; float *pnp_obs; int *pnp_feat; double *pnp_err; int8_t *pnp_level;
+    // row matching / triangulation
+    uint32_t *rcand; int *rncand;   // [NF_MAX][KC]
+    int *pair_l, *pair_r;           // [NF_MAX]
+    double *tri_X; int8_t *tri_ok;  // [NF_MAX][3]
+};
+
+// ---- small device helpers ----------------------------------------------------------------------
+__device__ __forceinline__ int lane_id() { return threadIdx.x & 63; }
+__device__ __forceinline__ int wave_id() { return threadIdx.x >> 6; }
+
+__device__ __forceinline__ int hamming256(const uint64_t a[4], const uint64_t b[4]) {
+    return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
+}
+
+// inclusive wave scan (64 lanes)
+__device__ __forceinline__ int wave_incl_scan(int v) {
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        int t = __shfl_up(v, d, 64);
+        if (lane_id() >= d) v += t;
+    }
+    return v;
+}
+
+// exclusive block scan over blockDim.x (<= 1024) threads; `scratch` >= 17 ints of LDS; returns
+// exclusive prefix, *total receives the block sum.  Contains __syncthreads().
+__device__ __forceinline__ int block_excl_scan(int v, int *scratch, int *total) {
+    const int incl = wave_incl_scan(v);
+    const int w = wave_id(), l = lane_id();
+    const int nw = (blockDim.x + 63) >> 6;
+    __syncthreads();
+    if (l == 63) scratch[w] = incl;
+    __syncthreads();
+    if (w == 0) {
+        int s = (l < nw) ? scratch[l] : 0;
+        int si = wave_incl_scan(s);
+        if (l < nw) scratch[l] = si - s;
+        if (l == nw - 1) scratch[16] = si;
+    }
+    __syncthreads();
+    const int base = scratch[w];
+    *total = scratch[16];
+    return base + incl - v;
+}
+
+}  // namespace lvt

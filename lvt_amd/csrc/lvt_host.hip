@@ -1,0 +1,774 @@
+// lvt_host.hip -- host side of the MI355X-native LVT tracking path: context/arena management, the fixed
+// per-frame launch chain, the reference-compatible C-ABI (include/lvt_c.h) and the additive entry
+// points (include/lvt_amd_ext.h).  The host mirrors lvt_system::create/track/reset
+// (reference lvt/src/lvt_system.cpp) but performs NO tracking arithmetic: the whole state machine
+// runs on the device, the host enqueues the chain and reads back one result record per frame.
+#define LVT_EXPORT_FUNCTIONS
+#include "../../include/lvt_amd_ext.h"
+
+#include "k_features.hip"
+#include "k_track.hip"
+#include "k_hamming.hip"
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+namespace lvt {
+
+#define HIPCHK(ctx, call)                                                                  \
+    do {                                                                                   \
+        hipError_t e__ = (call);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            (ctx)->set_error(std::string(#call) + ": " + hipGetErrorString(e__));          \
+            throw std::runtime_error((ctx)->err);                                          \
+        }                                                                                  \
+    } while (0)
+
+constexpr int EXT_MAX = 16384;
+
+struct FrameArgs {  // per-frame, per-sequence inputs (pinned host memory read by k_set_frame)
+    const uint8_t *img[2];
+    const float *depth;
+    int img_pitch, depth_pitch;
+};
+
+__global__ void k_set_frame(Seq *seqs, const FrameArgs *fa) {
+    if (threadIdx.x != 0) return;
+    Seq &S = seqs[blockIdx.x];
+    const FrameArgs &f = fa[blockIdx.x];
+    S.img[0] = f.img[0];
+    S.img[1] = f.img[1];
+    S.depth_img = f.depth;
+    S.img_pitch = f.img_pitch;
+    S.depth_pitch = f.depth_pitch;
+}
+
+struct Context {
+    int B = 1;                 // sequences advanced in lock-step by one launch chain
+    int sensor = 1;
+    Params prm{};
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::vector<void *> allocs;
+    Seq *d_seqs = nullptr;
+    std::vector<Seq> h_seqs;   // host mirror (device pointers inside)
+    std::vector<Ctl *> d_ctl;
+    Ctl *h_ctl = nullptr;      // pinned, B records
+    FrameArgs *h_fargs = nullptr;  // pinned
+    std::vector<uint8_t *> d_img_l, d_img_r;  // owned staging images for host-buffer entry points
+    std::vector<float *> d_depth;
+    std::vector<float *> d_ext[2];
+    int pitch = 0;
+    std::string err;
+    bool pending = false;
+
+    void set_error(const std::string &s) { err = s; }
+
+    template <typename T>
+    T *dalloc(size_t n) {
+        void *p = nullptr;
+        size_t bytes = ((n * sizeof(T) + 255) / 256) * 256;
+        if (bytes == 0) bytes = 256;
+        HIPCHK(this, hipMalloc(&p, bytes));
+        HIPCHK(this, hipMemset(p, 0, bytes));
+        allocs.push_back(p);
+        return static_cast<T *>(p);
+    }
+
+    ~Context() {
+        if (stream && own_stream) (void)hipStreamSynchronize(stream);
+        for (void *p : allocs) (void)hipFree(p);
+        if (h_ctl) (void)hipHostFree(h_ctl);
+        if (h_fargs) (void)hipHostFree(h_fargs);
+        if (stream && own_stream) (void)hipStreamDestroy(stream);
+    }
+};
+
+// ---- parameters ---------------------------------------------------------------------------------
+static bool derive_params(const lvt_amd_params &in, int sensor, Params &p) {
+    if (in.img_width <= 0 || in.img_height <= 0 || in.detection_cell_size <= 0 || in.max_keypoints_per_cell <= 0 ||
+        in.tracking_radius <= 0 || in.agast_threshold <= 0)
+        return false;  // the reference asserts these (lvt_image_features_handler.cpp:88-93)
+    std::memset(&p, 0, sizeof(p));
+    p.fx = in.fx, p.fy = in.fy, p.cx = in.cx, p.cy = in.cy, p.baseline = in.baseline;
+    p.k1 = in.k1, p.k2 = in.k2, p.p1 = in.p1, p.p2 = in.p2, p.k3 = in.k3;
+    p.near_plane = in.near_plane_distance, p.far_plane = in.far_plane_distance;
+    p.tri_ratio = in.triangulation_ratio_test_threshold;
+    p.track_ratio = in.tracking_ratio_test_threshold;
+    p.desc_th = in.descriptor_matching_threshold;
+    p.W = in.img_width, p.H = in.img_height;
+    p.min_matches = in.min_num_matches_for_tracking;
+    p.tracking_radius = in.tracking_radius;
+    p.cell_size = in.detection_cell_size;
+    p.max_kp_cell = in.max_keypoints_per_cell;
+    p.agast_th = in.agast_threshold;
+    p.agast_th_low = (int)((double)in.agast_threshold * 0.5 + 0.5);  // handler.cpp:165
+    p.untracked_th = in.untracked_threshold;
+    p.staged_th = in.staged_threshold;
+    p.tri_policy = in.triangulation_policy;
+    p.sensor = sensor;
+    // detection grid -- handler.cpp:95-114
+    p.cells_y = 1 + ((p.H - 1) / p.cell_size);
+    p.cells_x = 1 + ((p.W - 1) / p.cell_size);
+    p.n_cells = p.cells_x * p.cells_y;
+    if (p.n_cells > CELLS_MAX) return false;
+    // matching hash grid -- struct.cpp:47-53
+    const float kc = (float)HASH_CELL;
+    p.hash_ccx = (int)std::ceil(p.W / kc);
+    p.hash_ccy = (int)std::ceil(p.H / kc);
+    p.cell_search_radius = (p.tracking_radius == HASH_CELL) ? 1 : (int)std::ceil((float)p.tracking_radius / kc);
+    // image bounds -- lvt_local_map.cpp:84-123 (per instance)
+    if (std::fabs(p.k1) < 1e-5) {
+        p.min_x = 0.0f, p.max_x = (float)p.W, p.min_y = 0.0f, p.max_y = (float)p.H;
+    } else {
+        float x[4], y[4];
+        undistort_point(p, 0.0f, 0.0f, x[0], y[0]);
+        undistort_point(p, (float)p.W, 0.0f, x[1], y[1]);
+        undistort_point(p, 0.0f, (float)p.H, x[2], y[2]);
+        undistort_point(p, (float)p.W, (float)p.H, x[3], y[3]);
+        p.min_x = std::min(x[0], x[2]);
+        p.max_x = std::max(x[1], x[3]);
+        p.min_y = std::min(y[0], y[1]);
+        p.max_y = std::max(y[2], y[3]);
+    }
+    p.undistort = (std::fabs(p.k1) > 1e-5) ? 1 : 0;
+    return true;
+}
+
+static void default_params(lvt_amd_params *p) {  // lvt_parameters.cpp:29-52
+    std::memset(p, 0, sizeof(*p));
+    p->fx = p->fy = p->cx = p->cy = 0.5f;
+    p->near_plane_distance = 0.1f;
+    p->far_plane_distance = 500.0f;
+    p->triangulation_ratio_test_threshold = 0.60f;
+    p->tracking_ratio_test_threshold = 0.80f;
+    p->descriptor_matching_threshold = 30.0f;
+    p->min_num_matches_for_tracking = 10;
+    p->tracking_radius = 25;
+    p->agast_threshold = 25;
+    p->untracked_threshold = 10;
+    p->staged_threshold = 2;
+    p->detection_cell_size = 250;
+    p->max_keypoints_per_cell = 150;
+    p->triangulation_policy = 1;
+}
+
+// minimal reader for the reference's flat `%YAML:1.0` configs (lvt_parameters.cpp:54-93): every field
+// is overwritten; a key that is missing reads as 0 (cv::FileNode default), reals round to ints.
+static bool params_from_file(const char *fname, lvt_amd_params *p) {
+    FILE *f = fname ? std::fopen(fname, "r") : nullptr;
+    if (!f) return false;
+    std::vector<std::pair<std::string, double>> kv;
+    char line[1024];
+    while (std::fgets(line, sizeof(line), f)) {
+        char *hash = std::strchr(line, '#');
+        if (hash) *hash = 0;
+        char *colon = std::strchr(line, ':');
+        if (!colon || line[0] == '%') continue;
+        std::string key(line, colon - line);
+        size_t a = key.find_first_not_of(" \t"), b = key.find_last_not_of(" \t");
+        if (a == std::string::npos) continue;
+        key = key.substr(a, b - a + 1);
+        char *end = nullptr;
+        double v = std::strtod(colon + 1, &end);
+        if (end == colon + 1) continue;
+        kv.emplace_back(key, v);
+    }
+    std::fclose(f);
+    auto get = [&](const char *k) -> double {
+        for (auto &e : kv)
+            if (e.first == k) return e.second;
+        return 0.0;
+    };
+    auto geti = [&](const char *k) -> int { return (int)std::nearbyint(get(k)); };
+    p->fx = (float)get("fx"), p->fy = (float)get("fy"), p->cx = (float)get("cx"), p->cy = (float)get("cy");
+    p->k1 = (float)get("k1"), p->k2 = (float)get("k2"), p->p1 = (float)get("p1"), p->p2 = (float)get("p2"), p->k3 = (float)get("k3");
+    p->baseline = (float)get("baseline");
+    p->img_width = geti("img_width"), p->img_height = geti("img_height");
+    p->near_plane_distance = (float)get("near_plane_distance");
+    p->far_plane_distance = (float)get("far_plane_distance");
+    p->triangulation_ratio_test_threshold = (float)get("triangulation_ratio_test_threshold");
+    p->tracking_ratio_test_threshold = (float)get("tracking_ratio_test_threshold");
+    p->min_num_matches_for_tracking = geti("min_num_matches_for_tracking");
+    p->tracking_radius = geti("tracking_radius");
+    p->agast_threshold = geti("agast_threshold");
+    p->untracked_threshold = geti("untracked_threshold");
+    p->staged_threshold = geti("staged_threshold");
+    p->descriptor_matching_threshold = (float)get("descriptor_matching_threshold");
+    p->detection_cell_size = geti("detection_cell_size");
+    p->max_keypoints_per_cell = geti("max_keypoints_per_cell");
+    p->triangulation_policy = geti("triangulation_policy");
+    return true;
+}
+
+// ---- context creation ---------------------------------------------------------------------------
+static void alloc_feat(Context *c, Feat &F) {
+    F.x = c->dalloc<float>(NF_MAX), F.y = c->dalloc<float>(NF_MAX), F.resp = c->dalloc<float>(NF_MAX);
+    F.bx = c->dalloc<float>(NF_MAX), F.by = c->dalloc<float>(NF_MAX), F.depth = c->dalloc<float>(NF_MAX);
+    F.desc = c->dalloc<uint64_t>((size_t)NF_MAX * 4);
+    F.flag = c->dalloc<uint8_t>(NF_MAX);
+    F.hcx = c->dalloc<int16_t>(NF_MAX), F.hcy = c->dalloc<int16_t>(NF_MAX);
+    F.n = c->dalloc<int>(1);
+}
+static void alloc_points(Context *c, MapSoA &P, int cap) {
+    P.pos = c->dalloc<double>((size_t)cap * 3);
+    P.desc = c->dalloc<uint64_t>((size_t)cap * 4);
+    P.counter = c->dalloc<int>(cap), P.age = c->dalloc<int>(cap), P.match_idx = c->dalloc<int>(cap);
+}
+
+static void reset_state(Context *c) {  // lvt_system::reset (lvt_system.cpp:44-68)
+    for (int s = 0; s < c->B; s++) {
+        Ctl z;
+        std::memset(&z, 0, sizeof(z));
+        z.state = 1;
+        z.last_matches[0] = z.last_matches[1] = z.last_matches[2] = 0x7FFFFFFF;
+        z.last_pose.q[0] = 1.0;
+        z.mm_last_q[0] = 1.0;
+        z.mm_ang_vel[0] = 1.0;
+        z.optimized.q[0] = z.predicted.q[0] = 1.0;
+        z.out_R[0] = z.out_R[4] = z.out_R[8] = 1.0;
+        z.out_status = 1;
+        HIPCHK(c, hipMemcpyAsync(c->d_ctl[s], &z, sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemsetAsync(c->h_seqs[s].map_n, 0, sizeof(int), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->h_seqs[s].map_cur, 0, sizeof(int), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->h_seqs[s].staged_n, 0, sizeof(int), c->stream));
+        HIPCHK(c, hipMemsetAsync(c->h_seqs[s].staged_cur, 0, sizeof(int), c->stream));
+        c->h_ctl[s] = z;
+    }
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+}
+
+static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
+    if (sensor != 1 && sensor != 2) return nullptr;
+    Params prm;
+    if (!derive_params(in, sensor, prm)) return nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return nullptr;  // no CPU fallback, by design
+    Context *c = new Context();
+    try {
+        c->B = B;
+        c->sensor = sensor;
+        c->prm = prm;
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        c->own_stream = true;
+        c->pitch = ((prm.W + 63) / 64) * 64;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl) * B, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&c->h_fargs, sizeof(FrameArgs) * B, hipHostMallocDefault));
+        c->h_seqs.resize(B);
+        c->d_ctl.resize(B);
+        const size_t plane = (size_t)c->pitch * prm.H;
+        for (int s = 0; s < B; s++) {
+            Seq &S = c->h_seqs[s];
+            std::memset(&S, 0, sizeof(S));
+            S.prm = prm;
+            S.ctl = c->d_ctl[s] = c->dalloc<Ctl>(1);
+            S.plane_pitch = c->pitch;
+            for (int e = 0; e < 2; e++) {
+                S.score[e] = c->dalloc<uint8_t>(plane + 64);
+                S.boxsum[e] = c->dalloc<uint16_t>(plane + 64);
+                S.cell_kp[e] = c->dalloc<float>((size_t)CELLS_MAX * CELL_OUT_CAP * 3);
+                S.cell_n[e] = c->dalloc<int>(CELLS_MAX);
+                alloc_feat(c, S.feat[e]);
+                float *ext = c->dalloc<float>((size_t)EXT_MAX * 2);
+                c->d_ext[e].push_back(ext);
+                S.ext_xy[e] = ext;
+            }
+            for (int k = 0; k < 2; k++) {
+                alloc_points(c, S.map[k], MAP_MAX);
+                alloc_points(c, S.staged[k], STAGED_MAX);
+            }
+            S.map_cur = c->dalloc<int>(1), S.map_n = c->dalloc<int>(1);
+            S.staged_cur = c->dalloc<int>(1), S.staged_n = c->dalloc<int>(1);
+            S.proj = c->dalloc<float>((size_t)MAP_MAX * 2);
+            S.vis = c->dalloc<int8_t>(MAP_MAX);
+            S.match = c->dalloc<int>(MAP_MAX);
+            S.cand = c->dalloc<uint32_t>((size_t)MAP_MAX * KC);
+            S.ncand = c->dalloc<int>(MAP_MAX);
+            S.sproj = c->dalloc<float>((size_t)STAGED_MAX * 2);
+            S.svis = c->dalloc<int8_t>(STAGED_MAX);
+            S.smatch = c->dalloc<int>(STAGED_MAX);
+            S.scand = c->dalloc<uint32_t>((size_t)STAGED_MAX * KC);
+            S.sncand = c->dalloc<int>(STAGED_MAX);
+            S.sdel = c->dalloc<uint8_t>(STAGED_MAX);
+            S.pnp_X = c->dalloc<double>((size_t)NF_MAX * 3);
+            S.pnp_obs = c->dalloc<float>((size_t)NF_MAX * 2);
+            S.pnp_feat = c->dalloc<int>(NF_MAX);
+            S.pnp_err = c->dalloc<double>((size_t)NF_MAX * 2);
+            S.pnp_level = c->dalloc<int8_t>(NF_MAX);
+            S.rcand = c->dalloc<uint32_t>((size_t)NF_MAX * KC);
+            S.rncand = c->dalloc<int>(NF_MAX);
+            S.pair_l = c->dalloc<int>(NF_MAX), S.pair_r = c->dalloc<int>(NF_MAX);
+            S.tri_X = c->dalloc<double>((size_t)NF_MAX * 3);
+            S.tri_ok = c->dalloc<int8_t>(NF_MAX);
+            // staging images for the host-buffer entry points
+            c->d_img_l.push_back(c->dalloc<uint8_t>(plane + 64));
+            c->d_img_r.push_back(c->dalloc<uint8_t>(plane + 64));
+            c->d_depth.push_back(sensor == 2 ? c->dalloc<float>((size_t)prm.W * prm.H) : nullptr);
+        }
+        c->d_seqs = c->dalloc<Seq>(B);
+        HIPCHK(c, hipMemcpy(c->d_seqs, c->h_seqs.data(), sizeof(Seq) * B, hipMemcpyHostToDevice));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                      CELLS_LDS_BYTES));
+        reset_state(c);
+    } catch (...) {
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+
+// ---- the per-frame launch chain -------------------------------------------------------------------
+static void enqueue_frame(Context *c, int ext_corners, int n_ext_l, int n_ext_r) {
+    const int B = c->B;
+    hipStream_t st = c->stream;
+    const Params &p = c->prm;
+    Seq *S = c->d_seqs;
+    hipLaunchKernelGGL(k_set_frame, dim3(B), dim3(64), 0, st, S, c->h_fargs);
+    hipLaunchKernelGGL(k_begin, dim3(B), dim3(64), 0, st, S, ext_corners, n_ext_l, n_ext_r);
+    hipLaunchKernelGGL(k_score, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2 * B), dim3(256), 0, st, S);
+    if (!ext_corners) {
+        hipLaunchKernelGGL(k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, st, S, 0);
+        hipLaunchKernelGGL(k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, st, S, 1);
+    }
+    hipLaunchKernelGGL(k_gather, dim3(1, 2, B), dim3(1024), 0, st, S);
+    hipLaunchKernelGGL(k_brief, dim3(64, 2, B), dim3(256), 0, st, S);
+    hipLaunchKernelGGL(k_project, dim3(32, 1, B), dim3(256), 0, st, S, (int)MODE_MAP);
+    hipLaunchKernelGGL(k_candidates<MODE_MAP>, dim3(256, 1, B), dim3(256), 0, st, S, 0);
+    hipLaunchKernelGGL(k_resolve<MODE_MAP>, dim3(1, 1, B), dim3(256), 0, st, S, 0);
+    hipLaunchKernelGGL(k_candidates<MODE_MAP>, dim3(256, 1, B), dim3(256), 0, st, S, 1);
+    hipLaunchKernelGGL(k_resolve<MODE_MAP>, dim3(1, 1, B), dim3(256), 0, st, S, 1);
+    hipLaunchKernelGGL(k_bookkeep, dim3(1, 1, B), dim3(1024), 0, st, S);
+    hipLaunchKernelGGL(k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), 0, st, S);
+    hipLaunchKernelGGL(k_cull, dim3(1, 1, B), dim3(1024), 0, st, S);
+    hipLaunchKernelGGL(k_project, dim3(32, 1, B), dim3(256), 0, st, S, (int)MODE_STAGED);
+    hipLaunchKernelGGL(k_candidates<MODE_STAGED>, dim3(64, 1, B), dim3(256), 0, st, S, 0);
+    hipLaunchKernelGGL(k_staged, dim3(1, 1, B), dim3(1024), 0, st, S);
+    hipLaunchKernelGGL(k_candidates<MODE_ROW>, dim3(256, 1, B), dim3(256), 0, st, S, 0);
+    hipLaunchKernelGGL(k_resolve<MODE_ROW>, dim3(1, 1, B), dim3(256), 0, st, S, 0);
+    hipLaunchKernelGGL(k_triangulate, dim3(1, 1, B), dim3(1024), 0, st, S);
+    hipLaunchKernelGGL(k_finalize, dim3(B), dim3(64), 0, st, S);
+    for (int s = 0; s < B; s++)
+        (void)hipMemcpyAsync(&c->h_ctl[s], c->d_ctl[s], sizeof(Ctl), hipMemcpyDeviceToHost, st);
+    c->pending = true;
+}
+
+static void wait_frame(Context *c) {
+    if (!c->pending) return;
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    c->pending = false;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) c->set_error(std::string("kernel chain: ") + hipGetErrorString(e));
+    for (int s = 0; s < c->B; s++)
+        if (c->h_ctl[s].overflow) {
+            char buf[128];
+            std::snprintf(buf, sizeof(buf), "capacity overflow mask 0x%x in sequence %d", c->h_ctl[s].overflow, s);
+            c->set_error(buf);
+        }
+}
+
+static void result_out(Context *c, int s, double R[3][3], double t[3]) {
+    const Ctl &h = c->h_ctl[s];
+    if (R)
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) R[i][j] = h.out_R[3 * i + j];
+    if (t)
+        for (int i = 0; i < 3; i++) t[i] = h.out_t[i];
+}
+
+static bool size_ok(Context *c, int rows, int cols) { return rows == c->prm.H && cols == c->prm.W; }
+
+template <typename T>
+static void d2h(Context *c, T *dst, const T *src, size_t n) {
+    if (n && dst) HIPCHK(c, hipMemcpy(dst, src, sizeof(T) * n, hipMemcpyDeviceToHost));
+}
+static int read_scalar(Context *c, const int *d) {
+    int v = 0;
+    HIPCHK(c, hipMemcpy(&v, d, sizeof(int), hipMemcpyDeviceToHost));
+    return v;
+}
+
+}  // namespace lvt
+
+using namespace lvt;
+
+// =================================================================================================
+// C-ABI
+// =================================================================================================
+extern "C" {
+
+LVT_API void lvt_amd_default_params(lvt_amd_params *p) { default_params(p); }
+LVT_API int lvt_amd_params_from_file(const char *f, lvt_amd_params *p) { return params_from_file(f, p) ? 1 : 0; }
+
+LVT_API lvt_handle lvt_amd_create(const lvt_amd_params *p, int sensor_type) {
+    try {
+        return static_cast<lvt_handle>(create_context(*p, sensor_type, 1));
+    } catch (...) {
+    }
+    return nullptr;
+}
+
+LVT_API lvt_handle lvt_create(const char *config_file_name, int sensor_type) {
+    try {
+        lvt_amd_params p;
+        default_params(&p);
+        if (params_from_file(config_file_name, &p) && (sensor_type == 1 || sensor_type == 2))
+            return static_cast<lvt_handle>(create_context(p, sensor_type, 1));
+    } catch (...) {
+    }
+    return nullptr;
+}
+
+LVT_API void lvt_destroy(lvt_handle h) {
+    try {
+        delete static_cast<Context *>(h);
+    } catch (...) {
+    }
+}
+
+LVT_API void lvt_amd_reset(lvt_handle h) {
+    try {
+        Context *c = static_cast<Context *>(h);
+        wait_frame(c);
+        reset_state(c);
+    } catch (...) {
+    }
+}
+
+LVT_API void lvt_amd_set_stream(lvt_handle h, void *hip_stream) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        wait_frame(c);
+        if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
+        c->stream = static_cast<hipStream_t>(hip_stream);
+        c->own_stream = false;
+    } catch (...) {
+    }
+}
+
+LVT_API const char *lvt_amd_last_error(lvt_handle h) { return static_cast<Context *>(h)->err.c_str(); }
+
+LVT_API void lvt_amd_track_device_async(lvt_handle h, const void *d_left, const void *d_right, int n_rows, int n_cols, int pitch_bytes) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        if (!size_ok(c, n_rows, n_cols) || (pitch_bytes & 15)) {
+            c->set_error("lvt_amd_track_device: image size / pitch mismatch");
+            return;
+        }
+        wait_frame(c);
+        c->h_fargs[0].img[0] = static_cast<const uint8_t *>(d_left);
+        c->h_fargs[0].img[1] = static_cast<const uint8_t *>(d_right);
+        c->h_fargs[0].depth = nullptr;
+        c->h_fargs[0].img_pitch = pitch_bytes;
+        c->h_fargs[0].depth_pitch = 0;
+        enqueue_frame(c, 0, 0, 0);
+    } catch (...) {
+    }
+}
+
+LVT_API void lvt_amd_wait(lvt_handle h, double R[3][3], double t[3]) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        wait_frame(c);
+        result_out(c, 0, R, t);
+    } catch (...) {
+    }
+}
+
+LVT_API void lvt_amd_track_device(lvt_handle h, const void *d_left, const void *d_right, int n_rows, int n_cols, int pitch_bytes,
+                                  double R[3][3], double t[3]) {
+    Context *c = static_cast<Context *>(h);
+    if (!size_ok(c, n_rows, n_cols) || (pitch_bytes & 15)) {
+        c->set_error("lvt_amd_track_device: image size / pitch mismatch");
+        return;  // outputs untouched, like the reference on an exception
+    }
+    lvt_amd_track_device_async(h, d_left, d_right, n_rows, n_cols, pitch_bytes);
+    lvt_amd_wait(h, R, t);
+}
+
+static void upload_and_track(Context *c, const unsigned char *left, const void *second, bool rgbd, int n_rows, int n_cols, int ext,
+                             const float *cl, int ncl, const float *cr, int ncr, double R[3][3], double t[3]) {
+    if (!size_ok(c, n_rows, n_cols)) {
+        c->set_error("lvt_track: image size differs from the configured img_width/img_height");
+        return;
+    }
+    wait_frame(c);
+    HIPCHK(c, hipMemcpy2DAsync(c->d_img_l[0], c->pitch, left, n_cols, n_cols, n_rows, hipMemcpyHostToDevice, c->stream));
+    c->h_fargs[0].img[0] = c->d_img_l[0];
+    c->h_fargs[0].img[1] = c->d_img_r[0];
+    c->h_fargs[0].img_pitch = c->pitch;
+    c->h_fargs[0].depth = nullptr;
+    c->h_fargs[0].depth_pitch = 0;
+    if (rgbd) {
+        HIPCHK(c, hipMemcpyAsync(c->d_depth[0], second, sizeof(float) * (size_t)n_rows * n_cols, hipMemcpyHostToDevice, c->stream));
+        c->h_fargs[0].depth = c->d_depth[0];
+        c->h_fargs[0].depth_pitch = n_cols;
+    } else {
+        HIPCHK(c, hipMemcpy2DAsync(c->d_img_r[0], c->pitch, second, n_cols, n_cols, n_rows, hipMemcpyHostToDevice, c->stream));
+    }
+    if (ext) {
+        if (ncl) HIPCHK(c, hipMemcpyAsync(c->d_ext[0][0], cl, sizeof(float) * 2 * (size_t)ncl, hipMemcpyHostToDevice, c->stream));
+        if (ncr) HIPCHK(c, hipMemcpyAsync(c->d_ext[1][0], cr, sizeof(float) * 2 * (size_t)ncr, hipMemcpyHostToDevice, c->stream));
+    }
+    enqueue_frame(c, ext, ncl, ncr);
+    wait_frame(c);
+    result_out(c, 0, R, t);
+}
+
+LVT_API void lvt_track(lvt_handle h, unsigned char *left, unsigned char *right, int n_rows, int n_cols, double R[3][3], double t[3]) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        if (c->sensor != 1) return;  // the reference cannot run RGB-D through this entry either
+        upload_and_track(c, left, right, false, n_rows, n_cols, 0, nullptr, 0, nullptr, 0, R, t);
+    } catch (...) {
+    }
+}
+
+LVT_API void lvt_amd_track_rgbd(lvt_handle h, const unsigned char *gray, const float *depth, int n_rows, int n_cols, double R[3][3],
+                                double t[3]) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        if (c->sensor != 2) return;
+        upload_and_track(c, gray, depth, true, n_rows, n_cols, 0, nullptr, 0, nullptr, 0, R, t);
+    } catch (...) {
+    }
+}
+
+LVT_API void lvt_track_with_external_corners(lvt_handle h, unsigned char *left, unsigned char *right, int n_rows, int n_cols,
+                                             double corners_left[][2], int n_corners_left, double corners_right[][2],
+                                             int n_corners_right, double R[3][3], double t[3]) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        if (c->sensor != 1) return;
+        const int ncl = std::min(n_corners_left, EXT_MAX), ncr = std::min(n_corners_right, EXT_MAX);
+        std::vector<float> cl(2 * (size_t)ncl + 2), cr(2 * (size_t)ncr + 2);
+        for (int i = 0; i < ncl; i++) {  // doubles narrowed to float (lvt_c.cpp:104-117)
+            cl[2 * i] = (float)corners_left[i][0];
+            cl[2 * i + 1] = (float)corners_left[i][1];
+        }
+        for (int i = 0; i < ncr; i++) {
+            cr[2 * i] = (float)corners_right[i][0];
+            cr[2 * i + 1] = (float)corners_right[i][1];
+        }
+        upload_and_track(c, left, right, false, n_rows, n_cols, 1, cl.data(), ncl, cr.data(), ncr, R, t);
+    } catch (...) {
+    }
+}
+
+LVT_API int lvt_get_status(lvt_handle h) {
+    try {
+        Context *c = static_cast<Context *>(h);
+        wait_frame(c);
+        return c->h_ctl[0].out_status == 0 ? c->h_ctl[0].state : (c->h_ctl[0].state);
+    } catch (...) {
+    }
+    return -1;
+}
+
+// ---- introspection --------------------------------------------------------------------------------
+LVT_API void lvt_amd_get_counts(lvt_handle h, int out[LVT_AMD_C__COUNT]) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        wait_frame(c);
+        for (int i = 0; i < LVT_AMD_C__COUNT; i++) out[i] = c->h_ctl[0].counts[i];
+    } catch (...) {
+    }
+}
+
+
+LVT_API int lvt_amd_get_features(lvt_handle h, int eye, float *xy, float *resp, uint8_t *desc, int cap) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        wait_frame(c);
+        const Feat &F = c->h_seqs[0].feat[eye ? 1 : 0];
+        const int n = read_scalar(c, F.n), m = std::min(n, cap);
+        std::vector<float> x(m), y(m);
+        d2h(c, x.data(), F.x, m);
+        d2h(c, y.data(), F.y, m);
+        if (xy)
+            for (int i = 0; i < m; i++) xy[2 * i] = x[i], xy[2 * i + 1] = y[i];
+        d2h(c, resp, F.resp, m);
+        d2h(c, desc, reinterpret_cast<const uint8_t *>(F.desc), (size_t)m * 32);
+        return n;
+    } catch (...) {
+    }
+    return -1;
+}
+
+LVT_API int lvt_amd_get_matches(lvt_handle h, int *feat_idx, double *xyz, int cap) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        wait_frame(c);
+        const int n = c->h_ctl[0].n_matches, m = std::min(n, cap);
+        d2h(c, feat_idx, c->h_seqs[0].pnp_feat, m);
+        d2h(c, xyz, c->h_seqs[0].pnp_X, (size_t)m * 3);
+        return n;
+    } catch (...) {
+    }
+    return -1;
+}
+
+LVT_API int lvt_amd_get_row_matches(lvt_handle h, int *pairs, int cap) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        wait_frame(c);
+        const int n = c->h_ctl[0].counts[C_N_ROW_MATCHES], m = std::min(n, cap);
+        std::vector<int> l(m), r(m);
+        d2h(c, l.data(), c->h_seqs[0].pair_l, m);
+        d2h(c, r.data(), c->h_seqs[0].pair_r, m);
+        for (int i = 0; i < m; i++) pairs[2 * i] = l[i], pairs[2 * i + 1] = r[i];
+        return n;
+    } catch (...) {
+    }
+    return -1;
+}
+
+static int get_points(Context *c, const MapSoA *bufs, const int *d_cur, const int *d_n, double *xyz, int *counter, int *age, uint8_t *desc,
+                      int cap) {
+    const int cur = read_scalar(c, d_cur), n = read_scalar(c, d_n), m = std::min(n, cap);
+    const MapSoA &P = bufs[cur];
+    d2h(c, xyz, P.pos, (size_t)m * 3);
+    d2h(c, counter, P.counter, m);
+    d2h(c, age, P.age, m);
+    d2h(c, desc, reinterpret_cast<const uint8_t *>(P.desc), (size_t)m * 32);
+    return n;
+}
+LVT_API int lvt_amd_get_map(lvt_handle h, double *xyz, int *counter, int *age, uint8_t *desc, int cap) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        wait_frame(c);
+        const Seq &S = c->h_seqs[0];
+        return get_points(c, S.map, S.map_cur, S.map_n, xyz, counter, age, desc, cap);
+    } catch (...) {
+    }
+    return -1;
+}
+LVT_API int lvt_amd_get_staged(lvt_handle h, double *xyz, int *counter, uint8_t *desc, int cap) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        wait_frame(c);
+        const Seq &S = c->h_seqs[0];
+        return get_points(c, S.staged, S.staged_cur, S.staged_n, xyz, counter, nullptr, desc, cap);
+    } catch (...) {
+    }
+    return -1;
+}
+LVT_API void lvt_amd_get_pose(lvt_handle h, double q[4], double p[3]) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        wait_frame(c);
+        for (int k = 0; k < 4; k++) q[k] = c->h_ctl[0].last_pose.q[k];
+        for (int k = 0; k < 3; k++) p[k] = c->h_ctl[0].last_pose.p[k];
+    } catch (...) {
+    }
+}
+LVT_API void lvt_amd_get_predicted_pose(lvt_handle h, double q[4], double p[3]) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        wait_frame(c);
+        for (int k = 0; k < 4; k++) q[k] = c->h_ctl[0].predicted.q[k];
+        for (int k = 0; k < 3; k++) p[k] = c->h_ctl[0].predicted.p[k];
+    } catch (...) {
+    }
+}
+LVT_API int lvt_amd_get_plane(lvt_handle h, int eye, int what, void *dst, int cap_bytes, int *pitch_out) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        wait_frame(c);
+        const Seq &S = c->h_seqs[0];
+        const size_t n = (size_t)c->pitch * c->prm.H;
+        const size_t bytes = n * (what == 0 ? 1 : 2);
+        if ((size_t)cap_bytes < bytes) return -1;
+        if (what == 0) HIPCHK(c, hipMemcpy(dst, S.score[eye ? 1 : 0], bytes, hipMemcpyDeviceToHost));
+        else HIPCHK(c, hipMemcpy(dst, S.boxsum[eye ? 1 : 0], bytes, hipMemcpyDeviceToHost));
+        if (pitch_out) *pitch_out = c->pitch;
+        return (int)bytes;
+    } catch (...) {
+    }
+    return -1;
+}
+
+// ---- stage entry: motion-only BA on caller data ---------------------------------------------------
+LVT_API int lvt_amd_pnp(const lvt_amd_params *pin, const double q_in[4], const double p_in[3], const double *pts, const float *obs, int n,
+                        double q_out[4], double p_out[3], int *n_solve_calls) {
+    Params prm;
+    lvt_amd_params tmp = *pin;
+    if (tmp.img_width <= 0) tmp.img_width = 64;
+    if (tmp.img_height <= 0) tmp.img_height = 64;
+    if (!derive_params(tmp, 1, prm)) return -1;
+    double *dX = nullptr, *dErr = nullptr;
+    float *dObs = nullptr;
+    int8_t *dLevel = nullptr;
+    Pose *dOut = nullptr;
+    int *dInfo = nullptr;
+    int rc = -1;
+    const size_t nn = (size_t)std::max(n, 1);
+    if (hipMalloc((void **)&dX, nn * 24) == hipSuccess && hipMalloc((void **)&dErr, nn * 16) == hipSuccess &&
+        hipMalloc((void **)&dObs, nn * 8) == hipSuccess && hipMalloc((void **)&dLevel, nn) == hipSuccess &&
+        hipMalloc((void **)&dOut, sizeof(Pose)) == hipSuccess && hipMalloc((void **)&dInfo, 8) == hipSuccess) {
+        (void)hipMemcpy(dX, pts, (size_t)n * 24, hipMemcpyHostToDevice);
+        (void)hipMemcpy(dObs, obs, (size_t)n * 8, hipMemcpyHostToDevice);
+        Pose prior;
+        for (int k = 0; k < 4; k++) prior.q[k] = q_in[k];
+        for (int k = 0; k < 3; k++) prior.p[k] = p_in[k];
+        hipLaunchKernelGGL(k_pnp_standalone, dim3(1), dim3(PNP_THREADS), 0, 0, prm, prior, dX, dObs, dErr, dLevel, n, dOut, dInfo);
+        Pose out;
+        int info[2] = {0, 0};
+        if (hipMemcpy(&out, dOut, sizeof(Pose), hipMemcpyDeviceToHost) == hipSuccess &&
+            hipMemcpy(info, dInfo, 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            for (int k = 0; k < 4; k++) q_out[k] = out.q[k];
+            for (int k = 0; k < 3; k++) p_out[k] = out.p[k];
+            if (n_solve_calls) *n_solve_calls = info[0];
+            rc = info[1];
+        }
+    }
+    (void)hipFree(dX), (void)hipFree(dErr), (void)hipFree(dObs), (void)hipFree(dLevel), (void)hipFree(dOut), (void)hipFree(dInfo);
+    return rc;
+}
+
+
+// ---- stage entry: batched masked 2-NN Hamming matcher on device-resident problems --------------------
+LVT_API float lvt_amd_hamming_match_batched(const void *q_desc, const void *q_xy, const void *t_desc, const void *t_xy, const void *t_flag,
+                                            int B, int M, int N, float r2, int mode, int img_rows, int img_cols, void *out,
+                                            void *hip_stream) {
+    if (B <= 0 || M <= 0 || N <= 0 || N > 65535) return -1.0f;
+    HammingArgs a;
+    a.q_desc = static_cast<const uint64_t *>(q_desc);
+    a.q_xy = static_cast<const float2 *>(q_xy);
+    a.t_desc = static_cast<const uint64_t *>(t_desc);
+    a.t_xy = static_cast<const float2 *>(t_xy);
+    a.t_flag = static_cast<const uint8_t *>(t_flag);
+    a.out = static_cast<int4 *>(out);
+    a.M = M, a.N = N, a.r2 = r2, a.img_rows = img_rows, a.img_cols = img_cols;
+    if (mode == 1) {
+        a.nbx = 1, a.nby = img_rows + 1, a.csr = 0;
+    } else {
+        a.nbx = (int)std::ceil(img_cols / (float)HASH_CELL), a.nby = (int)std::ceil(img_rows / (float)HASH_CELL);
+        a.csr = std::max(1, (int)std::ceil(std::sqrt(r2) / (float)HASH_CELL));
+    }
+    const size_t lds = hamming_lds_bytes(N, a.nbx * a.nby);
+    if (lds > 160 * 1024) return -1.0f;
+    hipStream_t st = static_cast<hipStream_t>(hip_stream);
+    hipEvent_t e0, e1;
+    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0f;
+    float ms = -1.0f;
+    if (mode == 1) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hamming_batched<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipEventRecord(e0, st);
+        hipLaunchKernelGGL(k_hamming_batched<1>, dim3(B), dim3(256), lds, st, a);
+    } else {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hamming_batched<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipEventRecord(e0, st);
+        hipLaunchKernelGGL(k_hamming_batched<0>, dim3(B), dim3(256), lds, st, a);
+    }
+    (void)hipEventRecord(e1, st);
+    if (hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+    (void)hipEventDestroy(e0);
+    (void)hipEventDestroy(e1);
+    return ms < 0 ? -1.0f : ms * 1000.0f;
+}
+
+}  // extern "C"

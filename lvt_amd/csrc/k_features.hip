@@ -208,14 +208,20 @@ __device__ __forceinline__ int key_x(uint32_t k) { return (int)((k >> 8) & 1023)
 __device__ __forceinline__ int key_r(uint32_t k) { return (int)(k & 255); }
 __device__ __forceinline__ uint32_t key_pos(uint32_t k) { return k >> 8; }
 
-constexpr uint32_t NONE14 = 0x3FFFu;
-constexpr uint16_t NMS_MAX = 0xFFFFu;  // "is a maximum" (== -1 of the reference's nmsFlags)
+// index traits: 16-bit indices while a cell's corners fit in LDS, 32-bit in the global-memory path
+template <typename I> struct IdxT;
+template <> struct IdxT<uint16_t> {
+    static constexpr uint32_t NONE = 0x3FFFu, LEFT = 0x8000u, MAXF = 0xFFFFu;
+};
+template <> struct IdxT<uint32_t> {
+    static constexpr uint32_t NONE = 0x3FFFFFFFu, LEFT = 0x80000000u, MAXF = 0xFFFFFFFFu;
+};
 
 // ---- libstdc++ std::sort emulation pieces (comp(a,b) := resp(a) > resp(b); handler.cpp:38-41) ----
 __device__ __forceinline__ bool scomp(uint32_t a, uint32_t b) { return key_r(a) > key_r(b); }
 
 // heap fallback of introsort (std::__partial_sort(first,last,last)), sequential, one lane
-__device__ void heap_adjust(uint32_t *f, int hole, int len, uint32_t value) {
+__device__ __forceinline__ void heap_adjust(uint32_t *f, int hole, int len, uint32_t value) {
     const int top = hole;
     int child = hole;
     while (child < (len - 1) / 2) {
@@ -237,7 +243,7 @@ __device__ void heap_adjust(uint32_t *f, int hole, int len, uint32_t value) {
     }
     f[hole] = value;
 }
-__device__ void heap_sort_seq(uint32_t *f, int len) {
+__device__ __forceinline__ void heap_sort_seq(uint32_t *f, int len) {
     if (len >= 2) {
         int parent = (len - 2) / 2;
         while (true) {
@@ -259,7 +265,8 @@ __device__ void heap_sort_seq(uint32_t *f, int len) {
 // std::__unguarded_partition_pivot on arr[first,last) executed by ONE full wavefront.
 // Hoare partition evaluated with ballots: the k-th "left stop" (ascending) swaps with the k-th
 // "right stop" (descending) while they have not crossed (see DESIGN.md "std::sort emulation").
-__device__ int wave_partition_pivot(uint32_t *arr, int first, int last, uint16_t *posL, uint16_t *posR) {
+template <typename I>
+__device__ __forceinline__ int wave_partition_pivot(uint32_t *arr, int first, int last, I *posL, I *posR) {
     const int lane = lane_id();
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int mid = first + (last - first) / 2;
@@ -286,14 +293,14 @@ __device__ int wave_partition_pivot(uint32_t *arr, int first, int last, uint16_t
         const int p = base + lane;
         const bool isL = (p < hi) && !(key_r(arr[p]) > piv);
         const uint64_t m = __ballot(isL);
-        if (isL) posL[first + cntL + __popcll(m & lt_mask)] = (uint16_t)p;
+        if (isL) posL[first + cntL + __popcll(m & lt_mask)] = (I)p;
         cntL += __popcll(m);
     }
     for (int top = hi; top > lo; top -= 64) {
         const int q = top - 1 - lane;
         const bool isR = (q >= lo) && !(piv > key_r(arr[q]));
         const uint64_t m = __ballot(isR);
-        if (isR) posR[first + cntR + __popcll(m & lt_mask)] = (uint16_t)q;
+        if (isR) posR[first + cntR + __popcll(m & lt_mask)] = (I)q;
         cntR += __popcll(m);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -307,7 +314,7 @@ __device__ int wave_partition_pivot(uint32_t *arr, int first, int last, uint16_t
         if (b != ~0ull) break;  // monotone: once a pair has crossed, all later ones have
     }
     for (int k = lane; k < m; k += 64) {
-        const int p = posL[first + k], q = posR[first + k];
+        const int p = (int)posL[first + k], q = (int)posR[first + k];
         const uint32_t t = arr[p];
         arr[p] = arr[q];
         arr[q] = t;
@@ -320,7 +327,8 @@ __device__ int wave_partition_pivot(uint32_t *arr, int first, int last, uint16_t
 
 // std::__introsort_loop on arr[0,n): partitions only; the final insertion sort is a stable sort and
 // is done afterwards by ranking.  ONE wavefront; `stack` = 3*64 ints of LDS.
-__device__ void wave_introsort_partitions(uint32_t *arr, int n, uint16_t *posL, uint16_t *posR, int *stack) {
+template <typename I>
+__device__ __forceinline__ void wave_introsort_partitions(uint32_t *arr, int n, I *posL, I *posR, int *stack) {
     if (n <= 16) return;
     int depth0 = 0;
     for (int v = n; v > 1; v >>= 1) depth0++;
@@ -335,7 +343,7 @@ __device__ void wave_introsort_partitions(uint32_t *arr, int n, uint16_t *posL, 
                 break;
             }
             --depth;
-            const int cut = wave_partition_pivot(arr, first, last, posL, posR);
+            const int cut = wave_partition_pivot<I>(arr, first, last, posL, posR);
             if (last - cut > 16) {  // the recursive call introsort_loop(cut, last, depth)
                 if (lane_id() == 0) {
                     stack[3 * sp] = cut;
@@ -355,8 +363,8 @@ __device__ void wave_introsort_partitions(uint32_t *arr, int n, uint16_t *posL, 
     }
 }
 
-// LDS carve (bytes): keys 4*RAW | uf 4*RAW | root16 2*RAW | abv16 2*RAW | nms16 2*RAW | misc
-constexpr int CELLS_LDS_BYTES = RAW_CAP * 14 + 2 * 1024 * 2 + 64 * 4 + 3 * 64 * 4 + 64;
+// LDS carve (bytes): keys 4*RAW | uf 4*RAW | root 2*RAW | abv 2*RAW | nms 2*RAW | row_first/row_end | misc
+constexpr int CELLS_LDS_BYTES = RAW_CAP * 14 + 2 * 1024 * 4 + 64 * 4 + 3 * 64 * 4 + 64;
 
 __device__ __forceinline__ int uf_find(volatile uint32_t *parent, int i) {
     while (true) {
@@ -366,128 +374,104 @@ __device__ __forceinline__ int uf_find(volatile uint32_t *parent, int i) {
     }
 }
 
-__global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass) {
-    Seq &S = seqs[blockIdx.z];
-    const int eye = blockIdx.y, cell = blockIdx.x;
-    const Ctl &ctl = *S.ctl;
-    if (!ctl.active || ctl.ext_corners) return;
-    if (eye == 1 && S.prm.sensor == 2) return;
-    if (cell >= S.prm.n_cells) return;
-    int threshold = S.prm.agast_th;
-    if (pass == 1) {
-        if (ctl.n_detected[eye] >= CORNERS_LOW_TH) return;  // handler.cpp:161
-        threshold = S.prm.agast_th_low;
-    }
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t *keys = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *uf = keys + RAW_CAP;
-    uint16_t *root16 = reinterpret_cast<uint16_t *>(uf + RAW_CAP);
-    uint16_t *abv16 = root16 + RAW_CAP;
-    uint16_t *nms16 = abv16 + RAW_CAP;
-    uint16_t *row_first = nms16 + RAW_CAP;   // [1024]
-    uint16_t *row_end = row_first + 1024;    // [1024]
-    int *scan = reinterpret_cast<int *>(row_end + 1024);  // [64]
-    int *stack = scan + 64;                  // [192]
-    int *misc = stack + 192;                 // [16]
+struct CellGeom {
+    int X0, Y0, cw, ch, threshold, pp;
+    const uint8_t *score;
+};
 
+// raster-order compaction of the cell's raw corners into keys[0..cap); returns the true count
+__device__ __forceinline__ int cell_compact(const CellGeom &g, uint32_t *keys, int cap, int *scan) {
     const int tid = threadIdx.x;
-    const int cs = S.prm.cell_size;
-    const int cxi = cell % S.prm.cells_x, cyi = cell / S.prm.cells_x;
-    const int X0 = cxi * cs, Y0 = cyi * cs;
-    const int cw = min(cs, S.prm.W - X0), ch = min(cs, S.prm.H - Y0);
-    const uint8_t *score = S.score[eye];
-    const int pp = S.plane_pitch;
+    int n_raw = 0;
+    const int xa = g.X0 + 3, xb = g.X0 + g.cw - 4;  // inclusive pixel range
+    const int c0 = xa >> 4, c1 = xb >> 4;
+    const int nchunk = c1 - c0 + 1;
+    const int nrows = g.ch - 6;
+    const int items = nrows * nchunk;
+    for (int base = 0; base < items; base += 1024) {
+        const int it = base + tid;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        int ly = 0, gx0 = 0;
+        if (it < items) {
+            ly = 3 + it / nchunk;
+            gx0 = (c0 + it % nchunk) << 4;
+            v = *reinterpret_cast<const uint4 *>(g.score + (size_t)(g.Y0 + ly) * g.pp + gx0);
+        }
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        int cnt = 0;
+        if (it < items) {
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const int s = (w[b >> 2] >> (8 * (b & 3))) & 255;
+                const int gx = gx0 + b;
+                cnt += (s >= g.threshold && gx >= xa && gx <= xb) ? 1 : 0;
+            }
+        }
+        int total;
+        int off = n_raw + block_excl_scan(cnt, scan, &total);
+        if (it < items && cnt) {
+#pragma unroll
+            for (int b = 0; b < 16; b++) {
+                const int s = (w[b >> 2] >> (8 * (b & 3))) & 255;
+                const int gx = gx0 + b;
+                if (s >= g.threshold && gx >= xa && gx <= xb) {
+                    if (off < cap) keys[off] = mk_key(ly, gx - g.X0, s);
+                    off++;
+                }
+            }
+        }
+        n_raw += total;
+    }
+    __syncthreads();
+    return n_raw;
+}
 
-    // ---------------- phase 1: raster-order compaction of raw corners (score >= threshold)
+// AGAST NMS + LVT ANMS of one cell on arrays that live either in LDS (I = u16) or in global scratch
+// (I = u32).  Writes the cell's key points to `out` and returns how many.
+template <typename I>
+__device__ __forceinline__ int cell_nms_anms(const Seq &S, const CellGeom &g, uint32_t *keys, uint32_t *uf, I *root, I *abv, I *nms,
+                                             int n_raw, int *row_first, int *row_end, int *scan, int *stack, int *misc, float *out) {
+    constexpr uint32_t NONE = IdxT<I>::NONE, LEFT = IdxT<I>::LEFT, MAXF = IdxT<I>::MAXF;
+    const int tid = threadIdx.x;
+    // ---------------- neighbour links, union-find over 4-connected corner pixels
     for (int i = tid; i < 1024; i += 1024) {
-        row_first[i] = 0xFFFF;
+        row_first[i] = -1;
         row_end[i] = 0;
     }
-    int n_raw = 0;
-    bool ovf = false;
-    if (cw >= 7 && ch >= 7 && cw <= 1024 && ch <= 1024) {
-        const int xa = X0 + 3, xb = X0 + cw - 4;  // inclusive pixel range
-        const int c0 = xa >> 4, c1 = xb >> 4;
-        const int nchunk = c1 - c0 + 1;
-        const int nrows = ch - 6;
-        const int items = nrows * nchunk;
-        for (int base = 0; base < items; base += 1024) {
-            const int it = base + tid;
-            uint4 v = make_uint4(0, 0, 0, 0);
-            int ly = 0, gx0 = 0;
-            if (it < items) {
-                ly = 3 + it / nchunk;
-                gx0 = (c0 + it % nchunk) << 4;
-                v = *reinterpret_cast<const uint4 *>(score + (size_t)(Y0 + ly) * pp + gx0);
-            }
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-            int cnt = 0;
-            if (it < items) {
-#pragma unroll
-                for (int b = 0; b < 16; b++) {
-                    const int s = (w[b >> 2] >> (8 * (b & 3))) & 255;
-                    const int gx = gx0 + b;
-                    cnt += (s >= threshold && gx >= xa && gx <= xb) ? 1 : 0;
-                }
-            }
-            int total;
-            int off = n_raw + block_excl_scan(cnt, scan, &total);
-            if (it < items && cnt) {
-#pragma unroll
-                for (int b = 0; b < 16; b++) {
-                    const int s = (w[b >> 2] >> (8 * (b & 3))) & 255;
-                    const int gx = gx0 + b;
-                    if (s >= threshold && gx >= xa && gx <= xb) {
-                        if (off < RAW_CAP) keys[off] = mk_key(ly, gx - X0, s);
-                        off++;
-                    }
-                }
-            }
-            n_raw += total;
-        }
-        if (n_raw > RAW_CAP) {
-            ovf = true;
-            n_raw = RAW_CAP;
-        }
-    } else if (cw > 1024 || ch > 1024) {
-        if (tid == 0) atomicOr(&S.ctl->overflow, OVF_CELL_DIM);
-    }
-    if (ovf && tid == 0) atomicOr(&S.ctl->overflow, OVF_RAW);
     __syncthreads();
-
-    // ---------------- phase 2: neighbour links, union-find over 4-connected corner pixels
     for (int i = tid; i < n_raw; i += 1024) {
         const int y = key_y(keys[i]);
-        if (i == 0 || key_y(keys[i - 1]) != y) row_first[y] = (uint16_t)i;
-        if (i == n_raw - 1 || key_y(keys[i + 1]) != y) row_end[y] = (uint16_t)(i + 1);
+        if (i == 0 || key_y(keys[i - 1]) != y) row_first[y] = i;
+        if (i == n_raw - 1 || key_y(keys[i + 1]) != y) row_end[y] = i + 1;
         uf[i] = (uint32_t)i;
-        nms16[i] = NMS_MAX;
+        nms[i] = (I)MAXF;
     }
     __syncthreads();
     for (int i = tid; i < n_raw; i += 1024) {
         const uint32_t k = keys[i];
         const int y = key_y(k), x = key_x(k);
         const bool left = (i > 0) && (key_pos(keys[i - 1]) + 1 == key_pos(k));
-        uint32_t above = NONE14;
-        if (y > 0 && row_first[y - 1] != 0xFFFF) {
+        uint32_t above = NONE;
+        if (y > 0 && row_first[y - 1] >= 0) {
             int lo = row_first[y - 1], hi = row_end[y - 1];  // [lo,hi)
+            const int end = hi;
             while (lo < hi) {
                 const int m = (lo + hi) >> 1;
                 const int mx = key_x(keys[m]);
                 if (mx < x) lo = m + 1;
                 else hi = m;
             }
-            if (lo < (int)row_end[y - 1] && key_x(keys[lo]) == x) above = (uint32_t)lo;
+            if (lo < end && key_x(keys[lo]) == x) above = (uint32_t)lo;
         }
-        abv16[i] = (uint16_t)(above | (left ? 0x8000u : 0u));
+        abv[i] = (I)(above | (left ? LEFT : 0u));
     }
     __syncthreads();
     for (int i = tid; i < n_raw; i += 1024) {
-        const uint16_t a = abv16[i];
+        const uint32_t a = abv[i];
         int nb[2];
         int nn = 0;
-        if (a & 0x8000u) nb[nn++] = i - 1;
-        if ((a & NONE14) != NONE14) nb[nn++] = (int)(a & NONE14);
+        if (a & LEFT) nb[nn++] = i - 1;
+        if ((a & NONE) != NONE) nb[nn++] = (int)(a & NONE);
         for (int e = 0; e < nn; e++) {
             int u = i, v = nb[e];
             while (true) {
@@ -506,47 +490,47 @@ __global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass) {
         }
     }
     __syncthreads();
-    for (int i = tid; i < n_raw; i += 1024) root16[i] = (uint16_t)uf_find(uf, i);
+    for (int i = tid; i < n_raw; i += 1024) root[i] = (I)uf_find(uf, i);
     __syncthreads();
     for (int i = tid; i < n_raw; i += 1024) uf[i] = (uint32_t)i;  // uf := "last member" per root
     __syncthreads();
     for (int i = tid; i < n_raw; i += 1024) {
-        const int r = root16[i];
+        const int r = (int)root[i];
         if (r != i) atomicMax(&uf[r], (uint32_t)i);
     }
     __syncthreads();
 
-    // ---------------- phase 3: exact replay of AGAST's NMS sweep inside every multi-pixel component
+    // ---------------- exact replay of AGAST's NMS sweep inside every multi-pixel component
     for (int i = tid; i < n_raw; i += 1024) {
-        if (root16[i] != i) continue;
+        if ((int)root[i] != i) continue;
         const int lastm = (int)uf[i];
         if (lastm == i) continue;  // singleton: stays a maximum
         for (int cur = i; cur <= lastm; cur++) {
-            if (root16[cur] != i) continue;
-            const uint16_t a = abv16[cur];
+            if ((int)root[cur] != i) continue;
+            const uint32_t a = abv[cur];
             const int rc = key_r(keys[cur]);
-            if ((a & NONE14) != NONE14) {
-                int w = a & NONE14;
-                while (nms16[w] != NMS_MAX) w = nms16[w];
-                if (rc < key_r(keys[w])) nms16[cur] = (uint16_t)w;
-                else nms16[w] = (uint16_t)cur;
+            if ((a & NONE) != NONE) {
+                int w = (int)(a & NONE);
+                while ((uint32_t)nms[w] != MAXF) w = (int)nms[w];
+                if (rc < key_r(keys[w])) nms[cur] = (I)w;
+                else nms[w] = (I)cur;
             }
-            if (a & 0x8000u) {
+            if (a & LEFT) {
                 int t = cur - 1;
-                const uint16_t above_root = nms16[cur];
-                while (nms16[t] != NMS_MAX) t = nms16[t];
-                if (above_root == NMS_MAX) {
+                const uint32_t above_root = (uint32_t)nms[cur];
+                while ((uint32_t)nms[t] != MAXF) t = (int)nms[t];
+                if (above_root == MAXF) {
                     if (t != cur) {
-                        if (rc < key_r(keys[t])) nms16[cur] = (uint16_t)t;
-                        else nms16[t] = (uint16_t)cur;
+                        if (rc < key_r(keys[t])) nms[cur] = (I)t;
+                        else nms[t] = (I)cur;
                     }
                 } else if (t != (int)above_root) {
                     if (key_r(keys[above_root]) < key_r(keys[t])) {
-                        nms16[above_root] = (uint16_t)t;
-                        nms16[cur] = (uint16_t)t;
+                        nms[above_root] = (I)t;
+                        nms[cur] = (I)t;
                     } else {
-                        nms16[t] = above_root;
-                        nms16[cur] = above_root;
+                        nms[t] = (I)above_root;
+                        nms[cur] = (I)above_root;
                     }
                 }
             }
@@ -554,29 +538,28 @@ __global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass) {
     }
     __syncthreads();
 
-    // ---------------- phase 4: survivors, raster order -> arr (aliases uf)
+    // ---------------- survivors, raster order -> arr (aliases uf)
     uint32_t *arr = uf;
     int n_kp = 0;
     for (int base = 0; base < n_raw; base += 1024) {
         const int i = base + tid;
-        const bool keep = (i < n_raw) && (nms16[i] == NMS_MAX);
+        const bool keep = (i < n_raw) && ((uint32_t)nms[i] == MAXF);
         const uint32_t k = keep ? keys[i] : 0;
         int total;
         const int off = n_kp + block_excl_scan(keep ? 1 : 0, scan, &total);
-        // arr aliases uf; every uf[] read of this round happened before the scan's barriers
-        if (keep) arr[off] = k;
+        if (keep) arr[off] = k;  // off <= i, and uf[] is dead after the replay
         n_kp += total;
     }
     __syncthreads();
 
-    // ---------------- phase 5: ANMS when the cell is too dense (handler.cpp:140-143, 34-83)
+    // ---------------- ANMS when the cell is too dense (handler.cpp:140-143, 34-83)
     const int max_kp = S.prm.max_kp_cell;
-    float *out = S.cell_kp[eye] + (size_t)cell * CELL_OUT_CAP * 3;
+    const float fX0 = (float)g.X0, fY0 = (float)g.Y0;
     int n_out = 0;
     if (n_kp > max_kp) {
-        uint16_t *posL = root16;  // free after NMS
-        uint16_t *posR = abv16;
-        if (wave_id() == 0) wave_introsort_partitions(arr, n_kp, posL, posR, stack);
+        I *posL = root;  // free after NMS
+        I *posR = abv;
+        if (wave_id() == 0) wave_introsort_partitions<I>(arr, n_kp, posL, posR, stack);
         __syncthreads();
         // final insertion sort == stable sort by response (descending): rank every element
         uint32_t *sorted = keys;  // raw keys no longer needed
@@ -630,8 +613,8 @@ __global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass) {
             const int off = n_out + block_excl_scan(keep ? 1 : 0, scan, &total);
             if (keep && off < CELL_OUT_CAP) {
                 const uint32_t k = sorted[i];
-                out[3 * off] = (float)key_x(k) + (float)X0;
-                out[3 * off + 1] = (float)key_y(k) + (float)Y0;
+                out[3 * off] = (float)key_x(k) + fX0;
+                out[3 * off + 1] = (float)key_y(k) + fY0;
                 out[3 * off + 2] = (float)key_r(k);
             }
             n_out += total;
@@ -640,12 +623,67 @@ __global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass) {
         for (int i = tid; i < n_kp; i += 1024) {
             if (i < CELL_OUT_CAP) {
                 const uint32_t k = arr[i];
-                out[3 * i] = (float)key_x(k) + (float)X0;
-                out[3 * i + 1] = (float)key_y(k) + (float)Y0;
+                out[3 * i] = (float)key_x(k) + fX0;
+                out[3 * i + 1] = (float)key_y(k) + fY0;
                 out[3 * i + 2] = (float)key_r(k);
             }
         }
         n_out = n_kp;
+    }
+    return n_out;
+}
+
+__global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass) {
+    Seq &S = seqs[blockIdx.z];
+    const int eye = blockIdx.y, cell = blockIdx.x;
+    const Ctl &ctl = *S.ctl;
+    if (!ctl.active || ctl.ext_corners) return;
+    if (eye == 1 && S.prm.sensor == 2) return;
+    if (cell >= S.prm.n_cells) return;
+    CellGeom g;
+    g.threshold = S.prm.agast_th;
+    if (pass == 1) {
+        if (ctl.n_detected[eye] >= CORNERS_LOW_TH) return;  // handler.cpp:161
+        g.threshold = S.prm.agast_th_low;
+    }
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint32_t *keys = reinterpret_cast<uint32_t *>(smem);
+    uint32_t *uf = keys + RAW_CAP;
+    uint16_t *root16 = reinterpret_cast<uint16_t *>(uf + RAW_CAP);
+    uint16_t *abv16 = root16 + RAW_CAP;
+    uint16_t *nms16 = abv16 + RAW_CAP;
+    int *row_first = reinterpret_cast<int *>(nms16 + RAW_CAP);  // [1024]
+    int *row_end = row_first + 1024;                            // [1024]
+    int *scan = row_end + 1024;                                 // [64]
+    int *stack = scan + 64;                                     // [192]
+    int *misc = stack + 192;                                    // [16]
+
+    const int tid = threadIdx.x;
+    const int cs = S.prm.cell_size;
+    const int cxi = cell % S.prm.cells_x, cyi = cell / S.prm.cells_x;
+    g.X0 = cxi * cs;
+    g.Y0 = cyi * cs;
+    g.cw = min(cs, S.prm.W - g.X0);
+    g.ch = min(cs, S.prm.H - g.Y0);
+    g.score = S.score[eye];
+    g.pp = S.plane_pitch;
+    float *out = S.cell_kp[eye] + (size_t)cell * CELL_OUT_CAP * 3;
+
+    int n_out = 0;
+    if (g.cw > 1024 || g.ch > 1024) {
+        if (tid == 0) atomicOr(&S.ctl->overflow, OVF_CELL_DIM);
+    } else if (g.cw >= 7 && g.ch >= 7) {
+        int n_raw = cell_compact(g, keys, RAW_CAP, scan);
+        if (n_raw <= RAW_CAP) {
+            n_out = cell_nms_anms<uint16_t>(S, g, keys, uf, root16, abv16, nms16, n_raw, row_first, row_end, scan, stack, misc, out);
+        } else {
+            // dense / very large cell: same algorithm on global scratch sized for every pixel of the cell
+            const size_t cap = (size_t)g.cw * g.ch;
+            uint32_t *gk = S.cell_scratch[eye] + S.cell_scratch_off[cell];
+            uint32_t *guf = gk + cap, *groot = guf + cap, *gabv = groot + cap, *gnms = gabv + cap;
+            n_raw = cell_compact(g, gk, (int)cap, scan);
+            n_out = cell_nms_anms<uint32_t>(S, g, gk, guf, groot, gabv, gnms, n_raw, row_first, row_end, scan, stack, misc, out);
+        }
     }
     if (tid == 0) {
         if (n_out > CELL_OUT_CAP) {

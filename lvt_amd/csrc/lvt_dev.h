@@ -118,6 +118,8 @@ struct Seq {
     float *cell_kp[2];          // [CELLS_MAX][CELL_OUT_CAP][3] (x, y, response)
     int *cell_n[2];             // [CELLS_MAX]
     const float *ext_xy[2];     // external corners (n_ext x 2, f32) for track_with_external_corners
+    uint32_t *cell_scratch[2];  // global-memory arrays for cells whose raw corners exceed RAW_CAP (5 words / pixel)
+    size_t cell_scratch_off[CELLS_MAX];
     Feat feat[2];
     // map + staged, ping-pong
     MapSoA map[2], staged[2];

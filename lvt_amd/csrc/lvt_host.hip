@@ -47,6 +47,15 @@ __global__ void k_set_frame(Seq *seqs, const FrameArgs *fa) {
     S.depth_pitch = f.depth_pitch;
 }
 
+// tightly packed host-layout image (stride == cols) -> pitched device image; one byte per thread-iteration
+__global__ __launch_bounds__(256) void k_repitch(const uint8_t *src, uint8_t *dst, int W, int H, int pitch) {
+    const size_t n = (size_t)W * H;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
+        dst[(size_t)y * pitch + x] = src[i];
+    }
+}
+
 struct Context {
     int B = 1;                 // sequences advanced in lock-step by one launch chain
     int sensor = 1;
@@ -61,6 +70,7 @@ struct Context {
     FrameArgs *h_fargs = nullptr;  // pinned
     std::vector<uint8_t *> d_img_l, d_img_r;  // owned staging images for host-buffer entry points
     std::vector<float *> d_depth;
+    uint8_t *d_packed[2] = {nullptr, nullptr};  // contiguous landing buffers for host images
     std::vector<float *> d_ext[2];
     int pitch = 0;
     std::string err;
@@ -267,11 +277,21 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
             S.prm = prm;
             S.ctl = c->d_ctl[s] = c->dalloc<Ctl>(1);
             S.plane_pitch = c->pitch;
+            {
+                size_t off = 0;
+                for (int cc = 0; cc < prm.n_cells; cc++) {
+                    const int cx = cc % prm.cells_x, cy = cc / prm.cells_x;
+                    const int cw = std::min(prm.cell_size, prm.W - cx * prm.cell_size), ch = std::min(prm.cell_size, prm.H - cy * prm.cell_size);
+                    S.cell_scratch_off[cc] = off;
+                    off += (size_t)cw * ch * 5;
+                }
+            }
             for (int e = 0; e < 2; e++) {
                 S.score[e] = c->dalloc<uint8_t>(plane + 64);
                 S.boxsum[e] = c->dalloc<uint16_t>(plane + 64);
                 S.cell_kp[e] = c->dalloc<float>((size_t)CELLS_MAX * CELL_OUT_CAP * 3);
                 S.cell_n[e] = c->dalloc<int>(CELLS_MAX);
+                S.cell_scratch[e] = c->dalloc<uint32_t>((size_t)prm.W * prm.H * 5 + 64);
                 alloc_feat(c, S.feat[e]);
                 float *ext = c->dalloc<float>((size_t)EXT_MAX * 2);
                 c->d_ext[e].push_back(ext);
@@ -308,6 +328,9 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
             c->d_img_l.push_back(c->dalloc<uint8_t>(plane + 64));
             c->d_img_r.push_back(c->dalloc<uint8_t>(plane + 64));
             c->d_depth.push_back(sensor == 2 ? c->dalloc<float>((size_t)prm.W * prm.H) : nullptr);
+        }
+        for (int e = 0; e < 2; e++) c->d_packed[e] = c->dalloc<uint8_t>((size_t)prm.W * prm.H + 64);
+        {
         }
         c->d_seqs = c->dalloc<Seq>(B);
         HIPCHK(c, hipMemcpy(c->d_seqs, c->h_seqs.data(), sizeof(Seq) * B, hipMemcpyHostToDevice));
@@ -496,7 +519,10 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
         return;
     }
     wait_frame(c);
-    HIPCHK(c, hipMemcpy2DAsync(c->d_img_l[0], c->pitch, left, n_cols, n_cols, n_rows, hipMemcpyHostToDevice, c->stream));
+    // one contiguous H2D copy per image, then a device-side re-pitch (a strided 2-D copy of pageable memory is slow)
+    const size_t nbytes = (size_t)n_rows * n_cols;
+    HIPCHK(c, hipMemcpyAsync(c->d_packed[0], left, nbytes, hipMemcpyHostToDevice, c->stream));
+    hipLaunchKernelGGL(k_repitch, dim3(512), dim3(256), 0, c->stream, c->d_packed[0], c->d_img_l[0], n_cols, n_rows, c->pitch);
     c->h_fargs[0].img[0] = c->d_img_l[0];
     c->h_fargs[0].img[1] = c->d_img_r[0];
     c->h_fargs[0].img_pitch = c->pitch;
@@ -507,7 +533,8 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
         c->h_fargs[0].depth = c->d_depth[0];
         c->h_fargs[0].depth_pitch = n_cols;
     } else {
-        HIPCHK(c, hipMemcpy2DAsync(c->d_img_r[0], c->pitch, second, n_cols, n_cols, n_rows, hipMemcpyHostToDevice, c->stream));
+        HIPCHK(c, hipMemcpyAsync(c->d_packed[1], second, nbytes, hipMemcpyHostToDevice, c->stream));
+        hipLaunchKernelGGL(k_repitch, dim3(512), dim3(256), 0, c->stream, c->d_packed[1], c->d_img_r[0], n_cols, n_rows, c->pitch);
     }
     if (ext) {
         if (ncl) HIPCHK(c, hipMemcpyAsync(c->d_ext[0][0], cl, sizeof(float) * 2 * (size_t)ncl, hipMemcpyHostToDevice, c->stream));

@@ -65,6 +65,8 @@ def main():
     ap.add_argument("--seed", type=int, default=0)
     ap.add_argument("--planes", type=int, default=1)
     ap.add_argument("--verbose", type=int, default=1)
+    ap.add_argument("--set", action="append", default=[], help="param override key=value")
+    ap.add_argument("--jump", type=int, default=-1, help="skip 40 frames at this index (forces second pass / LOST)")
     a = ap.parse_args()
 
     world = make_world(a.kind, seed=a.seed, scale=a.scale)
@@ -73,13 +75,17 @@ def main():
     if a.kind != "tum":
         kw["baseline"] = world.baseline
     prm = mk(**kw)
+    for kv in a.set:
+        k, v = kv.split('=')
+        setattr(prm, k, type(getattr(prm, k))(float(v)))
     sensor = 2 if a.kind == "tum" else 1
     orc = O.Oracle(prm, sensor)
     hip = lvt_amd.LvtSystem.create(prm, sensor)
     n_bad = 0
     worst_t = worst_r = 0.0
     t_hip = t_cpu = 0.0
-    for i in range(a.frames):
+    for fi in range(a.frames):
+        i = fi if (a.jump < 0 or fi < a.jump) else fi + 40
         if sensor == 1:
             L, R = world.render_stereo(i)
             t0 = time.time(); Ro, to = orc.track(L, R); t_cpu += time.time() - t0
@@ -91,7 +97,7 @@ def main():
         msgs = []
         if hip.last_error():
             msgs.append("hip error: " + hip.last_error())
-        if a.planes and i == 0:
+        if a.planes and fi == 0:
             for eye, img in ((0, L),) + (((1, R),) if sensor == 1 else ()):
                 sp = hip.plane(eye, 0)[:, :world.W].astype(np.int32)
                 m = cmp(f"score plane eye{eye}", sp, expected_score_plane(img, prm))
@@ -141,7 +147,7 @@ def main():
         if msgs:
             n_bad += 1
         if a.verbose or msgs:
-            print(f"[{tag}] frame {i}: N=({ch['n_left']},{ch['n_right']}) map={ch['map_size']} staged={ch['staged_size']} "
+            print(f"[{tag}] frame {fi}: N=({ch['n_left']},{ch['n_right']}) map={ch['map_size']} staged={ch['staged_size']} "
                   f"matches={ch['n_matches']} rowm={ch['n_row_matches']} tri={ch['n_triangulated']} pnp_it={ch['pnp_iters']} "
                   f"e_t={e_t:.2e} e_R={e_R:.2e} oracle_vs_gt={gt_err:.4f}")
         for m in msgs[:12]:

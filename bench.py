@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""bench.py -- stereo frames/sec of the MI355X-native LVT tracking path on KITTI-shaped input.
+
+Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU).
+A "step" is one pass of the hot path over one stereo pair (one lvt_track call) of a synthetic KITTI-00-shaped
+sequence (1241x376, BASELINE.json configs[1]); independent sequences (seed = rank) shard one per GPU, there is
+no collective on the data path -> "scaling": "weak".  Frames are pre-rendered into HBM before the
+timed region.  Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is achievable
+
+
+def bmatch(M, N):
+    """algorithmic bytes of one masked-Hamming problem: 40(M+N) + N + 16M"""
+    return 40 * (M + N) + N + 16 * M
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--profile-steps", type=int, default=100, help="extra frames run with per-kernel HIP events")
+    ap.add_argument("--cpu-frames", type=int, default=600, help="upper bound of frames timed on the CPU oracle")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--hamming-batch", type=int, default=2048)
+    args = ap.parse_args()
+
+    import torch
+    import lvt_amd
+    from lvt_amd.synth import make_world
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world_size = int(os.environ.get("WORLD_SIZE", "1"))
+    if world_size != args.gpus:
+        if args.gpus > 1 and world_size == 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
+                             "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the tracking path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world_size > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=dev)
+
+    K, Wm, P = args.steps, args.warmup, args.profile_steps
+    world = make_world("kitti", seed=rank)
+    prm = lvt_amd.kitti_params()
+    H, W = world.H, world.W
+    pitch = ((W + 63) // 64) * 64
+    n_frames = Wm + K + P
+    # ---- synthetic frames rendered straight into HBM (pitched, zero padded)
+    frames = torch.zeros((n_frames, 2, H, pitch), dtype=torch.uint8, device=dev)
+    for i in range(n_frames):
+        frames[i, :, :, :W] = world.render_stereo_torch(i, device=dev)
+    torch.cuda.synchronize()
+    base = frames.data_ptr()
+    fstride = 2 * H * pitch
+
+    vo = lvt_amd.LvtSystem.create(prm, lvt_amd.eSensor_STEREO)
+
+    def run(i):
+        p = base + i * fstride
+        return vo.track_device(p, p + H * pitch, H, W, pitch)
+
+    n_lost = 0
+    for i in range(Wm):
+        run(i)
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(Wm, Wm + K):
+        run(i)
+        if vo.get_state() != lvt_amd.eState_TRACKING:
+            n_lost += 1
+    torch.cuda.synchronize()
+    if dist: dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+        lost = torch.tensor([n_lost], dtype=torch.int64, device=dev)
+        dist.all_reduce(lost, op=dist.ReduceOp.SUM)
+        n_lost = int(lost.item())
+    counts = vo.counts()
+    err = vo.last_error()
+
+    result = None
+    if rank == 0:
+        # ---- per-kernel timing pass (HIP events on the launch stream) over the next P frames
+        kernels = []
+        roofline = None
+        if P > 0:
+            vo.profile_enable(True)
+            nl = nr = mp = 0
+            for i in range(Wm + K, Wm + K + P):
+                run(i)
+                c = vo.counts()
+                nl += c["n_left"]; nr += c["n_right"]; mp += c["map_size_at_match"]
+            prof = vo.profile_read()
+            vo.profile_enable(False)
+            nl /= P; nr /= P; mp /= P
+            alg = {  # algorithmic HBM bytes per launch (DESIGN.md "roofline accounting")
+                "k_score": 2.0 * W * H,
+                "k_cells(pass0)": 0.0, "k_gather": 0.0,
+                "k_brief": (nl + nr) * 40.0,
+                "k_candidates(map)": bmatch(mp, nl), "k_resolve(map)": 16.0 * mp + nl,
+                "k_candidates(row)": bmatch(nl, nr), "k_resolve(row)": 16.0 * nl + nr,
+                "k_candidates(staged)": 0.0,
+                "k_pnp": counts["n_matches"] * 32.0 + 56.0,
+            }
+            tot = sum(ms for _, ms, _ in prof)
+            for name, ms, calls in prof:
+                if calls:
+                    kernels.append({"kernel": name, "avg_us": round(1e3 * ms / calls, 3), "share": round(ms / tot, 4)})
+            dom = max(prof, key=lambda x: x[1])
+            dom_us = 1e3 * dom[1] / max(dom[2], 1)
+            ab = alg.get(dom[0], 0.0)
+            ach = ab / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
+            roofline = {"kernel": dom[0], "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None, "avg_us": round(dom_us, 3),
+                        "algorithmic_bytes_per_launch": round(ab, 1),
+                        "note": "latency-bound single-sequence launch; see roofline_hamming_batched for the batched matcher"}
+        # ---- batched Hamming matcher micro-benchmark (the kernel north_star prices against the HBM roof)
+        hb = None
+        try:
+            B, M, N = args.hamming_batch, 1000, 1500
+            g = torch.Generator(device=dev); g.manual_seed(1234)
+            qd = torch.randint(0, 256, (B, M, 32), dtype=torch.uint8, device=dev, generator=g)
+            td = torch.randint(0, 256, (B, N, 32), dtype=torch.uint8, device=dev, generator=g)
+            qxy = torch.rand((B, M, 2), device=dev, generator=g) * torch.tensor([W - 1.0, H - 1.0], device=dev)
+            txy = torch.floor(torch.rand((B, N, 2), device=dev, generator=g) * torch.tensor([W - 1.0, H - 1.0], device=dev))
+            tf = torch.zeros((B, N), dtype=torch.uint8, device=dev)
+            out = torch.zeros((B, M, 4), dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            us = []
+            for _ in range(6):
+                us.append(lvt_amd.hamming_match_batched(qd, qxy.contiguous(), td, txy.contiguous(), tf, 625.0, 0, H, W, out))
+            us = sorted(us[1:])
+            med = us[len(us) // 2]
+            byts = float(B) * bmatch(M, N)
+            ach = byts / (med * 1e-6) / 1e9
+            hb = {"kernel": "k_hamming_batched<radius>", "bound": "hbm", "B": B, "M": M, "N": N, "avg_us": round(med, 2),
+                  "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+        except Exception as e:  # noqa: BLE001
+            hb = {"error": str(e)}
+        # ---- CPU baseline: the oracle (port of the reference path), 2 threads like the reference, same frames
+        cpu = None
+        if not args.no_cpu:
+            from oracle import pyoracle as O
+            nf = min(n_frames, args.cpu_frames)
+            host = frames[:nf, :, :, :W].contiguous().cpu().numpy()
+            orc = O.Oracle(prm, 1, threads=2)
+            tc = time.perf_counter()
+            done = 0
+            for i in range(nf):
+                orc.track(host[i, 0], host[i, 1])
+                done += 1
+                if time.perf_counter() - tc > 30.0:
+                    break
+            tcpu = time.perf_counter() - tc
+            cpu = {"value": round(done / tcpu, 2), "unit": "frames/s", "cores": 2, "kind": "port",
+                   "sample": f"first {done} stereo pairs of the rank-0 sequence, oracle/liblvt_oracle.so with the reference's 2-thread "
+                             f"left/right split; host has {os.cpu_count()} logical cores"}
+        fps = world_size * K / elapsed
+        result = {
+            "metric": "stereo frames/sec (KITTI-shaped 1241x376), per-frame SE3 vs CPU ref",
+            "value": round(fps, 2), "unit": "frames/s", "n_gpus": world_size, "steps": K, "warmup": Wm,
+            "ms_per_step": round(1e3 * elapsed / K, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8/f64", "data": "synthetic",
+            "config": {"workload": "KITTI seq 00-shaped synthetic stereo sequence (1241x376, vo_config.yaml), one sequence per GPU, "
+                                   "one lvt_track per step, frames resident in HBM",
+                       "sequences_per_gpu": 1, "parallelism": f"{world_size} independent sequences, no collective"},
+            "tracking": {"lost_frames": n_lost, "features_left": counts["n_left"], "map_size": counts["map_size"],
+                         "matches": counts["n_matches"], "error": err},
+            "roofline": roofline, "roofline_hamming_batched": hb, "kernels": kernels, "cpu_baseline": cpu,
+        }
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

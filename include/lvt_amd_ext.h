@@ -62,6 +62,11 @@ LVT_API void lvt_amd_set_stream(lvt_handle h, void *hip_stream);
 /* last HIP error string seen by this handle ("" if none); overflow / capacity diagnostics too */
 LVT_API const char *lvt_amd_last_error(lvt_handle h);
 
+/* per-kernel timing with HIP events recorded on the handle's stream around every launch of the frame chain.
+ * enable=1 resets the accumulators.  lvt_amd_profile_read returns 0 past the last slot. */
+LVT_API void lvt_amd_profile_enable(lvt_handle h, int enable);
+LVT_API int lvt_amd_profile_read(lvt_handle h, int slot, char *name, int name_cap, double *total_ms, long *calls);
+
 /* ---- per-frame introspection (same slots as the oracle's LVTO_C_*; see oracle/lvt_oracle.h) ---- */
 enum {
     LVT_AMD_C_N_LEFT = 0, LVT_AMD_C_N_RIGHT, LVT_AMD_C_MAP_SIZE, LVT_AMD_C_STAGED_SIZE, LVT_AMD_C_N_MATCHES,

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "lvt_amd_set_stream", "lvt_amd_last_error", "lvt_amd_get_counts", "lvt_amd_get_features",
     "lvt_amd_get_matches", "lvt_amd_get_row_matches", "lvt_amd_get_map", "lvt_amd_get_staged",
     "lvt_amd_get_pose", "lvt_amd_get_predicted_pose", "lvt_amd_get_plane", "lvt_amd_pnp",
-    "lvt_amd_hamming_match_batched",
+    "lvt_amd_hamming_match_batched", "lvt_amd_profile_enable", "lvt_amd_profile_read",
 ]
 
 N_COUNTS = 32
@@ -82,6 +82,8 @@ def load_library():
     L.lvt_amd_pnp.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]
     L.lvt_amd_hamming_match_batched.restype = C.c_float
     L.lvt_amd_hamming_match_batched.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.lvt_amd_profile_enable.argtypes = [vp, C.c_int]
+    L.lvt_amd_profile_read.argtypes = [vp, C.c_int, C.c_char_p, C.c_int, vp, vp]
     _lib = L
     return L
 
@@ -188,7 +190,7 @@ class LvtSystem:
     def set_stream(self, hip_stream: int):
         load_library().lvt_amd_set_stream(self._h, C.c_void_p(hip_stream))
 
-    # ---- introspection (same shapes as oracle.pyoracle.Oracle) ----
+    # ---- introspection of the last frame (for stage-by-stage parity tests) ----
     def counts(self):
         a = np.zeros(N_COUNTS, dtype=np.int32)
         load_library().lvt_amd_get_counts(self._h, _p(a))
@@ -228,6 +230,21 @@ class LvtSystem:
         q = np.zeros(4); p = np.zeros(3)
         load_library().lvt_amd_get_predicted_pose(self._h, _p(q), _p(p))
         return q, p
+
+    def profile_enable(self, on: bool = True):
+        load_library().lvt_amd_profile_enable(self._h, 1 if on else 0)
+
+    def profile_read(self):
+        """[(kernel name, total ms, launches)] accumulated since profile_enable(True)"""
+        out = []
+        name = C.create_string_buffer(64); ms = C.c_double(0); calls = C.c_long(0)
+        for slot in range(64):
+            if not load_library().lvt_amd_profile_read(self._h, slot, name, 64, C.byref(ms), C.byref(calls)):
+                if slot >= 22:
+                    break
+                continue
+            out.append((name.value.decode(), ms.value, calls.value))
+        return out
 
     def plane(self, eye=0, what=0):
         """what=0: corner score map (u8), what=1: 9x9 box sums (u16); returns (rows, pitch) array"""

@@ -75,6 +75,14 @@ struct Context {
     int pitch = 0;
     std::string err;
     bool pending = false;
+    // optional per-kernel timing with HIP events on the launch stream (lvt_amd_profile_*)
+    bool prof = false;
+    static constexpr int PROF_SLOTS = 24;
+    hipEvent_t ev[PROF_SLOTS][2] = {};
+    bool ev_used[PROF_SLOTS] = {};
+    double prof_ms[PROF_SLOTS] = {};
+    long prof_calls[PROF_SLOTS] = {};
+    long prof_frames = 0;
 
     void set_error(const std::string &s) { err = s; }
 
@@ -92,6 +100,9 @@ struct Context {
     ~Context() {
         if (stream && own_stream) (void)hipStreamSynchronize(stream);
         for (void *p : allocs) (void)hipFree(p);
+        for (auto &e : ev)
+            for (auto &x : e)
+                if (x) (void)hipEventDestroy(x);
         if (h_ctl) (void)hipHostFree(h_ctl);
         if (h_fargs) (void)hipHostFree(h_fargs);
         if (stream && own_stream) (void)hipStreamDestroy(stream);
@@ -345,35 +356,52 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
 }
 
 // ---- the per-frame launch chain -------------------------------------------------------------------
+static const char *kProfNames[Context::PROF_SLOTS] = {
+    "k_set_frame", "k_begin", "k_score", "k_cells(pass0)", "k_cells(retry)", "k_gather", "k_brief", "k_project(map)",
+    "k_candidates(map)", "k_resolve(map)", "k_candidates(map,pass2)", "k_resolve(map,pass2)", "k_bookkeep", "k_pnp", "k_cull",
+    "k_project(staged)", "k_candidates(staged)", "k_staged", "k_candidates(row)", "k_resolve(row)", "k_triangulate", "k_finalize",
+    "", ""};
+
+#define LAUNCH(slot, kern, grid, block, lds, ...)                                  \
+    do {                                                                           \
+        if (c->prof) (void)hipEventRecord(c->ev[slot][0], st);                     \
+        hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);               \
+        if (c->prof) {                                                             \
+            (void)hipEventRecord(c->ev[slot][1], st);                              \
+            c->ev_used[slot] = true;                                               \
+        }                                                                          \
+    } while (0)
+
 static void enqueue_frame(Context *c, int ext_corners, int n_ext_l, int n_ext_r) {
     const int B = c->B;
     hipStream_t st = c->stream;
     const Params &p = c->prm;
     Seq *S = c->d_seqs;
-    hipLaunchKernelGGL(k_set_frame, dim3(B), dim3(64), 0, st, S, c->h_fargs);
-    hipLaunchKernelGGL(k_begin, dim3(B), dim3(64), 0, st, S, ext_corners, n_ext_l, n_ext_r);
-    hipLaunchKernelGGL(k_score, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2 * B), dim3(256), 0, st, S);
+    for (int i = 0; i < Context::PROF_SLOTS; i++) c->ev_used[i] = false;
+    LAUNCH(0, k_set_frame, dim3(B), dim3(64), 0, S, c->h_fargs);
+    LAUNCH(1, k_begin, dim3(B), dim3(64), 0, S, ext_corners, n_ext_l, n_ext_r);
+    LAUNCH(2, k_score, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2 * B), dim3(256), 0, S);
     if (!ext_corners) {
-        hipLaunchKernelGGL(k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, st, S, 0);
-        hipLaunchKernelGGL(k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, st, S, 1);
+        LAUNCH(3, k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, S, 0);
+        LAUNCH(4, k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, S, 1);
     }
-    hipLaunchKernelGGL(k_gather, dim3(1, 2, B), dim3(1024), 0, st, S);
-    hipLaunchKernelGGL(k_brief, dim3(64, 2, B), dim3(256), 0, st, S);
-    hipLaunchKernelGGL(k_project, dim3(32, 1, B), dim3(256), 0, st, S, (int)MODE_MAP);
-    hipLaunchKernelGGL(k_candidates<MODE_MAP>, dim3(256, 1, B), dim3(256), 0, st, S, 0);
-    hipLaunchKernelGGL(k_resolve<MODE_MAP>, dim3(1, 1, B), dim3(256), 0, st, S, 0);
-    hipLaunchKernelGGL(k_candidates<MODE_MAP>, dim3(256, 1, B), dim3(256), 0, st, S, 1);
-    hipLaunchKernelGGL(k_resolve<MODE_MAP>, dim3(1, 1, B), dim3(256), 0, st, S, 1);
-    hipLaunchKernelGGL(k_bookkeep, dim3(1, 1, B), dim3(1024), 0, st, S);
-    hipLaunchKernelGGL(k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), 0, st, S);
-    hipLaunchKernelGGL(k_cull, dim3(1, 1, B), dim3(1024), 0, st, S);
-    hipLaunchKernelGGL(k_project, dim3(32, 1, B), dim3(256), 0, st, S, (int)MODE_STAGED);
-    hipLaunchKernelGGL(k_candidates<MODE_STAGED>, dim3(64, 1, B), dim3(256), 0, st, S, 0);
-    hipLaunchKernelGGL(k_staged, dim3(1, 1, B), dim3(1024), 0, st, S);
-    hipLaunchKernelGGL(k_candidates<MODE_ROW>, dim3(256, 1, B), dim3(256), 0, st, S, 0);
-    hipLaunchKernelGGL(k_resolve<MODE_ROW>, dim3(1, 1, B), dim3(256), 0, st, S, 0);
-    hipLaunchKernelGGL(k_triangulate, dim3(1, 1, B), dim3(1024), 0, st, S);
-    hipLaunchKernelGGL(k_finalize, dim3(B), dim3(64), 0, st, S);
+    LAUNCH(5, k_gather, dim3(1, 2, B), dim3(1024), 0, S);
+    LAUNCH(6, k_brief, dim3(64, 2, B), dim3(256), 0, S);
+    LAUNCH(7, k_project, dim3(32, 1, B), dim3(256), 0, S, (int)MODE_MAP);
+    LAUNCH(8, k_candidates<MODE_MAP>, dim3(256, 1, B), dim3(256), 0, S, 0);
+    LAUNCH(9, k_resolve<MODE_MAP>, dim3(1, 1, B), dim3(256), 0, S, 0);
+    LAUNCH(10, k_candidates<MODE_MAP>, dim3(256, 1, B), dim3(256), 0, S, 1);
+    LAUNCH(11, k_resolve<MODE_MAP>, dim3(1, 1, B), dim3(256), 0, S, 1);
+    LAUNCH(12, k_bookkeep, dim3(1, 1, B), dim3(1024), 0, S);
+    LAUNCH(13, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), 0, S);
+    LAUNCH(14, k_cull, dim3(1, 1, B), dim3(1024), 0, S);
+    LAUNCH(15, k_project, dim3(32, 1, B), dim3(256), 0, S, (int)MODE_STAGED);
+    LAUNCH(16, k_candidates<MODE_STAGED>, dim3(64, 1, B), dim3(256), 0, S, 0);
+    LAUNCH(17, k_staged, dim3(1, 1, B), dim3(1024), 0, S);
+    LAUNCH(18, k_candidates<MODE_ROW>, dim3(256, 1, B), dim3(256), 0, S, 0);
+    LAUNCH(19, k_resolve<MODE_ROW>, dim3(1, 1, B), dim3(256), 0, S, 0);
+    LAUNCH(20, k_triangulate, dim3(1, 1, B), dim3(1024), 0, S);
+    LAUNCH(21, k_finalize, dim3(B), dim3(64), 0, S);
     for (int s = 0; s < B; s++)
         (void)hipMemcpyAsync(&c->h_ctl[s], c->d_ctl[s], sizeof(Ctl), hipMemcpyDeviceToHost, st);
     c->pending = true;
@@ -383,6 +411,17 @@ static void wait_frame(Context *c) {
     if (!c->pending) return;
     HIPCHK(c, hipStreamSynchronize(c->stream));
     c->pending = false;
+    if (c->prof) {
+        for (int i = 0; i < Context::PROF_SLOTS; i++)
+            if (c->ev_used[i]) {
+                float ms = 0;
+                if (hipEventElapsedTime(&ms, c->ev[i][0], c->ev[i][1]) == hipSuccess) {
+                    c->prof_ms[i] += ms;
+                    c->prof_calls[i]++;
+                }
+            }
+        c->prof_frames++;
+    }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) c->set_error(std::string("kernel chain: ") + hipGetErrorString(e));
     for (int s = 0; s < c->B; s++)
@@ -473,6 +512,30 @@ LVT_API void lvt_amd_set_stream(lvt_handle h, void *hip_stream) {
 }
 
 LVT_API const char *lvt_amd_last_error(lvt_handle h) { return static_cast<Context *>(h)->err.c_str(); }
+
+LVT_API void lvt_amd_profile_enable(lvt_handle h, int enable) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        wait_frame(c);
+        if (enable) {
+            for (auto &e : c->ev)
+                for (auto &x : e)
+                    if (!x) HIPCHK(c, hipEventCreate(&x));
+            for (int i = 0; i < Context::PROF_SLOTS; i++) c->prof_ms[i] = 0, c->prof_calls[i] = 0;
+            c->prof_frames = 0;
+        }
+        c->prof = enable != 0;
+    } catch (...) {
+    }
+}
+LVT_API int lvt_amd_profile_read(lvt_handle h, int slot, char *name, int name_cap, double *total_ms, long *calls) {
+    Context *c = static_cast<Context *>(h);
+    if (slot < 0 || slot >= Context::PROF_SLOTS || !kProfNames[slot][0]) return 0;
+    std::snprintf(name, name_cap, "%s", kProfNames[slot]);
+    *total_ms = c->prof_ms[slot];
+    *calls = c->prof_calls[slot];
+    return 1;
+}
 
 LVT_API void lvt_amd_track_device_async(lvt_handle h, const void *d_left, const void *d_right, int n_rows, int n_cols, int pitch_bytes) {
     Context *c = static_cast<Context *>(h);

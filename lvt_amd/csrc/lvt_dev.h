@@ -83,6 +83,7 @@ struct Ctl {
     Pose predicted, optimized;
     int counts[N_COUNTS];
     int overflow;
+    long long dbg[32];  // phase cycle stamps of cell 0 / eye 0 (bring-up profiling)
     // result record copied to the host
     double out_R[9], out_t[3];
     int out_status;

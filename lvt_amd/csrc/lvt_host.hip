@@ -294,7 +294,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
                     const int cx = cc % prm.cells_x, cy = cc / prm.cells_x;
                     const int cw = std::min(prm.cell_size, prm.W - cx * prm.cell_size), ch = std::min(prm.cell_size, prm.H - cy * prm.cell_size);
                     S.cell_scratch_off[cc] = off;
-                    off += (size_t)cw * ch * 5;
+                    off += (size_t)cw * ch * 6;
                 }
             }
             for (int e = 0; e < 2; e++) {
@@ -302,7 +302,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
                 S.boxsum[e] = c->dalloc<uint16_t>(plane + 64);
                 S.cell_kp[e] = c->dalloc<float>((size_t)CELLS_MAX * CELL_OUT_CAP * 3);
                 S.cell_n[e] = c->dalloc<int>(CELLS_MAX);
-                S.cell_scratch[e] = c->dalloc<uint32_t>((size_t)prm.W * prm.H * 5 + 64);
+                S.cell_scratch[e] = c->dalloc<uint32_t>((size_t)prm.W * prm.H * 6 + 64);
                 alloc_feat(c, S.feat[e]);
                 float *ext = c->dalloc<float>((size_t)EXT_MAX * 2);
                 c->d_ext[e].push_back(ext);
@@ -761,6 +761,14 @@ LVT_API void lvt_amd_get_predicted_pose(lvt_handle h, double q[4], double p[3]) 
         wait_frame(c);
         for (int k = 0; k < 4; k++) q[k] = c->h_ctl[0].predicted.q[k];
         for (int k = 0; k < 3; k++) p[k] = c->h_ctl[0].predicted.p[k];
+    } catch (...) {
+    }
+}
+LVT_API void lvt_amd_get_debug(lvt_handle h, long long out[32]) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        wait_frame(c);
+        for (int i = 0; i < 32; i++) out[i] = c->h_ctl[0].dbg[i];
     } catch (...) {
     }
 }

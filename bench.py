@@ -35,6 +35,7 @@ def main():
     ap.add_argument("--profile-steps", type=int, default=100, help="extra frames run with per-kernel HIP events")
     ap.add_argument("--cpu-frames", type=int, default=600, help="upper bound of frames timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--depth", type=int, default=4, help="poses outstanding in the async pipeline (1 = synchronous)")
     ap.add_argument("--hamming-batch", type=int, default=2048)
     args = ap.parse_args()
 
@@ -79,19 +80,33 @@ def main():
         p = base + i * fstride
         return vo.track_device(p, p + H * pitch, H, W, pitch)
 
+    def run_async(i):
+        p = base + i * fstride
+        vo.track_device_async(p, p + H * pitch, H, W, pitch)
+
+    # frames are enqueued asynchronously with at most DEPTH poses outstanding: the feature stage of frame t+1
+    # overlaps the tracking chain of frame t on the device, the host never idles the GPU between frames
+    DEPTH = args.depth
     n_lost = 0
     for i in range(Wm):
         run(i)
     torch.cuda.synchronize()
     if dist: dist.barrier()
     t0 = time.perf_counter()
+    inflight = 0
+    poses = []
     for i in range(Wm, Wm + K):
-        run(i)
-        if vo.get_state() != lvt_amd.eState_TRACKING:
-            n_lost += 1
+        run_async(i)
+        inflight += 1
+        if inflight >= DEPTH:
+            poses.append(vo.wait()); inflight -= 1
+    while inflight:
+        poses.append(vo.wait()); inflight -= 1
     torch.cuda.synchronize()
     if dist: dist.barrier()
     elapsed = time.perf_counter() - t0
+    assert len(poses) == K
+    n_lost = 0 if vo.get_state() == lvt_amd.eState_TRACKING else 1   # LOST is sticky: the final state tells
     if dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -187,7 +202,7 @@ def main():
             "vs_baseline": None, "dtype": "u8/f64", "data": "synthetic",
             "config": {"workload": "KITTI seq 00-shaped synthetic stereo sequence (1241x376, vo_config.yaml), one sequence per GPU, "
                                    "one lvt_track per step, frames resident in HBM",
-                       "sequences_per_gpu": 1, "parallelism": f"{world_size} independent sequences, no collective"},
+                       "sequences_per_gpu": 1, "frames_in_flight": DEPTH, "parallelism": f"{world_size} independent sequences, no collective"},
             "tracking": {"lost_frames": n_lost, "features_left": counts["n_left"], "map_size": counts["map_size"],
                          "matches": counts["n_matches"], "error": err},
             "roofline": roofline, "roofline_hamming_batched": hb, "kernels": kernels, "cpu_baseline": cpu,

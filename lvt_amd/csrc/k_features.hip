@@ -17,7 +17,7 @@ __constant__ signed char c_brief[256][4] = {
 // =================================================================================================
 // k_begin
 // =================================================================================================
-__global__ void k_begin(Seq *seqs, int ext_corners, int n_ext_l, int n_ext_r) {
+__global__ void k_begin(Seq *seqs, int par) {
     Seq &S = seqs[blockIdx.x];
     if (threadIdx.x != 0) return;
     Ctl &c = *S.ctl;
@@ -26,11 +26,6 @@ __global__ void k_begin(Seq *seqs, int ext_corners, int n_ext_l, int n_ext_r) {
     c.frame_number++;
     c.active = (c.state != 3);
     c.first_frame = (c.state == 1);
-    c.ext_corners = ext_corners;
-    c.n_ext[0] = n_ext_l;
-    c.n_ext[1] = n_ext_r;
-    c.n_detected[0] = c.n_detected[1] = 0;
-    c.retry[0] = c.retry[1] = 0;
     c.do_pass2 = 0;
     c.n_pass1 = c.n_pass2 = 0;
     c.n_matches = 0;
@@ -38,7 +33,9 @@ __global__ void k_begin(Seq *seqs, int ext_corners, int n_ext_l, int n_ext_r) {
     c.need_tri = 0;
     c.dont_stage = 0;
     c.n_pairs = 0;
-    c.overflow = 0;
+    c.overflow = S.fb[par].fc->overflow;
+    c.counts[C_RETRY_LEFT] = S.fb[par].fc->retry[0];
+    c.counts[C_RETRY_RIGHT] = S.fb[par].fc->retry[1];
     if (!c.active) {  // LOST: return the last pose forever (lvt_system.cpp:161-166)
         pose_to_Rt(c.last_pose, c.out_R, c.out_t);
         c.out_status = 3;
@@ -85,16 +82,16 @@ __device__ __forceinline__ int oast9_score(int p, const int r[16]) {
     return best - 1;
 }
 
-__global__ __launch_bounds__(256) void k_score(Seq *seqs) {
+__global__ __launch_bounds__(256) void k_score(Seq *seqs, int par) {
     const int seq = blockIdx.z >> 1, eye = blockIdx.z & 1;
     Seq &S = seqs[seq];
-    if (!S.ctl->active) return;
+    FrameBuf &FB = S.fb[par];
     if (eye == 1 && S.prm.sensor == 2) return;
     const int W = S.prm.W, H = S.prm.H;
     const int x0 = blockIdx.x * TS_W, y0 = blockIdx.y * TS_H;
     if (x0 >= W || y0 >= H) return;
-    const uint8_t *img = S.img[eye];
-    const int pitch = S.img_pitch;
+    const uint8_t *img = FB.img[eye];
+    const int pitch = FB.img_pitch;
 
     __shared__ __attribute__((aligned(16))) uint8_t tile[TILE_H][TILE_W];
     __shared__ uint16_t hs[TILE_H][TS_W];
@@ -182,7 +179,7 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs) {
     __syncthreads();  // hs complete
     if (gy < H) {
         const int pp = S.plane_pitch;
-        *reinterpret_cast<uint32_t *>(S.score[eye] + (size_t)gy * pp + x0 + 4 * tx) = packed;
+        *reinterpret_cast<uint32_t *>(FB.score[eye] + (size_t)gy * pp + x0 + 4 * tx) = packed;
         uint16_t b[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -194,7 +191,7 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs) {
         uint2 o;
         o.x = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
         o.y = (uint32_t)b[2] | ((uint32_t)b[3] << 16);
-        *reinterpret_cast<uint2 *>(S.boxsum[eye] + (size_t)gy * pp + x0 + 4 * tx) = o;
+        *reinterpret_cast<uint2 *>(FB.boxsum[eye] + (size_t)gy * pp + x0 + 4 * tx) = o;
     }
 }
 
@@ -861,11 +858,12 @@ __device__ __forceinline__ int cell_nms_anms(const Seq &S, const CellGeom &g, ui
     return n_out;
 }
 
-__global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass) {
+__global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass, int par) {
     Seq &S = seqs[blockIdx.z];
     const int eye = blockIdx.y, cell = blockIdx.x;
-    const Ctl &ctl = *S.ctl;
-    if (!ctl.active || ctl.ext_corners) return;
+    FrameBuf &FB = S.fb[par];
+    FeatCtl &ctl = *FB.fc;
+    if (ctl.ext_corners) return;
     if (eye == 1 && S.prm.sensor == 2) return;
     if (cell >= S.prm.n_cells) return;
     CellGeom g;
@@ -894,15 +892,15 @@ __global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass) {
     g.Y0 = cyi * cs;
     g.cw = min(cs, S.prm.W - g.X0);
     g.ch = min(cs, S.prm.H - g.Y0);
-    g.score = S.score[eye];
+    g.score = FB.score[eye];
     g.pp = S.plane_pitch;
-    float *out = S.cell_kp[eye] + (size_t)cell * CELL_OUT_CAP * 3;
+    float *out = FB.cell_kp[eye] + (size_t)cell * CELL_OUT_CAP * 3;
 
     long long *dbg = (cell == 0 && eye == 0 && pass == 0) ? S.ctl->dbg : nullptr;
     if (dbg && tid == 0) dbg[0] = clock64();
     int n_out = 0;
     if (g.cw > 1024 || g.ch > 1024) {
-        if (tid == 0) atomicOr(&S.ctl->overflow, OVF_CELL_DIM);
+        if (tid == 0) atomicOr(&ctl.overflow, OVF_CELL_DIM);
     } else if (g.cw >= 7 && g.ch >= 7) {
         int n_raw = cell_compact(g, keys, RAW_CAP, scan);
         if (dbg && tid == 0) dbg[1] = clock64();
@@ -920,15 +918,12 @@ __global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass) {
     if (dbg && tid == 0) dbg[11] = clock64();
     if (tid == 0) {
         if (n_out > CELL_OUT_CAP) {
-            atomicOr(&S.ctl->overflow, OVF_CELL_OUT);
+            atomicOr(&ctl.overflow, OVF_CELL_OUT);
             n_out = CELL_OUT_CAP;
         }
-        S.cell_n[eye][cell] = n_out;
-        if (pass == 0) atomicAdd(&S.ctl->n_detected[eye], n_out);
-        else if (cell == 0) {
-            S.ctl->retry[eye] = 1;
-            S.ctl->counts[eye ? C_RETRY_RIGHT : C_RETRY_LEFT] = 1;
-        }
+        FB.cell_n[eye][cell] = n_out;
+        if (pass == 0) atomicAdd(&ctl.n_detected[eye], n_out);
+        else if (cell == 0) ctl.retry[eye] = 1;
     }
 }
 
@@ -942,20 +937,17 @@ __device__ __forceinline__ bool brief_border_keep(float x, float y, int rows, in
     return ix >= B && ix < cols - B && iy >= B && iy < rows - B;
 }
 
-__global__ __launch_bounds__(1024) void k_gather(Seq *seqs) {
+__global__ __launch_bounds__(1024) void k_gather(Seq *seqs, int par) {
     Seq &S = seqs[blockIdx.z];
     const int eye = blockIdx.y;
-    Ctl &ctl = *S.ctl;
-    if (!ctl.active) return;
+    FrameBuf &FB = S.fb[par];
+    FeatCtl &ctl = *FB.fc;
     __shared__ int cell_off[CELLS_MAX + 1];
     __shared__ int scan[32];
     const int tid = threadIdx.x;
-    Feat &F = S.feat[eye];
+    Feat &F = FB.feat[eye];
     if (eye == 1 && S.prm.sensor == 2) {
-        if (tid == 0) {
-            *F.n = 0;
-            ctl.counts[C_N_RIGHT] = 0;
-        }
+        if (tid == 0) *F.n = 0;
         return;
     }
     const int nc = ctl.ext_corners ? 1 : S.prm.n_cells;
@@ -963,7 +955,7 @@ __global__ __launch_bounds__(1024) void k_gather(Seq *seqs) {
         int acc = 0;
         for (int c = 0; c < nc; c++) {
             cell_off[c] = acc;
-            acc += ctl.ext_corners ? ctl.n_ext[eye] : S.cell_n[eye][c];
+            acc += ctl.ext_corners ? ctl.n_ext[eye] : FB.cell_n[eye][c];
         }
         cell_off[nc] = acc;
     }
@@ -978,12 +970,12 @@ __global__ __launch_bounds__(1024) void k_gather(Seq *seqs) {
         float x = 0, y = 0, r = 0, ox = 0, oy = 0, dep = 0;
         if (g < total_in) {
             if (ctl.ext_corners) {
-                x = S.ext_xy[eye][2 * g];
-                y = S.ext_xy[eye][2 * g + 1];
+                x = FB.ext_xy[eye][2 * g];
+                y = FB.ext_xy[eye][2 * g + 1];
             } else {
                 int c = 0;
                 while (g >= cell_off[c + 1]) c++;
-                const float *kp = S.cell_kp[eye] + ((size_t)c * CELL_OUT_CAP + (g - cell_off[c])) * 3;
+                const float *kp = FB.cell_kp[eye] + ((size_t)c * CELL_OUT_CAP + (g - cell_off[c])) * 3;
                 x = kp[0];
                 y = kp[1];
                 r = kp[2];
@@ -992,7 +984,7 @@ __global__ __launch_bounds__(1024) void k_gather(Seq *seqs) {
             oy = y;
             keep = brief_border_keep(x, y, H, W);
             if (keep && rgbd) {  // handler.cpp:255-265 (depth at the distorted pixel), :268-294
-                dep = S.depth_img[(size_t)((int)y) * S.depth_pitch + (int)x];
+                dep = FB.depth_img[(size_t)((int)y) * FB.depth_pitch + (int)x];
                 keep = (dep >= S.prm.near_plane && dep <= S.prm.far_plane);
                 if (keep && S.prm.undistort) {
                     undistort_point(S.prm, x, y, x, y);
@@ -1022,28 +1014,27 @@ __global__ __launch_bounds__(1024) void k_gather(Seq *seqs) {
             n_out = NF_MAX;
         }
         *F.n = n_out;
-        ctl.counts[eye ? C_N_RIGHT : C_N_LEFT] = n_out;
     }
 }
 
 // =================================================================================================
 // k_brief : one wavefront per key point, lane l evaluates tests 4l..4l+3
 // =================================================================================================
-__device__ __forceinline__ int box_at(const Seq &S, int eye, int iy, int ix) {
+__device__ __forceinline__ int box_at(const Seq &S, const FrameBuf &FB, int eye, int iy, int ix) {
     const int W = S.prm.W, H = S.prm.H;
-    if (ix >= 0 && ix < W && iy >= 0 && iy < H) return S.boxsum[eye][(size_t)iy * S.plane_pitch + ix];
+    if (ix >= 0 && ix < W && iy >= 0 && iy < H) return FB.boxsum[eye][(size_t)iy * S.plane_pitch + ix];
     // centre outside the image (fractional external corners at the border only): clipped window
     int s = 0;
     for (int y = max(iy - 4, 0); y <= min(iy + 4, H - 1); y++)
-        for (int x = max(ix - 4, 0); x <= min(ix + 4, W - 1); x++) s += S.img[eye][(size_t)y * S.img_pitch + x];
+        for (int x = max(ix - 4, 0); x <= min(ix + 4, W - 1); x++) s += FB.img[eye][(size_t)y * FB.img_pitch + x];
     return s;
 }
 
-__global__ __launch_bounds__(256) void k_brief(Seq *seqs) {
+__global__ __launch_bounds__(256) void k_brief(Seq *seqs, int par) {
     Seq &S = seqs[blockIdx.z];
     const int eye = blockIdx.y;
-    if (!S.ctl->active) return;
-    Feat &F = S.feat[eye];
+    FrameBuf &FB = S.fb[par];
+    Feat &F = FB.feat[eye];
     const int n = *F.n;
     const int lane = lane_id();
     const int wpb = blockDim.x >> 6;
@@ -1053,8 +1044,8 @@ __global__ __launch_bounds__(256) void k_brief(Seq *seqs) {
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const signed char *t = c_brief[4 * lane + k];
-            const int a = box_at(S, eye, cy + t[0], cx + t[1]);
-            const int b = box_at(S, eye, cy + t[2], cx + t[3]);
+            const int a = box_at(S, FB, eye, cy + t[0], cx + t[1]);
+            const int b = box_at(S, FB, eye, cy + t[2], cx + t[3]);
             nib |= (a < b ? 1 : 0) << (3 - k);
         }
         // byte j = nibble(lane 2j) << 4 | nibble(lane 2j+1); gather 8 bytes into one u64 per 16 lanes

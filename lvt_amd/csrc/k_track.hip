@@ -23,7 +23,7 @@ enum : int { MODE_MAP = 0, MODE_STAGED = 1, MODE_ROW = 2 };
 // =================================================================================================
 // k_project
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_project(Seq *seqs, int mode) {
+__global__ __launch_bounds__(256) void k_project(Seq *seqs, int mode, int par) {
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     if (!ctl.active || ctl.first_frame) return;
@@ -104,7 +104,7 @@ __device__ __forceinline__ bool cand_pred(const Query &q, const Feat &F, int j) 
 // k_candidates : one wavefront per query; output sorted ascending by (distance << 16 | index)
 // =================================================================================================
 template <int MODE>
-__global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2) {
+__global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2, int par) {
     Seq &S = seqs[blockIdx.z];
     const Ctl &ctl = *S.ctl;
     if (!ctl.active) return;
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2) {
     __shared__ uint32_t lbuf[4][KC];
     const int lane = lane_id(), wv = wave_id();
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-    const Feat &T = (MODE == MODE_ROW) ? S.feat[1] : S.feat[0];
+    const Feat &T = (MODE == MODE_ROW) ? S.fb[par].feat[1] : S.fb[par].feat[0];
     const int N = *T.n;
     int M;
     const uint64_t *qdesc;
@@ -135,8 +135,8 @@ __global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2) {
         cand = S.scand;
         ncand = S.sncand;
     } else {
-        M = *S.feat[0].n;
-        qdesc = S.feat[0].desc;
+        M = *S.fb[par].feat[0].n;
+        qdesc = S.fb[par].feat[0].desc;
         cand = S.rcand;
         ncand = S.rncand;
     }
@@ -157,11 +157,11 @@ __global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2) {
             }
             make_query_track(S.prm, S.sproj[2 * i], S.sproj[2 * i + 1], radius, q);
         } else {
-            if (S.feat[0].flag[i]) {  // already matched by tracking (handler.cpp:307)
+            if (S.fb[par].feat[0].flag[i]) {  // already matched by tracking (handler.cpp:307)
                 if (lane == 0) ncand[i] = 0;
                 continue;
             }
-            make_query_row(S.prm, S.feat[0].x[i], S.feat[0].y[i], q);
+            make_query_row(S.prm, S.fb[par].feat[0].x[i], S.fb[par].feat[0].y[i], q);
         }
 #pragma unroll
         for (int k = 0; k < 4; k++) q.d[k] = qdesc[(size_t)i * 4 + k];
@@ -268,120 +268,147 @@ __device__ __forceinline__ void wave_first_two(uint32_t c0, uint32_t c1, bool v0
 }
 
 // =================================================================================================
-// k_resolve : the greedy, order-dependent part.
+// The greedy, order-dependent accept/mark scans (find_matches, row_match, update_staged_map_points) as a
+// BLOCK-WIDE FIXPOINT ITERATION.
 //
-// One 256-thread workgroup per sequence.  Queries are taken 64 at a time: wavefronts 1..3 stage the sorted
-// candidate lists of the NEXT 64 queries into LDS while wavefront 0 decides the current 64.  Deciding is
-// lane-parallel and speculative: every lane walks its own list for the first two unmatched candidates, then
-// lanes whose two picks were touched by an EARLIER lane's acceptance are rolled back and retried in the next
-// round -- the result is identical to the strictly sequential scan (lvt_local_map.cpp:146-199,
-// lvt_image_features_handler.cpp:302-323) because a query's outcome depends on earlier queries only through
-// features they marked, and a mark matters only if it hits one of the first two unmatched candidates.
+// Sequentially, query q takes the best two still-unmarked candidates of its list, applies the ratio / threshold
+// test and marks the winner; later queries see that mark.  Here all queries of a "super-chunk" decide at once:
+// in iteration t a candidate counts as unavailable when it is marked, or when a query with a SMALLER index
+// accepted it in iteration t-1 (tab[(t-1)&1][f] = earliest such query, stamped with t-1 so the tables are never
+// cleared).  Query 0 is final after one iteration, query q after at most q+1.  When an iteration changes no
+// decision, every decision satisfies D_q = f(marks, {D_j : j < q}) -- the defining recurrence of the sequential
+// scan (lvt_local_map.cpp:146-199, lvt_image_features_handler.cpp:302-323, lvt_local_map.cpp:355-391), whose
+// solution is unique.  Observed depth: 2-4 iterations.  Candidate lists (already sorted by (distance, index) by
+// k_candidates) are packed into LDS once per super-chunk.
 // =================================================================================================
-constexpr int RCHUNK = 64;
-constexpr int LSTRIDE = KC + 1;  // +1 word: lanes walk different rows, keep them on different banks
+constexpr int RES_THREADS = 1024;
+constexpr int QCAP = 2 * RES_THREADS;  // queries per super-chunk (two per thread, contiguous)
+constexpr int LCAP = 24576;            // packed candidate entries per super-chunk (96 KB of LDS)
 
-// decide one query from its LDS-resident sorted list (used by the exact slow path); wave-cooperative
+struct ResolveLds {
+    uint8_t *flag;     // [NF_MAX] matched marks
+    uint32_t *tab0;    // [NF_MAX] claims of odd iterations
+    uint32_t *tab1;    // [NF_MAX] claims of even iterations
+    uint32_t *lists;   // [LCAP]
+    int *scan;         // [32]
+    int *misc;         // [8]
+};
+
+// exact slow path for ONE query whose list overflowed KC; executed by wavefront 0 (all lanes)
 template <int MODE>
-__device__ __forceinline__ int decide_query(const Seq &S, const Feat &T, int N, const uint32_t *list, int n, const uint8_t *flag,
-                                            const uint64_t *qdesc, int i, float qx, float qy, int radius, float ratio, float desc_th) {
-    const int lane = lane_id();
+__device__ __forceinline__ int decide_query_slow(const Seq &S, const Feat &T, int N, const uint8_t *flag, const uint64_t *qdesc, int i,
+                                                 float qx, float qy, int radius, float ratio, float desc_th) {
+    Query q;
+    if (MODE == MODE_ROW) make_query_row(S.prm, qx, qy, q);
+    else make_query_track(S.prm, qx, qy, radius, q);
+#pragma unroll
+    for (int k = 0; k < 4; k++) q.d[k] = qdesc[(size_t)i * 4 + k];
     uint32_t k1, k2;
     int cnt;
-    if (n <= KC) {
-        const uint32_t c0 = (lane < n) ? list[lane] : 0u;
-        const uint32_t c1 = (lane + 64 < n) ? list[lane + 64] : 0u;
-        const bool v0 = (lane < n) && !flag[c0 & 0xFFFFu];
-        const bool v1 = (lane + 64 < n) && !flag[c1 & 0xFFFFu];
-        wave_first_two(c0, c1, v0, v1, k1, k2, cnt);
-    } else {
-        Query q;
-        if (MODE == MODE_ROW) make_query_row(S.prm, qx, qy, q);
-        else make_query_track(S.prm, qx, qy, radius, q);
-#pragma unroll
-        for (int k = 0; k < 4; k++) q.d[k] = qdesc[(size_t)i * 4 + k];
-        wave_top2_slow<MODE>(q, T, N, flag, k1, k2, cnt);
-    }
+    wave_top2_slow<MODE>(q, T, N, flag, k1, k2, cnt);
     return accept_match(cnt, k1, k2, ratio, desc_th) ? (int)(k1 & 0xFFFFu) : -1;
 }
 
-// stage the candidate lists of queries [base, base+chunk) into LDS; executed by waves [w0, w0+nw).
-// All global loads of a batch are issued before any is consumed: one coalesced load brings the 64 list lengths,
-// then every wave fetches the lists of 8 of its queries at a time (lists are short: one load per query).
-__device__ __forceinline__ void stage_lists(const uint32_t *cand, const int *ncand, int base, int chunk, uint32_t *lists, int *ns, int w0,
-                                            int nw) {
-    const int lane = lane_id();
-    const int w = wave_id() - w0;
-    if (w < 0 || w >= nw) return;
-    const int my_n = (lane < chunk) ? ncand[base + lane] : 0;
-    if (w == 0 && lane < chunk) ns[lane] = my_n;
-    constexpr int BATCH = 8;
-    for (int q0 = w; q0 < chunk; q0 += BATCH * nw) {
-        uint32_t v[BATCH];
-        int nn[BATCH];
+// One super-chunk starting at query b0.  nfn(q) = candidate count of query q (0 = nothing to decide).
+// Returns the number of queries consumed (>= 1), or -1 when query b0 itself overflows KC (caller: slow path).
+// acc[u] = accepted feature (or -1) of local query 2*tid+u; marks in L.flag are updated.
+template <class NFn>
+__device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint32_t *cand, ResolveLds &L, uint32_t &iter, float ratio,
+                                             float desc_th, int acc[2]) {
+    const int tid = threadIdx.x;
+    int n[2], off[2];
+    const int lq0 = 2 * tid;
+    if (tid == 0) L.misc[0] = QCAP;
+    __syncthreads();
 #pragma unroll
-        for (int u = 0; u < BATCH; u++) {
-            const int q = q0 + u * nw;
-            int n = (q < chunk) ? __shfl(my_n, q & 63, 64) : 0;
-            if (q >= chunk || n > KC) n = 0;  // overflowing lists take the exact slow path, nothing to stage
-            nn[u] = n;
-            v[u] = (lane < n) ? cand[(size_t)(base + q) * KC + lane] : 0u;
-        }
+    for (int u = 0; u < 2; u++) {
+        const int q = b0 + lq0 + u;
+        n[u] = (q < M) ? nfn(q) : 0;
+        if (n[u] > KC) atomicMin(&L.misc[0], lq0 + u);
+    }
+    __syncthreads();
+    int limit = min(min(QCAP, M - b0), L.misc[0]);
+    if (limit == 0) return -1;
 #pragma unroll
-        for (int u = 0; u < BATCH; u++) {
-            const int q = q0 + u * nw;
-            if (lane < nn[u]) lists[q * LSTRIDE + lane] = v[u];
-            if (nn[u] > 64)  // rare: second half of a long list
-                for (int e = 64 + lane; e < nn[u]; e += 64) lists[q * LSTRIDE + e] = cand[(size_t)(base + q) * KC + e];
+    for (int u = 0; u < 2; u++)
+        if (lq0 + u >= limit) n[u] = 0;
+    int total;
+    const int ex = block_excl_scan(n[0] + n[1], L.scan, &total);
+    off[0] = ex;
+    off[1] = ex + n[0];
+    if (total > LCAP) {  // keep the longest prefix of queries whose lists fit
+        int fit = ((lq0 < limit && off[0] + n[0] <= LCAP) ? 1 : 0) + ((lq0 + 1 < limit && off[1] + n[1] <= LCAP) ? 1 : 0);
+        int nfit;
+        block_excl_scan(fit, L.scan, &nfit);
+        limit = nfit;
+#pragma unroll
+        for (int u = 0; u < 2; u++)
+            if (lq0 + u >= limit) n[u] = 0;
+    }
+    // pack the lists into LDS (independent loads, 8 in flight per query)
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+        const uint32_t *src = cand + (size_t)(b0 + lq0 + u) * KC;
+        for (int e0 = 0; e0 < n[u]; e0 += 8) {
+            uint32_t v[8];
+#pragma unroll
+            for (int k = 0; k < 8; k++) v[k] = (e0 + k < n[u]) ? src[e0 + k] : 0u;
+#pragma unroll
+            for (int k = 0; k < 8; k++)
+                if (e0 + k < n[u]) L.lists[off[u] + e0 + k] = v[k];
         }
     }
-}
-
-// lane-parallel decision of one chunk (<= 64 queries, all with n <= KC) by fixpoint iteration.  Executed by ONE
-// full wavefront.  In iteration t every lane decides as the sequential scan would IF the tentative acceptances of
-// the earlier lanes from iteration t-1 were final: a candidate is unavailable when it is marked, or when an
-// earlier lane accepted it in iteration t-1 (tab[(t-1)&1][f] holds that lane, stamped with the iteration so the
-// tables never need clearing).  Lane 0 is final after one iteration, lane l after at most l+1; when no lane
-// changes its decision the state satisfies D_l = f(marks, {D_j : j < l}) for every l, i.e. it IS the sequential
-// result (lvt_local_map.cpp:146-199, lvt_image_features_handler.cpp:302-323).  Typical depth: 2-3 iterations.
-__device__ __forceinline__ int resolve_chunk_spec(const uint32_t *lists, const int *ns, int chunk, uint8_t *flag, uint32_t *tab0,
-                                                  uint32_t *tab1, uint32_t &iter, float ratio, float desc_th, int &my_idx) {
-    const int lane = lane_id();
-    const int n = (lane < chunk) ? ns[lane] : 0;
-    const uint32_t *list = lists + lane * LSTRIDE;
-    int acc = -1, prev = -2;
+    __syncthreads();
+    int prev[2] = {-2, -2};
+    acc[0] = acc[1] = -1;
     while (true) {
         iter++;
-        const uint32_t *rd = (iter & 1u) ? tab0 : tab1;   // written during iteration iter-1
-        uint32_t *wr = (iter & 1u) ? tab1 : tab0;
-        uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
-        int cnt = 0;
-        for (int e = 0; e < n; e++) {
-            const uint32_t c = list[e];
-            const uint32_t f = c & 0xFFFFu;
-            if (flag[f]) continue;
-            const uint32_t v = rd[f];
-            if ((v >> 8) == iter - 1u && (int)(63u - (v & 255u)) < lane) continue;  // taken by an earlier lane
-            if (cnt == 0) k1 = c;
-            else k2 = c;
-            if (++cnt == 2) break;
+        const uint32_t *rd = (iter & 1u) ? L.tab0 : L.tab1;  // written during iteration iter-1
+        uint32_t *wr = (iter & 1u) ? L.tab1 : L.tab0;
+        bool changed = false;
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            if (n[u] == 0) continue;
+            const int lq = lq0 + u;
+            const uint32_t *list = L.lists + off[u];
+            uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+            int cnt = 0;
+            for (int e = 0; e < n[u]; e++) {
+                const uint32_t c = list[e];
+                const uint32_t f = c & 0xFFFFu;
+                if (L.flag[f]) continue;
+                const uint32_t v = rd[f];
+                if ((v >> 11) == iter - 1u && (int)(2047u - (v & 2047u)) < lq) continue;  // taken by an earlier query
+                if (cnt == 0) k1 = c;
+                else k2 = c;
+                if (++cnt == 2) break;
+            }
+            const bool ok = accept_match(cnt, k1, k2, ratio, desc_th);
+            acc[u] = ok ? (int)(k1 & 0xFFFFu) : -1;
+            if (ok) atomicMax(&wr[acc[u]], (iter << 11) | (uint32_t)(2047 - lq));
+            changed = changed || (acc[u] != prev[u]);
+            prev[u] = acc[u];
         }
-        const bool ok = accept_match(cnt, k1, k2, ratio, desc_th);
-        acc = ok ? (int)(k1 & 0xFFFFu) : -1;
-        if (ok) atomicMax(&wr[acc], (iter << 8) | (uint32_t)(63 - lane));
-        const bool changed = (acc != prev);
-        prev = acc;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-        if (__ballot(changed) == 0ull) break;
+        if (!__syncthreads_or(changed ? 1 : 0)) break;
     }
-    if (acc >= 0) flag[acc] = 1;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    my_idx = acc;
-    return __popcll(__ballot(acc >= 0));
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+        if (acc[u] >= 0) L.flag[acc[u]] = 1;
+    __syncthreads();
+    return limit;
 }
 
+#define RESOLVE_LDS_DECL                                    \
+    __shared__ uint8_t r_flag[NF_MAX];                      \
+    __shared__ uint32_t r_tab[2 * NF_MAX];                  \
+    __shared__ uint32_t r_lists[LCAP];                      \
+    __shared__ int r_scan[32];                              \
+    __shared__ int r_misc[8];                               \
+    ResolveLds L;                                           \
+    L.flag = r_flag, L.tab0 = r_tab, L.tab1 = r_tab + NF_MAX, L.lists = r_lists, L.scan = r_scan, L.misc = r_misc;
+
 template <int MODE>
-__global__ __launch_bounds__(256) void k_resolve(Seq *seqs, int pass2) {
+__global__ __launch_bounds__(RES_THREADS) void k_resolve(Seq *seqs, int pass2, int par) {
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     if (!ctl.active) return;
@@ -390,19 +417,13 @@ __global__ __launch_bounds__(256) void k_resolve(Seq *seqs, int pass2) {
         if (pass2 && !ctl.do_pass2) return;
     }
     if (MODE == MODE_ROW && (!ctl.need_tri || ctl.lost_now || S.prm.sensor != 1)) return;
-
-    __shared__ uint8_t flag[NF_MAX];
-    __shared__ uint32_t claim[2 * NF_MAX];
-    __shared__ uint32_t lists[2][RCHUNK * LSTRIDE];
-    __shared__ int ns[2][RCHUNK];
-    const int tid = threadIdx.x, lane = lane_id();
-    uint32_t round = 0;
-    for (int j = tid; j < 2 * NF_MAX; j += blockDim.x) claim[j] = 0;
-    const Feat &T = (MODE == MODE_ROW) ? S.feat[1] : S.feat[0];
+    RESOLVE_LDS_DECL
+    const int tid = threadIdx.x;
+    const Feat &T = (MODE == MODE_ROW) ? S.fb[par].feat[1] : S.fb[par].feat[0];
     const int N = *T.n;
     // find_matches pass 2 starts from cleared marks (lvt_local_map.cpp:176)
-    for (int j = tid; j < N; j += blockDim.x) flag[j] = (MODE == MODE_MAP && pass2) ? 0 : T.flag[j];
-
+    for (int j = tid; j < N; j += RES_THREADS) L.flag[j] = (MODE == MODE_MAP && pass2) ? 0 : T.flag[j];
+    for (int j = tid; j < 2 * NF_MAX; j += RES_THREADS) r_tab[j] = 0;
     int M;
     const uint64_t *qdesc;
     const uint32_t *cand;
@@ -413,79 +434,71 @@ __global__ __launch_bounds__(256) void k_resolve(Seq *seqs, int pass2) {
         cand = S.cand;
         ncand = S.ncand;
     } else {
-        M = *S.feat[0].n;
-        qdesc = S.feat[0].desc;
+        M = *S.fb[par].feat[0].n;
+        qdesc = S.fb[par].feat[0].desc;
         cand = S.rcand;
         ncand = S.rncand;
     }
     const float ratio = (MODE == MODE_ROW) ? S.prm.tri_ratio : S.prm.track_ratio;
     const float desc_th = S.prm.desc_th;
     const int radius = S.prm.tracking_radius * ((MODE == MODE_MAP && pass2) ? 2 : 1);
-    int accepted = 0;  // meaningful in wavefront 0
-
-    // prologue: chunk 0 staged by all four wavefronts
-    if (M > 0) stage_lists(cand, ncand, 0, min(RCHUNK, M), lists[0], ns[0], 0, 4);
+    uint32_t iter = 0;
+    int accepted = 0;  // block-uniform
     __syncthreads();
-    int buf = 0;
-    for (int base = 0; base < M; base += RCHUNK, buf ^= 1) {
-        const int chunk = min(RCHUNK, M - base);
-        if (wave_id() != 0) {  // waves 1..3 prefetch the next chunk while wave 0 decides this one
-            if (base + RCHUNK < M) stage_lists(cand, ncand, base + RCHUNK, min(RCHUNK, M - base - RCHUNK), lists[buf ^ 1], ns[buf ^ 1], 1, 3);
-        } else {
-            const int my_n = (lane < chunk) ? ns[buf][lane] : 0;
-            const bool any_ovf = __ballot(my_n > KC) != 0ull;
-            int my_idx = -1;
-            if (!any_ovf) {
-                const int acc = resolve_chunk_spec(lists[buf], ns[buf], chunk, flag, claim, claim + NF_MAX, round, ratio, desc_th, my_idx);
-                const int i = base + lane;
-                if (MODE == MODE_MAP) {
-                    if (lane < chunk && my_n > 0) S.match[i] = my_idx;
-                } else {
-                    const uint64_t am = __ballot(my_idx >= 0);
-                    if (my_idx >= 0) {
-                        const int slot = accepted + __popcll(am & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
-                        S.pair_l[slot] = i;
-                        S.pair_r[slot] = my_idx;
-                        S.feat[0].flag[i] = 1;  // handler.cpp:319
-                    }
-                }
-                accepted += acc;
-            } else {  // a list overflowed KC: exact sequential path for this chunk
-                for (int qi = 0; qi < chunk; qi++) {
-                    const int i = base + qi;
-                    const int n = ns[buf][qi];
-                    if (n == 0) continue;
-                    float qx, qy;
-                    if (MODE == MODE_MAP) {
-                        qx = S.proj[2 * i];
-                        qy = S.proj[2 * i + 1];
-                    } else {
-                        qx = S.feat[0].x[i];
-                        qy = S.feat[0].y[i];
-                    }
-                    const int idx = decide_query<MODE>(S, T, N, lists[buf] + qi * LSTRIDE, n, flag, qdesc, i, qx, qy, radius, ratio, desc_th);
-                    if (MODE == MODE_MAP && lane == 0) S.match[i] = idx;
+    for (int b0 = 0; b0 < M;) {
+        int acc[2];
+        const int used = resolve_super(b0, M, [&](int q) { return ncand[q]; }, cand, L, iter, ratio, desc_th, acc);
+        if (used < 0) {  // query b0 overflowed KC: exact scan of all train features by wavefront 0
+            if (wave_id() == 0) {
+                float qx, qy;
+                if (MODE == MODE_MAP) qx = S.proj[2 * b0], qy = S.proj[2 * b0 + 1];
+                else qx = S.fb[par].feat[0].x[b0], qy = S.fb[par].feat[0].y[b0];
+                const int idx = decide_query_slow<MODE>(S, T, N, L.flag, qdesc, b0, qx, qy, radius, ratio, desc_th);
+                if (lane_id() == 0) {
+                    if (MODE == MODE_MAP) S.match[b0] = idx;
                     if (idx >= 0) {
-                        if (lane == 0) {
-                            flag[idx] = 1;
-                            if (MODE == MODE_ROW) {
-                                S.pair_l[accepted] = i;
-                                S.pair_r[accepted] = idx;
-                                S.feat[0].flag[i] = 1;
-                            }
+                        L.flag[idx] = 1;
+                        if (MODE == MODE_ROW) {
+                            S.pair_l[accepted] = b0;
+                            S.pair_r[accepted] = idx;
+                            S.fb[par].feat[0].flag[b0] = 1;
                         }
-                        accepted++;
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
                     }
+                    L.misc[1] = (idx >= 0) ? 1 : 0;
                 }
             }
+            __syncthreads();
+            accepted += L.misc[1];
+            __syncthreads();
+            b0 += 1;
+            continue;
         }
+        // results, in query order
+        const int lq0 = 2 * tid;
+        const int a0 = (lq0 < used && acc[0] >= 0) ? 1 : 0, a1 = (lq0 + 1 < used && acc[1] >= 0) ? 1 : 0;
+        int tot;
+        const int ex = block_excl_scan(a0 + a1, L.scan, &tot);
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int lq = lq0 + u, q = b0 + lq;
+            if (lq >= used) continue;
+            if (MODE == MODE_MAP) {
+                if (ncand[q] > 0) S.match[q] = acc[u];  // invisible / candidate-less points keep -2 / -1 (k_project)
+            } else if (acc[u] >= 0) {
+                const int slot = accepted + ex + (u ? a0 : 0);
+                S.pair_l[slot] = q;
+                S.pair_r[slot] = acc[u];
+                S.fb[par].feat[0].flag[q] = 1;  // handler.cpp:319
+            }
+        }
+        accepted += tot;
+        b0 += used;
         __syncthreads();
     }
     __syncthreads();
     if (MODE == MODE_MAP) {
         // a failed pass 1 (< 50) is discarded: pass 2 rebuilds the marks from scratch
-        for (int j = tid; j < N; j += blockDim.x) S.feat[0].flag[j] = flag[j];
+        for (int j = tid; j < N; j += RES_THREADS) S.fb[par].feat[0].flag[j] = L.flag[j];
         if (tid == 0) {
             if (!pass2) {
                 ctl.n_pass1 = accepted;
@@ -495,7 +508,7 @@ __global__ __launch_bounds__(256) void k_resolve(Seq *seqs, int pass2) {
                 ctl.n_pass2 = accepted;
         }
     } else {
-        for (int j = tid; j < N; j += blockDim.x) S.feat[1].flag[j] = flag[j];
+        for (int j = tid; j < N; j += RES_THREADS) S.fb[par].feat[1].flag[j] = L.flag[j];
         if (tid == 0) {
             ctl.n_pairs = accepted;
             ctl.counts[C_N_ROW_MATCHES] = accepted;
@@ -506,7 +519,7 @@ __global__ __launch_bounds__(256) void k_resolve(Seq *seqs, int pass2) {
 // =================================================================================================
 // k_bookkeep : lvt_local_map.cpp:201-224 + lvt_system.cpp:266-274
 // =================================================================================================
-__global__ __launch_bounds__(1024) void k_bookkeep(Seq *seqs) {
+__global__ __launch_bounds__(1024) void k_bookkeep(Seq *seqs, int par) {
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     if (!ctl.active || ctl.first_frame) return;
@@ -514,7 +527,7 @@ __global__ __launch_bounds__(1024) void k_bookkeep(Seq *seqs) {
     const int tid = threadIdx.x;
     const int M = *S.map_n;
     MapSoA &P = S.map[*S.map_cur];
-    const Feat &F = S.feat[0];
+    const Feat &F = S.fb[par].feat[0];
     int n_out = 0;
     for (int base = 0; base < M; base += 1024) {
         const int i = base + tid;
@@ -626,12 +639,22 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red) {
 #pragma unroll
         for (int k = 0; k < NV; k++) part[k * PNP_THREADS + tid] = v[k];
         __syncthreads();
-        for (int k = w; k < NV; k += 4) {
+        constexpr int PER = (NV + 3) / 4;
+        double sacc[PER];
+#pragma unroll
+        for (int u = 0; u < PER; u++) {  // branch-free so the PER butterfly chains interleave
+            const int k = min(w + 4 * u, NV - 1);
             const double *p = part + k * PNP_THREADS;
-            double s = (p[l] + p[l + 64]) + (p[l + 128] + p[l + 192]);
-            s = wave_sum(s);
-            if (l == 0) red[k] = s;
+            sacc[u] = (p[l] + p[l + 64]) + (p[l + 128] + p[l + 192]);
         }
+#pragma unroll
+        for (int d = 32; d >= 1; d >>= 1) {
+#pragma unroll
+            for (int u = 0; u < PER; u++) sacc[u] += __shfl_xor(sacc[u], d, 64);
+        }
+#pragma unroll
+        for (int u = 0; u < PER; u++)
+            if (l == 0 && w + 4 * u < NV) red[w + 4 * u] = sacc[u];
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < NV; k++) v[k] = red[k];
@@ -871,7 +894,7 @@ __device__ void pnp_run(const Params &prm, const Pose &prior, const double *X, c
     __syncthreads();
 }
 
-__global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs) {
+__global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs, int par) {
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     if (!ctl.active || ctl.first_frame || ctl.lost_now) return;
@@ -925,7 +948,7 @@ __device__ __forceinline__ void copy_point(const MapSoA &src, int i, MapSoA &dst
 // =================================================================================================
 // k_cull : clean_untracked_points (lvt_local_map.cpp:393-413), stable compaction into the other buffer
 // =================================================================================================
-__global__ __launch_bounds__(1024) void k_cull(Seq *seqs) {
+__global__ __launch_bounds__(1024) void k_cull(Seq *seqs, int par) {
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     if (!ctl.active || ctl.first_frame || ctl.lost_now) return;
@@ -940,7 +963,7 @@ __global__ __launch_bounds__(1024) void k_cull(Seq *seqs) {
         bool keep = false;
         if (i < M) {
             keep = A.counter[i] < th;
-            if (!keep && A.match_idx[i] >= 0) S.feat[0].flag[A.match_idx[i]] = 0;  // :402-405
+            if (!keep && A.match_idx[i] >= 0) S.fb[par].feat[0].flag[A.match_idx[i]] = 0;  // :402-405
         }
         int total;
         const int off = n_out + block_excl_scan(keep ? 1 : 0, scan, &total);
@@ -956,118 +979,111 @@ __global__ __launch_bounds__(1024) void k_cull(Seq *seqs) {
 }
 
 // =================================================================================================
-// k_staged : update_staged_map_points (lvt_local_map.cpp:355-391) then the triangulation policy
+// k_staged : update_staged_map_points (lvt_local_map.cpp:355-391) then the triangulation policy.
+// Matching = the same block-wide fixpoint; the promotion rule "counter == staged_threshold || map_size < 250"
+// depends on the RUNNING map size, which has the closed form  map_n0 + #(matched staged points before i)  as long
+// as it is below 250 (every matched point is promoted while the map is small), so promotions and their
+// destinations come from two prefix sums.
 // =================================================================================================
-__global__ __launch_bounds__(1024) void k_staged(Seq *seqs) {
+__global__ __launch_bounds__(RES_THREADS) void k_staged(Seq *seqs, int par) {
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     if (!ctl.active || ctl.lost_now) return;
-    __shared__ uint8_t flag[NF_MAX];
-    __shared__ uint32_t claim[2 * NF_MAX];
-    __shared__ uint32_t lists[RCHUNK * LSTRIDE];
-    __shared__ int ns[RCHUNK], cnt0[RCHUNK], res[RCHUNK], dst[RCHUNK];
-    __shared__ int8_t visq[RCHUNK];
-    __shared__ int scan[32];
-    __shared__ int sh_map_n;
-    const int tid = threadIdx.x, lane = lane_id();
+    RESOLVE_LDS_DECL
+    const int tid = threadIdx.x;
     if (!ctl.first_frame && S.prm.staged_th > 0) {
-        const Feat &T = S.feat[0];
+        const Feat &T = S.fb[par].feat[0];
         const int N = *T.n;
         const int scur = *S.staged_cur, SM = *S.staged_n;
         MapSoA &A = S.staged[scur], &B = S.staged[scur ^ 1];
         MapSoA &MP = S.map[*S.map_cur];
-        for (int j = tid; j < N; j += 1024) flag[j] = T.flag[j];
-        for (int j = tid; j < 2 * NF_MAX; j += 1024) claim[j] = 0;
-        uint32_t round = 0;
-        if (tid == 0) sh_map_n = *S.map_n;
-        __syncthreads();
-        int erased = 0, promoted = 0;  // wavefront 0's copies are the live ones
+        for (int j = tid; j < N; j += RES_THREADS) L.flag[j] = T.flag[j];
+        for (int j = tid; j < 2 * NF_MAX; j += RES_THREADS) r_tab[j] = 0;
+        const int map_n0 = *S.map_n;
+        uint32_t iter = 0;
+        int matched_before = 0, promoted_before = 0, erased = 0;  // block-uniform running totals
         bool map_ovf = false;
-        for (int base = 0; base < SM; base += RCHUNK) {
-            const int chunk = min(RCHUNK, SM - base);
-            __syncthreads();
-            stage_lists(S.scand, S.sncand, base, chunk, lists, ns, 0, 16);
-            for (int q = tid; q < chunk; q += 1024) {
-                cnt0[q] = A.counter[base + q];
-                visq[q] = S.svis[base + q];
-                dst[q] = -1;
-            }
-            __syncthreads();
-            if (wave_id() == 0) {
-                // 1. which staged points find their feature (order-dependent through the marks)
-                const int my_n = (lane < chunk && visq[lane]) ? ns[lane] : 0;
-                int my_idx = -1;
-                if (__ballot(my_n > KC) == 0ull) {
-                    if (lane < chunk && !visq[lane]) ns[lane] = 0;
-                    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                    resolve_chunk_spec(lists, ns, chunk, flag, claim, claim + NF_MAX, round, S.prm.track_ratio, S.prm.desc_th, my_idx);
-                    if (lane < chunk) res[lane] = my_idx;
-                } else {
-                    for (int qi = 0; qi < chunk; qi++) {
-                        int idx = -1;
-                        if (visq[qi] && ns[qi] > 0)
-                            idx = decide_query<MODE_STAGED>(S, T, N, lists + qi * LSTRIDE, ns[qi], flag, A.desc, base + qi, S.sproj[2 * (base + qi)],
-                                                            S.sproj[2 * (base + qi) + 1], S.prm.tracking_radius, S.prm.track_ratio, S.prm.desc_th);
-                        if (lane == 0) {
-                            res[qi] = idx;
-                            if (idx >= 0) flag[idx] = 1;
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        __syncthreads();
+        for (int b0 = 0; b0 < SM;) {
+            int acc[2];
+            int used = resolve_super(b0, SM, [&](int q) { return S.svis[q] ? S.sncand[q] : 0; }, S.scand, L, iter, S.prm.track_ratio,
+                                     S.prm.desc_th, acc);
+            if (used < 0) {
+                if (wave_id() == 0) {
+                    const int idx = decide_query_slow<MODE_STAGED>(S, T, N, L.flag, A.desc, b0, S.sproj[2 * b0], S.sproj[2 * b0 + 1],
+                                                                   S.prm.tracking_radius, S.prm.track_ratio, S.prm.desc_th);
+                    if (lane_id() == 0) {
+                        if (idx >= 0) L.flag[idx] = 1;
+                        L.misc[1] = idx;
                     }
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-                // 2. counters / promotion: depends on the running map size, cheap and strictly in order
-                if (lane == 0) {
-                    int map_n = sh_map_n;
-                    for (int qi = 0; qi < chunk; qi++) {
-                        bool del = false;
-                        if (res[qi] < 0) {
-                            del = true;
-                            erased++;
-                        } else {
-                            const int c = cnt0[qi] + 1;
-                            cnt0[qi] = c;
-                            if (c == S.prm.staged_th || map_n < N_MAP_POINTS) {  // promote (:377-382)
-                                if (map_n < MAP_MAX) dst[qi] = map_n++;
-                                else map_ovf = true;
-                                del = true;
-                                promoted++;
-                            }
-                        }
-                        S.sdel[base + qi] = del ? 1 : 0;
-                    }
-                    sh_map_n = map_n;
+                __syncthreads();
+                acc[0] = (tid == 0) ? L.misc[1] : -1;
+                acc[1] = -1;
+                used = 1;
+                __syncthreads();
+            }
+            const int lq0 = 2 * tid;
+            int m[2], c[2], pr[2];
+#pragma unroll
+            for (int u = 0; u < 2; u++) m[u] = (lq0 + u < used && acc[u] >= 0) ? 1 : 0;
+            int mtot;
+            const int mex = block_excl_scan(m[0] + m[1], L.scan, &mtot);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                pr[u] = 0;
+                c[u] = 0;
+                if (m[u]) {
+                    const int i = b0 + lq0 + u;
+                    c[u] = A.counter[i] + 1;
+                    const int mb = matched_before + mex + (u ? m[0] : 0);
+                    pr[u] = (c[u] == S.prm.staged_th || map_n0 + mb < N_MAP_POINTS) ? 1 : 0;  // :377
                 }
             }
+            int ptot;
+            const int pex = block_excl_scan(pr[0] + pr[1], L.scan, &ptot);
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int lq = lq0 + u, i = b0 + lq;
+                if (lq >= used) continue;
+                bool del = true;
+                if (m[u]) {
+                    A.counter[i] = c[u];
+                    del = false;
+                    if (pr[u]) {
+                        const int dst = map_n0 + promoted_before + pex + (u ? pr[0] : 0);
+                        if (dst < MAP_MAX) {
+                            copy_point(A, i, MP, dst);
+                            MP.counter[dst] = c[u];
+                            MP.match_idx[dst] = -1;
+                        } else
+                            map_ovf = true;
+                        del = true;
+                    }
+                }
+                S.sdel[i] = del ? 1 : 0;
+            }
+            matched_before += mtot;
+            promoted_before += ptot;
+            erased += used - mtot;
+            b0 += used;
             __syncthreads();
-            // 3. apply: counters and promoted copies, in parallel
-            for (int q = tid; q < chunk; q += 1024) {
-                if (res[q] >= 0) {
-                    A.counter[base + q] = cnt0[q];
-                    if (dst[q] >= 0) {
-                        copy_point(A, base + q, MP, dst[q]);
-                        MP.counter[dst[q]] = cnt0[q];
-                        MP.match_idx[dst[q]] = -1;
-                    }
-                }
-            }
         }
         __syncthreads();
+        if (map_ovf) atomicOr(&ctl.overflow, OVF_MAP);
         if (tid == 0) {
-            *S.map_n = sh_map_n;
+            *S.map_n = min(map_n0 + promoted_before, MAP_MAX);
             ctl.counts[C_N_STAGED_ERASED] = erased;
-            ctl.counts[C_N_STAGED_PROMOTED] = promoted;
-            if (map_ovf) atomicOr(&ctl.overflow, OVF_MAP);
+            ctl.counts[C_N_STAGED_PROMOTED] = promoted_before;
         }
-        __syncthreads();
-        for (int j = tid; j < N; j += 1024) S.feat[0].flag[j] = flag[j];
+        for (int j = tid; j < N; j += RES_THREADS) S.fb[par].feat[0].flag[j] = L.flag[j];
         // stable compaction of the staged set
         int n_out = 0;
-        for (int base = 0; base < SM; base += 1024) {
+        for (int base = 0; base < SM; base += RES_THREADS) {
             const int i = base + tid;
             const bool keep = (i < SM) && !S.sdel[i];
             int total;
-            const int off = n_out + block_excl_scan(keep ? 1 : 0, scan, &total);
+            const int off = n_out + block_excl_scan(keep ? 1 : 0, L.scan, &total);
             if (keep) copy_point(A, i, B, off);
             n_out += total;
         }
@@ -1167,7 +1183,7 @@ __device__ bool triangulate_pair(const Params &p, const double *cml, const doubl
     return true;
 }
 
-__global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs) {
+__global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par) {
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     if (!ctl.active || ctl.lost_now || !ctl.need_tri) return;
@@ -1188,7 +1204,7 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs) {
         q_to_R(cam.q, R);
     }
     __syncthreads();
-    const Feat &FL = S.feat[0], &FR = S.feat[1];
+    const Feat &FL = S.fb[par].feat[0], &FR = S.fb[par].feat[1];
     const bool rgbd = (S.prm.sensor == 2);
     const int n_in = rgbd ? *FL.n : ctl.n_pairs;
     // destination: lvt_local_map.cpp:345 (decided once, before anything is appended)
@@ -1249,7 +1265,7 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs) {
 // =================================================================================================
 // k_finalize
 // =================================================================================================
-__global__ void k_finalize(Seq *seqs) {
+__global__ void k_finalize(Seq *seqs, int par) {
     Seq &S = seqs[blockIdx.x];
     if (threadIdx.x != 0) return;
     Ctl &ctl = *S.ctl;
@@ -1262,16 +1278,19 @@ __global__ void k_finalize(Seq *seqs) {
         pose_to_Rt(id, ctl.out_R, ctl.out_t);
         ctl.out_status = 2;
     }
+    ctl.counts[C_N_LEFT] = *S.fb[par].feat[0].n;
+    ctl.counts[C_N_RIGHT] = *S.fb[par].feat[1].n;
     ctl.counts[C_MAP_SIZE] = *S.map_n;
     ctl.counts[C_STAGED_SIZE] = *S.staged_n;
+    ctl.overflow |= S.fb[par].fc->overflow;
     ctl.counts[C_OVERFLOW] = ctl.overflow;
 }
 
 // explicit instantiations used by the host
-template __global__ void k_candidates<MODE_MAP>(Seq *, int);
-template __global__ void k_candidates<MODE_STAGED>(Seq *, int);
-template __global__ void k_candidates<MODE_ROW>(Seq *, int);
-template __global__ void k_resolve<MODE_MAP>(Seq *, int);
-template __global__ void k_resolve<MODE_ROW>(Seq *, int);
+template __global__ void k_candidates<MODE_MAP>(Seq *, int, int);
+template __global__ void k_candidates<MODE_STAGED>(Seq *, int, int);
+template __global__ void k_candidates<MODE_ROW>(Seq *, int, int);
+template __global__ void k_resolve<MODE_MAP>(Seq *, int, int);
+template __global__ void k_resolve<MODE_ROW>(Seq *, int, int);
 
 }  // namespace lvt

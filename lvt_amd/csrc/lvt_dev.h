@@ -69,10 +69,6 @@ struct Ctl {
     // per-frame control, written by k_begin / later kernels
     int active;         // 0: LOST at frame start -> every kernel exits
     int first_frame;    // state was NOT_INITIALIZED at frame start
-    int ext_corners;    // track_with_external_corners frame
-    int n_detected[2];  // corners before BRIEF (for the <200 retry)
-    int retry[2];
-    int n_ext[2];
     int do_pass2;       // find_matches second pass (lvt_local_map.cpp:173)
     int n_pass1, n_pass2;
     int n_matches;      // accepted 2D-3D matches
@@ -87,6 +83,14 @@ struct Ctl {
     // result record copied to the host
     double out_R[9], out_t[3];
     int out_status;
+};
+
+struct FeatCtl {        // per-frame state of the FEATURE stage (own stream, double buffered)
+    int ext_corners;    // track_with_external_corners frame
+    int n_ext[2];
+    int n_detected[2];  // corners before BRIEF (for the <200 retry, handler.cpp:161)
+    int retry[2];
+    int overflow;
 };
 
 struct Feat {  // one image's lvt_image_features_struct (lvt_image_features_struct.h:62-80), SoA
@@ -105,23 +109,28 @@ struct MapSoA {            // lvt_local_map.h:64-72 as SoA; two copies for stabl
     int *counter, *age, *match_idx;
 };
 
-struct Seq {
-    Params prm;
-    Ctl *ctl;
-    // images (this frame)
+// everything the feature stage of ONE frame produces / consumes; two copies (frame parity) so that the
+// feature extraction of frame t+1 overlaps the tracking chain of frame t on a second HIP stream
+struct FrameBuf {
     const uint8_t *img[2];
     const float *depth_img;     // RGB-D
     int img_pitch, depth_pitch; // bytes / elements
     uint8_t *score[2];          // OAST-9/16 score map (0 = below the lowered threshold / dead band)
     uint16_t *boxsum[2];        // 9x9 box sums
-    int plane_pitch;            // elements, multiple of 64
-    // per-cell detector output
     float *cell_kp[2];          // [CELLS_MAX][CELL_OUT_CAP][3] (x, y, response)
     int *cell_n[2];             // [CELLS_MAX]
     const float *ext_xy[2];     // external corners (n_ext x 2, f32) for track_with_external_corners
-    uint32_t *cell_scratch[2];  // global-memory arrays for cells whose raw corners exceed RAW_CAP (5 words / pixel)
-    size_t cell_scratch_off[CELLS_MAX];
     Feat feat[2];
+    FeatCtl *fc;
+};
+
+struct Seq {
+    Params prm;
+    Ctl *ctl;
+    FrameBuf fb[2];
+    int plane_pitch;            // elements, multiple of 64
+    uint32_t *cell_scratch[2];  // global-memory arrays for cells whose raw corners exceed RAW_CAP (6 words / pixel)
+    size_t cell_scratch_off[CELLS_MAX];
     // map + staged, ping-pong
     MapSoA map[2], staged[2];
     int *map_cur, *map_n, *staged_cur, *staged_n;   // device scalars

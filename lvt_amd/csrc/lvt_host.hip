@@ -3,6 +3,12 @@
 // points (include/lvt_amd_ext.h).  The host mirrors lvt_system::create/track/reset
 // (reference lvt/src/lvt_system.cpp) but performs NO tracking arithmetic: the whole state machine
 // runs on the device, the host enqueues the chain and reads back one result record per frame.
+//
+// Two HIP streams form a software pipeline: the FEATURE stage of frame t+1 (k_score .. k_brief, wide kernels)
+// runs on stream_f while the TRACKING chain of frame t (matching, the serial Levenberg-Marquardt pose
+// refinement, map maintenance -- latency-bound, a few workgroups) runs on stream_t.  Feature buffers are
+// double buffered by frame parity; events order the two stages.  Results land in a ring of pinned records,
+// so frames can be enqueued asynchronously (lvt_amd_track_device_async / lvt_amd_wait).
 #define LVT_EXPORT_FUNCTIONS
 #include "../../include/lvt_amd_ext.h"
 
@@ -29,25 +35,36 @@ namespace lvt {
     } while (0)
 
 constexpr int EXT_MAX = 16384;
+constexpr int RING = 8;  // frames that may be in flight / un-collected
 
-struct FrameArgs {  // per-frame, per-sequence inputs (pinned host memory read by k_set_frame)
+struct FrameArgs {  // per-frame, per-sequence inputs (pinned host memory read by k_feat_begin)
     const uint8_t *img[2];
     const float *depth;
     int img_pitch, depth_pitch;
+    int ext_corners, n_ext[2];
 };
 
-__global__ void k_set_frame(Seq *seqs, const FrameArgs *fa) {
+// first kernel of the feature stage: publish this frame's inputs, clear the stage's control block
+__global__ void k_feat_begin(Seq *seqs, const FrameArgs *fa, int par) {
     if (threadIdx.x != 0) return;
     Seq &S = seqs[blockIdx.x];
     const FrameArgs &f = fa[blockIdx.x];
-    S.img[0] = f.img[0];
-    S.img[1] = f.img[1];
-    S.depth_img = f.depth;
-    S.img_pitch = f.img_pitch;
-    S.depth_pitch = f.depth_pitch;
+    FrameBuf &FB = S.fb[par];
+    FB.img[0] = f.img[0];
+    FB.img[1] = f.img[1];
+    FB.depth_img = f.depth;
+    FB.img_pitch = f.img_pitch;
+    FB.depth_pitch = f.depth_pitch;
+    FeatCtl &c = *FB.fc;
+    c.ext_corners = f.ext_corners;
+    c.n_ext[0] = f.n_ext[0];
+    c.n_ext[1] = f.n_ext[1];
+    c.n_detected[0] = c.n_detected[1] = 0;
+    c.retry[0] = c.retry[1] = 0;
+    c.overflow = 0;
 }
 
-// tightly packed host-layout image (stride == cols) -> pitched device image; one byte per thread-iteration
+// tightly packed host-layout image (stride == cols) -> pitched device image
 __global__ __launch_bounds__(256) void k_repitch(const uint8_t *src, uint8_t *dst, int W, int H, int pitch) {
     const size_t n = (size_t)W * H;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -60,29 +77,31 @@ struct Context {
     int B = 1;                 // sequences advanced in lock-step by one launch chain
     int sensor = 1;
     Params prm{};
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;    // tracking chain
+    hipStream_t stream_f = nullptr;  // feature stage
     bool own_stream = false;
     std::vector<void *> allocs;
     Seq *d_seqs = nullptr;
     std::vector<Seq> h_seqs;   // host mirror (device pointers inside)
     std::vector<Ctl *> d_ctl;
-    Ctl *h_ctl = nullptr;      // pinned, B records
-    FrameArgs *h_fargs = nullptr;  // pinned
-    std::vector<uint8_t *> d_img_l, d_img_r;  // owned staging images for host-buffer entry points
-    std::vector<float *> d_depth;
-    uint8_t *d_packed[2] = {nullptr, nullptr};  // contiguous landing buffers for host images
-    std::vector<float *> d_ext[2];
+    Ctl *h_ctl = nullptr;          // pinned, RING x B records
+    FrameArgs *h_fargs = nullptr;  // pinned, RING x B
+    hipEvent_t ev_feat[2] = {}, ev_track[2] = {}, ev_done[RING] = {};
+    // owned staging for the host-buffer entry points, per frame parity
+    uint8_t *d_packed[2][2] = {}, *d_img[2][2] = {};
+    float *d_depth[2] = {};
+    float *d_ext[2][2] = {};
     int pitch = 0;
+    long enq = 0, done = 0;    // frames enqueued / collected
+    int last_slot = 0, last_par = 0;
     std::string err;
-    bool pending = false;
-    // optional per-kernel timing with HIP events on the launch stream (lvt_amd_profile_*)
+    // optional per-kernel timing with HIP events on the launch streams (lvt_amd_profile_*)
     bool prof = false;
     static constexpr int PROF_SLOTS = 24;
     hipEvent_t ev[PROF_SLOTS][2] = {};
     bool ev_used[PROF_SLOTS] = {};
     double prof_ms[PROF_SLOTS] = {};
     long prof_calls[PROF_SLOTS] = {};
-    long prof_frames = 0;
 
     void set_error(const std::string &s) { err = s; }
 
@@ -98,14 +117,19 @@ struct Context {
     }
 
     ~Context() {
-        if (stream && own_stream) (void)hipStreamSynchronize(stream);
+        if (stream) (void)hipStreamSynchronize(stream);
+        if (stream_f) (void)hipStreamSynchronize(stream_f);
         for (void *p : allocs) (void)hipFree(p);
         for (auto &e : ev)
             for (auto &x : e)
                 if (x) (void)hipEventDestroy(x);
+        for (auto &x : ev_feat) if (x) (void)hipEventDestroy(x);
+        for (auto &x : ev_track) if (x) (void)hipEventDestroy(x);
+        for (auto &x : ev_done) if (x) (void)hipEventDestroy(x);
         if (h_ctl) (void)hipHostFree(h_ctl);
         if (h_fargs) (void)hipHostFree(h_fargs);
         if (stream && own_stream) (void)hipStreamDestroy(stream);
+        if (stream_f) (void)hipStreamDestroy(stream_f);
     }
 };
 
@@ -241,7 +265,10 @@ static void alloc_points(Context *c, MapSoA &P, int cap) {
     P.counter = c->dalloc<int>(cap), P.age = c->dalloc<int>(cap), P.match_idx = c->dalloc<int>(cap);
 }
 
+static void drain(Context *c);
+
 static void reset_state(Context *c) {  // lvt_system::reset (lvt_system.cpp:44-68)
+    drain(c);
     for (int s = 0; s < c->B; s++) {
         Ctl z;
         std::memset(&z, 0, sizeof(z));
@@ -258,7 +285,7 @@ static void reset_state(Context *c) {  // lvt_system::reset (lvt_system.cpp:44-6
         HIPCHK(c, hipMemsetAsync(c->h_seqs[s].map_cur, 0, sizeof(int), c->stream));
         HIPCHK(c, hipMemsetAsync(c->h_seqs[s].staged_n, 0, sizeof(int), c->stream));
         HIPCHK(c, hipMemsetAsync(c->h_seqs[s].staged_cur, 0, sizeof(int), c->stream));
-        c->h_ctl[s] = z;
+        for (int r = 0; r < RING; r++) c->h_ctl[r * c->B + s] = z;
     }
     HIPCHK(c, hipStreamSynchronize(c->stream));
 }
@@ -275,10 +302,14 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
         c->sensor = sensor;
         c->prm = prm;
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream_f, hipStreamNonBlocking));
         c->own_stream = true;
+        for (auto &e : c->ev_feat) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : c->ev_track) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : c->ev_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->pitch = ((prm.W + 63) / 64) * 64;
-        HIPCHK(c, hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl) * B, hipHostMallocDefault));
-        HIPCHK(c, hipHostMalloc((void **)&c->h_fargs, sizeof(FrameArgs) * B, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl) * B * RING, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&c->h_fargs, sizeof(FrameArgs) * B * RING, hipHostMallocDefault));
         c->h_seqs.resize(B);
         c->d_ctl.resize(B);
         const size_t plane = (size_t)c->pitch * prm.H;
@@ -297,16 +328,24 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
                     off += (size_t)cw * ch * 6;
                 }
             }
-            for (int e = 0; e < 2; e++) {
-                S.score[e] = c->dalloc<uint8_t>(plane + 64);
-                S.boxsum[e] = c->dalloc<uint16_t>(plane + 64);
-                S.cell_kp[e] = c->dalloc<float>((size_t)CELLS_MAX * CELL_OUT_CAP * 3);
-                S.cell_n[e] = c->dalloc<int>(CELLS_MAX);
-                S.cell_scratch[e] = c->dalloc<uint32_t>((size_t)prm.W * prm.H * 6 + 64);
-                alloc_feat(c, S.feat[e]);
-                float *ext = c->dalloc<float>((size_t)EXT_MAX * 2);
-                c->d_ext[e].push_back(ext);
-                S.ext_xy[e] = ext;
+            for (int e = 0; e < 2; e++) S.cell_scratch[e] = c->dalloc<uint32_t>((size_t)prm.W * prm.H * 6 + 64);
+            for (int par = 0; par < 2; par++) {
+                FrameBuf &FB = S.fb[par];
+                FB.fc = c->dalloc<FeatCtl>(1);
+                for (int e = 0; e < 2; e++) {
+                    FB.score[e] = c->dalloc<uint8_t>(plane + 64);
+                    FB.boxsum[e] = c->dalloc<uint16_t>(plane + 64);
+                    FB.cell_kp[e] = c->dalloc<float>((size_t)CELLS_MAX * CELL_OUT_CAP * 3);
+                    FB.cell_n[e] = c->dalloc<int>(CELLS_MAX);
+                    alloc_feat(c, FB.feat[e]);
+                    if (s == 0) {
+                        c->d_ext[par][e] = c->dalloc<float>((size_t)EXT_MAX * 2);
+                        c->d_packed[par][e] = c->dalloc<uint8_t>((size_t)prm.W * prm.H + 64);
+                        c->d_img[par][e] = c->dalloc<uint8_t>(plane + 64);
+                    }
+                    FB.ext_xy[e] = c->d_ext[par][e];
+                }
+                if (s == 0 && sensor == 2) c->d_depth[par] = c->dalloc<float>((size_t)prm.W * prm.H);
             }
             for (int k = 0; k < 2; k++) {
                 alloc_points(c, S.map[k], MAP_MAX);
@@ -335,13 +374,6 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
             S.pair_l = c->dalloc<int>(NF_MAX), S.pair_r = c->dalloc<int>(NF_MAX);
             S.tri_X = c->dalloc<double>((size_t)NF_MAX * 3);
             S.tri_ok = c->dalloc<int8_t>(NF_MAX);
-            // staging images for the host-buffer entry points
-            c->d_img_l.push_back(c->dalloc<uint8_t>(plane + 64));
-            c->d_img_r.push_back(c->dalloc<uint8_t>(plane + 64));
-            c->d_depth.push_back(sensor == 2 ? c->dalloc<float>((size_t)prm.W * prm.H) : nullptr);
-        }
-        for (int e = 0; e < 2; e++) c->d_packed[e] = c->dalloc<uint8_t>((size_t)prm.W * prm.H + 64);
-        {
         }
         c->d_seqs = c->dalloc<Seq>(B);
         HIPCHK(c, hipMemcpy(c->d_seqs, c->h_seqs.data(), sizeof(Seq) * B, hipMemcpyHostToDevice));
@@ -357,12 +389,12 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
 
 // ---- the per-frame launch chain -------------------------------------------------------------------
 static const char *kProfNames[Context::PROF_SLOTS] = {
-    "k_set_frame", "k_begin", "k_score", "k_cells(pass0)", "k_cells(retry)", "k_gather", "k_brief", "k_project(map)",
+    "k_feat_begin", "k_begin", "k_score", "k_cells(pass0)", "k_cells(retry)", "k_gather", "k_brief", "k_project(map)",
     "k_candidates(map)", "k_resolve(map)", "k_candidates(map,pass2)", "k_resolve(map,pass2)", "k_bookkeep", "k_pnp", "k_cull",
     "k_project(staged)", "k_candidates(staged)", "k_staged", "k_candidates(row)", "k_resolve(row)", "k_triangulate", "k_finalize",
     "", ""};
 
-#define LAUNCH(slot, kern, grid, block, lds, ...)                                  \
+#define LAUNCH(slot, st, kern, grid, block, lds, ...)                              \
     do {                                                                           \
         if (c->prof) (void)hipEventRecord(c->ev[slot][0], st);                     \
         hipLaunchKernelGGL(kern, grid, block, lds, st, __VA_ARGS__);               \
@@ -372,46 +404,65 @@ static const char *kProfNames[Context::PROF_SLOTS] = {
         }                                                                          \
     } while (0)
 
-static void enqueue_frame(Context *c, int ext_corners, int n_ext_l, int n_ext_r) {
+static void collect_oldest(Context *c);
+
+// frame inputs must already be in h_fargs[slot] (and any upload enqueued on stream_f)
+static void enqueue_frame(Context *c) {
     const int B = c->B;
-    hipStream_t st = c->stream;
     const Params &p = c->prm;
     Seq *S = c->d_seqs;
+    const int slot = (int)(c->enq % RING), par = (int)(c->enq & 1);
+    const FrameArgs *fa = c->h_fargs + (size_t)slot * B;
+    const int ext = fa[0].ext_corners;
+    hipStream_t sf = c->stream_f, st = c->stream;
     for (int i = 0; i < Context::PROF_SLOTS; i++) c->ev_used[i] = false;
-    LAUNCH(0, k_set_frame, dim3(B), dim3(64), 0, S, c->h_fargs);
-    LAUNCH(1, k_begin, dim3(B), dim3(64), 0, S, ext_corners, n_ext_l, n_ext_r);
-    LAUNCH(2, k_score, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2 * B), dim3(256), 0, S);
-    if (!ext_corners) {
-        LAUNCH(3, k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, S, 0);
-        LAUNCH(4, k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, S, 1);
+    // ---- feature stage (stream_f): may start as soon as the tracking chain of frame enq-2 released this parity
+    if (c->enq >= 2) (void)hipStreamWaitEvent(sf, c->ev_track[par], 0);
+    LAUNCH(0, sf, k_feat_begin, dim3(B), dim3(64), 0, S, fa, par);
+    LAUNCH(2, sf, k_score, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2 * B), dim3(256), 0, S, par);
+    if (!ext) {
+        LAUNCH(3, sf, k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, S, 0, par);
+        LAUNCH(4, sf, k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, S, 1, par);
     }
-    LAUNCH(5, k_gather, dim3(1, 2, B), dim3(1024), 0, S);
-    LAUNCH(6, k_brief, dim3(64, 2, B), dim3(256), 0, S);
-    LAUNCH(7, k_project, dim3(32, 1, B), dim3(256), 0, S, (int)MODE_MAP);
-    LAUNCH(8, k_candidates<MODE_MAP>, dim3(256, 1, B), dim3(256), 0, S, 0);
-    LAUNCH(9, k_resolve<MODE_MAP>, dim3(1, 1, B), dim3(256), 0, S, 0);
-    LAUNCH(10, k_candidates<MODE_MAP>, dim3(256, 1, B), dim3(256), 0, S, 1);
-    LAUNCH(11, k_resolve<MODE_MAP>, dim3(1, 1, B), dim3(256), 0, S, 1);
-    LAUNCH(12, k_bookkeep, dim3(1, 1, B), dim3(1024), 0, S);
-    LAUNCH(13, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), 0, S);
-    LAUNCH(14, k_cull, dim3(1, 1, B), dim3(1024), 0, S);
-    LAUNCH(15, k_project, dim3(32, 1, B), dim3(256), 0, S, (int)MODE_STAGED);
-    LAUNCH(16, k_candidates<MODE_STAGED>, dim3(64, 1, B), dim3(256), 0, S, 0);
-    LAUNCH(17, k_staged, dim3(1, 1, B), dim3(1024), 0, S);
-    LAUNCH(18, k_candidates<MODE_ROW>, dim3(256, 1, B), dim3(256), 0, S, 0);
-    LAUNCH(19, k_resolve<MODE_ROW>, dim3(1, 1, B), dim3(256), 0, S, 0);
-    LAUNCH(20, k_triangulate, dim3(1, 1, B), dim3(1024), 0, S);
-    LAUNCH(21, k_finalize, dim3(B), dim3(64), 0, S);
+    LAUNCH(5, sf, k_gather, dim3(1, 2, B), dim3(1024), 0, S, par);
+    LAUNCH(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, S, par);
+    (void)hipEventRecord(c->ev_feat[par], sf);
+    // ---- tracking chain (stream): strictly ordered frame after frame
+    (void)hipStreamWaitEvent(st, c->ev_feat[par], 0);
+    LAUNCH(1, st, k_begin, dim3(B), dim3(64), 0, S, par);
+    LAUNCH(7, st, k_project, dim3(32, 1, B), dim3(256), 0, S, (int)MODE_MAP, par);
+    LAUNCH(8, st, k_candidates<MODE_MAP>, dim3(256, 1, B), dim3(256), 0, S, 0, par);
+    LAUNCH(9, st, k_resolve<MODE_MAP>, dim3(1, 1, B), dim3(RES_THREADS), 0, S, 0, par);
+    LAUNCH(10, st, k_candidates<MODE_MAP>, dim3(256, 1, B), dim3(256), 0, S, 1, par);
+    LAUNCH(11, st, k_resolve<MODE_MAP>, dim3(1, 1, B), dim3(RES_THREADS), 0, S, 1, par);
+    LAUNCH(12, st, k_bookkeep, dim3(1, 1, B), dim3(1024), 0, S, par);
+    LAUNCH(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), 0, S, par);
+    LAUNCH(14, st, k_cull, dim3(1, 1, B), dim3(1024), 0, S, par);
+    LAUNCH(15, st, k_project, dim3(32, 1, B), dim3(256), 0, S, (int)MODE_STAGED, par);
+    LAUNCH(16, st, k_candidates<MODE_STAGED>, dim3(64, 1, B), dim3(256), 0, S, 0, par);
+    LAUNCH(17, st, k_staged, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par);
+    LAUNCH(18, st, k_candidates<MODE_ROW>, dim3(256, 1, B), dim3(256), 0, S, 0, par);
+    LAUNCH(19, st, k_resolve<MODE_ROW>, dim3(1, 1, B), dim3(RES_THREADS), 0, S, 0, par);
+    LAUNCH(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, S, par);
+    LAUNCH(21, st, k_finalize, dim3(B), dim3(64), 0, S, par);
     for (int s = 0; s < B; s++)
-        (void)hipMemcpyAsync(&c->h_ctl[s], c->d_ctl[s], sizeof(Ctl), hipMemcpyDeviceToHost, st);
-    c->pending = true;
+        (void)hipMemcpyAsync(&c->h_ctl[(size_t)slot * B + s], c->d_ctl[s], sizeof(Ctl), hipMemcpyDeviceToHost, st);
+    (void)hipEventRecord(c->ev_track[par], st);
+    (void)hipEventRecord(c->ev_done[slot], st);
+    c->enq++;
 }
 
-static void wait_frame(Context *c) {
-    if (!c->pending) return;
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    c->pending = false;
-    if (c->prof) {
+// wait for the oldest un-collected frame; its record becomes "last"
+static void collect_oldest(Context *c) {
+    if (c->done >= c->enq) return;
+    const int slot = (int)(c->done % RING);
+    HIPCHK(c, hipEventSynchronize(c->ev_done[slot]));
+    c->last_slot = slot;
+    c->last_par = (int)(c->done & 1);
+    c->done++;
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) c->set_error(std::string("kernel chain: ") + hipGetErrorString(e));
+    if (c->prof && c->done == c->enq) {  // profiling is meaningful when frames are collected one at a time
         for (int i = 0; i < Context::PROF_SLOTS; i++)
             if (c->ev_used[i]) {
                 float ms = 0;
@@ -420,20 +471,24 @@ static void wait_frame(Context *c) {
                     c->prof_calls[i]++;
                 }
             }
-        c->prof_frames++;
     }
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) c->set_error(std::string("kernel chain: ") + hipGetErrorString(e));
     for (int s = 0; s < c->B; s++)
-        if (c->h_ctl[s].overflow) {
+        if (c->h_ctl[(size_t)slot * c->B + s].overflow) {
             char buf[128];
-            std::snprintf(buf, sizeof(buf), "capacity overflow mask 0x%x in sequence %d", c->h_ctl[s].overflow, s);
+            std::snprintf(buf, sizeof(buf), "capacity overflow mask 0x%x in sequence %d", c->h_ctl[(size_t)slot * c->B + s].overflow, s);
             c->set_error(buf);
         }
 }
+static void drain(Context *c) {
+    while (c->done < c->enq) collect_oldest(c);
+}
+static void make_room(Context *c) {  // at most RING-1 frames un-collected before a new one is enqueued
+    while (c->enq - c->done >= RING - 1) collect_oldest(c);
+}
+static const Ctl &last_ctl(Context *c, int s = 0) { return c->h_ctl[(size_t)c->last_slot * c->B + s]; }
 
 static void result_out(Context *c, int s, double R[3][3], double t[3]) {
-    const Ctl &h = c->h_ctl[s];
+    const Ctl &h = last_ctl(c, s);
     if (R)
         for (int i = 0; i < 3; i++)
             for (int j = 0; j < 3; j++) R[i][j] = h.out_R[3 * i + j];
@@ -493,9 +548,7 @@ LVT_API void lvt_destroy(lvt_handle h) {
 
 LVT_API void lvt_amd_reset(lvt_handle h) {
     try {
-        Context *c = static_cast<Context *>(h);
-        wait_frame(c);
-        reset_state(c);
+        reset_state(static_cast<Context *>(h));
     } catch (...) {
     }
 }
@@ -503,7 +556,7 @@ LVT_API void lvt_amd_reset(lvt_handle h) {
 LVT_API void lvt_amd_set_stream(lvt_handle h, void *hip_stream) {
     Context *c = static_cast<Context *>(h);
     try {
-        wait_frame(c);
+        drain(c);
         if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
         c->stream = static_cast<hipStream_t>(hip_stream);
         c->own_stream = false;
@@ -516,13 +569,12 @@ LVT_API const char *lvt_amd_last_error(lvt_handle h) { return static_cast<Contex
 LVT_API void lvt_amd_profile_enable(lvt_handle h, int enable) {
     Context *c = static_cast<Context *>(h);
     try {
-        wait_frame(c);
+        drain(c);
         if (enable) {
             for (auto &e : c->ev)
                 for (auto &x : e)
                     if (!x) HIPCHK(c, hipEventCreate(&x));
             for (int i = 0; i < Context::PROF_SLOTS; i++) c->prof_ms[i] = 0, c->prof_calls[i] = 0;
-            c->prof_frames = 0;
         }
         c->prof = enable != 0;
     } catch (...) {
@@ -544,13 +596,16 @@ LVT_API void lvt_amd_track_device_async(lvt_handle h, const void *d_left, const 
             c->set_error("lvt_amd_track_device: image size / pitch mismatch");
             return;
         }
-        wait_frame(c);
-        c->h_fargs[0].img[0] = static_cast<const uint8_t *>(d_left);
-        c->h_fargs[0].img[1] = static_cast<const uint8_t *>(d_right);
-        c->h_fargs[0].depth = nullptr;
-        c->h_fargs[0].img_pitch = pitch_bytes;
-        c->h_fargs[0].depth_pitch = 0;
-        enqueue_frame(c, 0, 0, 0);
+        make_room(c);
+        FrameArgs &f = c->h_fargs[(size_t)(c->enq % RING) * c->B];
+        f.img[0] = static_cast<const uint8_t *>(d_left);
+        f.img[1] = static_cast<const uint8_t *>(d_right);
+        f.depth = nullptr;
+        f.img_pitch = pitch_bytes;
+        f.depth_pitch = 0;
+        f.ext_corners = 0;
+        f.n_ext[0] = f.n_ext[1] = 0;
+        enqueue_frame(c);
     } catch (...) {
     }
 }
@@ -558,7 +613,7 @@ LVT_API void lvt_amd_track_device_async(lvt_handle h, const void *d_left, const 
 LVT_API void lvt_amd_wait(lvt_handle h, double R[3][3], double t[3]) {
     Context *c = static_cast<Context *>(h);
     try {
-        wait_frame(c);
+        if (c->done < c->enq) collect_oldest(c);  // FIFO: the oldest frame not yet collected
         result_out(c, 0, R, t);
     } catch (...) {
     }
@@ -571,8 +626,13 @@ LVT_API void lvt_amd_track_device(lvt_handle h, const void *d_left, const void *
         c->set_error("lvt_amd_track_device: image size / pitch mismatch");
         return;  // outputs untouched, like the reference on an exception
     }
-    lvt_amd_track_device_async(h, d_left, d_right, n_rows, n_cols, pitch_bytes);
-    lvt_amd_wait(h, R, t);
+    try {
+        drain(c);
+        lvt_amd_track_device_async(h, d_left, d_right, n_rows, n_cols, pitch_bytes);
+        drain(c);
+        result_out(c, 0, R, t);
+    } catch (...) {
+    }
 }
 
 static void upload_and_track(Context *c, const unsigned char *left, const void *second, bool rgbd, int n_rows, int n_cols, int ext,
@@ -581,30 +641,36 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
         c->set_error("lvt_track: image size differs from the configured img_width/img_height");
         return;
     }
-    wait_frame(c);
+    drain(c);
+    const int par = (int)(c->enq & 1);
+    hipStream_t sf = c->stream_f;
     // one contiguous H2D copy per image, then a device-side re-pitch (a strided 2-D copy of pageable memory is slow)
     const size_t nbytes = (size_t)n_rows * n_cols;
-    HIPCHK(c, hipMemcpyAsync(c->d_packed[0], left, nbytes, hipMemcpyHostToDevice, c->stream));
-    hipLaunchKernelGGL(k_repitch, dim3(512), dim3(256), 0, c->stream, c->d_packed[0], c->d_img_l[0], n_cols, n_rows, c->pitch);
-    c->h_fargs[0].img[0] = c->d_img_l[0];
-    c->h_fargs[0].img[1] = c->d_img_r[0];
-    c->h_fargs[0].img_pitch = c->pitch;
-    c->h_fargs[0].depth = nullptr;
-    c->h_fargs[0].depth_pitch = 0;
+    HIPCHK(c, hipMemcpyAsync(c->d_packed[par][0], left, nbytes, hipMemcpyHostToDevice, sf));
+    hipLaunchKernelGGL(k_repitch, dim3(512), dim3(256), 0, sf, c->d_packed[par][0], c->d_img[par][0], n_cols, n_rows, c->pitch);
+    FrameArgs &f = c->h_fargs[(size_t)(c->enq % RING) * c->B];
+    f.img[0] = c->d_img[par][0];
+    f.img[1] = c->d_img[par][1];
+    f.img_pitch = c->pitch;
+    f.depth = nullptr;
+    f.depth_pitch = 0;
     if (rgbd) {
-        HIPCHK(c, hipMemcpyAsync(c->d_depth[0], second, sizeof(float) * (size_t)n_rows * n_cols, hipMemcpyHostToDevice, c->stream));
-        c->h_fargs[0].depth = c->d_depth[0];
-        c->h_fargs[0].depth_pitch = n_cols;
+        HIPCHK(c, hipMemcpyAsync(c->d_depth[par], second, sizeof(float) * nbytes, hipMemcpyHostToDevice, sf));
+        f.depth = c->d_depth[par];
+        f.depth_pitch = n_cols;
     } else {
-        HIPCHK(c, hipMemcpyAsync(c->d_packed[1], second, nbytes, hipMemcpyHostToDevice, c->stream));
-        hipLaunchKernelGGL(k_repitch, dim3(512), dim3(256), 0, c->stream, c->d_packed[1], c->d_img_r[0], n_cols, n_rows, c->pitch);
+        HIPCHK(c, hipMemcpyAsync(c->d_packed[par][1], second, nbytes, hipMemcpyHostToDevice, sf));
+        hipLaunchKernelGGL(k_repitch, dim3(512), dim3(256), 0, sf, c->d_packed[par][1], c->d_img[par][1], n_cols, n_rows, c->pitch);
     }
+    f.ext_corners = ext;
+    f.n_ext[0] = ncl;
+    f.n_ext[1] = ncr;
     if (ext) {
-        if (ncl) HIPCHK(c, hipMemcpyAsync(c->d_ext[0][0], cl, sizeof(float) * 2 * (size_t)ncl, hipMemcpyHostToDevice, c->stream));
-        if (ncr) HIPCHK(c, hipMemcpyAsync(c->d_ext[1][0], cr, sizeof(float) * 2 * (size_t)ncr, hipMemcpyHostToDevice, c->stream));
+        if (ncl) HIPCHK(c, hipMemcpyAsync(c->d_ext[par][0], cl, sizeof(float) * 2 * (size_t)ncl, hipMemcpyHostToDevice, sf));
+        if (ncr) HIPCHK(c, hipMemcpyAsync(c->d_ext[par][1], cr, sizeof(float) * 2 * (size_t)ncr, hipMemcpyHostToDevice, sf));
     }
-    enqueue_frame(c, ext, ncl, ncr);
-    wait_frame(c);
+    enqueue_frame(c);
+    drain(c);
     result_out(c, 0, R, t);
 }
 
@@ -651,29 +717,28 @@ LVT_API void lvt_track_with_external_corners(lvt_handle h, unsigned char *left, 
 LVT_API int lvt_get_status(lvt_handle h) {
     try {
         Context *c = static_cast<Context *>(h);
-        wait_frame(c);
-        return c->h_ctl[0].out_status == 0 ? c->h_ctl[0].state : (c->h_ctl[0].state);
+        drain(c);
+        return last_ctl(c).state;
     } catch (...) {
     }
     return -1;
 }
 
-// ---- introspection --------------------------------------------------------------------------------
+// ---- introspection (of the most recently COLLECTED frame; drains the pipeline first) -----------------
 LVT_API void lvt_amd_get_counts(lvt_handle h, int out[LVT_AMD_C__COUNT]) {
     Context *c = static_cast<Context *>(h);
     try {
-        wait_frame(c);
-        for (int i = 0; i < LVT_AMD_C__COUNT; i++) out[i] = c->h_ctl[0].counts[i];
+        drain(c);
+        for (int i = 0; i < LVT_AMD_C__COUNT; i++) out[i] = last_ctl(c).counts[i];
     } catch (...) {
     }
 }
 
-
 LVT_API int lvt_amd_get_features(lvt_handle h, int eye, float *xy, float *resp, uint8_t *desc, int cap) {
     Context *c = static_cast<Context *>(h);
     try {
-        wait_frame(c);
-        const Feat &F = c->h_seqs[0].feat[eye ? 1 : 0];
+        drain(c);
+        const Feat &F = c->h_seqs[0].fb[c->last_par].feat[eye ? 1 : 0];
         const int n = read_scalar(c, F.n), m = std::min(n, cap);
         std::vector<float> x(m), y(m);
         d2h(c, x.data(), F.x, m);
@@ -691,8 +756,8 @@ LVT_API int lvt_amd_get_features(lvt_handle h, int eye, float *xy, float *resp, 
 LVT_API int lvt_amd_get_matches(lvt_handle h, int *feat_idx, double *xyz, int cap) {
     Context *c = static_cast<Context *>(h);
     try {
-        wait_frame(c);
-        const int n = c->h_ctl[0].n_matches, m = std::min(n, cap);
+        drain(c);
+        const int n = last_ctl(c).n_matches, m = std::min(n, cap);
         d2h(c, feat_idx, c->h_seqs[0].pnp_feat, m);
         d2h(c, xyz, c->h_seqs[0].pnp_X, (size_t)m * 3);
         return n;
@@ -704,8 +769,8 @@ LVT_API int lvt_amd_get_matches(lvt_handle h, int *feat_idx, double *xyz, int ca
 LVT_API int lvt_amd_get_row_matches(lvt_handle h, int *pairs, int cap) {
     Context *c = static_cast<Context *>(h);
     try {
-        wait_frame(c);
-        const int n = c->h_ctl[0].counts[C_N_ROW_MATCHES], m = std::min(n, cap);
+        drain(c);
+        const int n = last_ctl(c).counts[C_N_ROW_MATCHES], m = std::min(n, cap);
         std::vector<int> l(m), r(m);
         d2h(c, l.data(), c->h_seqs[0].pair_l, m);
         d2h(c, r.data(), c->h_seqs[0].pair_r, m);
@@ -729,7 +794,7 @@ static int get_points(Context *c, const MapSoA *bufs, const int *d_cur, const in
 LVT_API int lvt_amd_get_map(lvt_handle h, double *xyz, int *counter, int *age, uint8_t *desc, int cap) {
     Context *c = static_cast<Context *>(h);
     try {
-        wait_frame(c);
+        drain(c);
         const Seq &S = c->h_seqs[0];
         return get_points(c, S.map, S.map_cur, S.map_n, xyz, counter, age, desc, cap);
     } catch (...) {
@@ -739,7 +804,7 @@ LVT_API int lvt_amd_get_map(lvt_handle h, double *xyz, int *counter, int *age, u
 LVT_API int lvt_amd_get_staged(lvt_handle h, double *xyz, int *counter, uint8_t *desc, int cap) {
     Context *c = static_cast<Context *>(h);
     try {
-        wait_frame(c);
+        drain(c);
         const Seq &S = c->h_seqs[0];
         return get_points(c, S.staged, S.staged_cur, S.staged_n, xyz, counter, nullptr, desc, cap);
     } catch (...) {
@@ -749,39 +814,39 @@ LVT_API int lvt_amd_get_staged(lvt_handle h, double *xyz, int *counter, uint8_t 
 LVT_API void lvt_amd_get_pose(lvt_handle h, double q[4], double p[3]) {
     Context *c = static_cast<Context *>(h);
     try {
-        wait_frame(c);
-        for (int k = 0; k < 4; k++) q[k] = c->h_ctl[0].last_pose.q[k];
-        for (int k = 0; k < 3; k++) p[k] = c->h_ctl[0].last_pose.p[k];
+        drain(c);
+        for (int k = 0; k < 4; k++) q[k] = last_ctl(c).last_pose.q[k];
+        for (int k = 0; k < 3; k++) p[k] = last_ctl(c).last_pose.p[k];
     } catch (...) {
     }
 }
 LVT_API void lvt_amd_get_predicted_pose(lvt_handle h, double q[4], double p[3]) {
     Context *c = static_cast<Context *>(h);
     try {
-        wait_frame(c);
-        for (int k = 0; k < 4; k++) q[k] = c->h_ctl[0].predicted.q[k];
-        for (int k = 0; k < 3; k++) p[k] = c->h_ctl[0].predicted.p[k];
+        drain(c);
+        for (int k = 0; k < 4; k++) q[k] = last_ctl(c).predicted.q[k];
+        for (int k = 0; k < 3; k++) p[k] = last_ctl(c).predicted.p[k];
     } catch (...) {
     }
 }
 LVT_API void lvt_amd_get_debug(lvt_handle h, long long out[32]) {
     Context *c = static_cast<Context *>(h);
     try {
-        wait_frame(c);
-        for (int i = 0; i < 32; i++) out[i] = c->h_ctl[0].dbg[i];
+        drain(c);
+        for (int i = 0; i < 32; i++) out[i] = last_ctl(c).dbg[i];
     } catch (...) {
     }
 }
 LVT_API int lvt_amd_get_plane(lvt_handle h, int eye, int what, void *dst, int cap_bytes, int *pitch_out) {
     Context *c = static_cast<Context *>(h);
     try {
-        wait_frame(c);
-        const Seq &S = c->h_seqs[0];
+        drain(c);
+        const FrameBuf &FB = c->h_seqs[0].fb[c->last_par];
         const size_t n = (size_t)c->pitch * c->prm.H;
         const size_t bytes = n * (what == 0 ? 1 : 2);
         if ((size_t)cap_bytes < bytes) return -1;
-        if (what == 0) HIPCHK(c, hipMemcpy(dst, S.score[eye ? 1 : 0], bytes, hipMemcpyDeviceToHost));
-        else HIPCHK(c, hipMemcpy(dst, S.boxsum[eye ? 1 : 0], bytes, hipMemcpyDeviceToHost));
+        if (what == 0) HIPCHK(c, hipMemcpy(dst, FB.score[eye ? 1 : 0], bytes, hipMemcpyDeviceToHost));
+        else HIPCHK(c, hipMemcpy(dst, FB.boxsum[eye ? 1 : 0], bytes, hipMemcpyDeviceToHost));
         if (pitch_out) *pitch_out = c->pitch;
         return (int)bytes;
     } catch (...) {

@@ -122,3 +122,37 @@ def test_full_size_properties(hip_lib):
             assert np.array_equal(R1, np.eye(3)) and np.array_equal(t1, np.zeros(3))
         Rg, tg = world.pose(i)
         assert np.linalg.norm(t1 - tg) < 0.02, "odometry drifted from ground truth"
+
+
+def test_async_pipeline_equals_synchronous(hip_lib):
+    """lvt_amd_track_device_async / lvt_amd_wait (feature stage of frame t+1 overlapped with the tracking chain of
+    frame t, several frames in flight) returns exactly the poses of the synchronous entry point, in FIFO order"""
+    import torch
+    world, prm, sensor = make_case("kitti", 12, 0.5)
+    n = 24
+    pitch = ((world.W + 63) // 64) * 64
+    dev = torch.zeros((n, 2, world.H, pitch), dtype=torch.uint8, device="cuda")
+    for i in range(n):
+        L, R = world.render_stereo(i)
+        dev[i, 0, :, :world.W] = torch.from_numpy(L).cuda(); dev[i, 1, :, :world.W] = torch.from_numpy(R).cuda()
+    torch.cuda.synchronize()
+    a = hip_lib.LvtSystem.create(prm, 1); b = hip_lib.LvtSystem.create(prm, 1)
+    ref = []
+    for i in range(n):
+        p = dev[i].data_ptr()
+        ref.append(a.track_device(p, p + world.H * pitch, world.H, world.W, pitch))
+    got = []
+    inflight = 0
+    for i in range(n):
+        p = dev[i].data_ptr()
+        b.track_device_async(p, p + world.H * pitch, world.H, world.W, pitch)
+        inflight += 1
+        if inflight >= 5:
+            got.append(b.wait()); inflight -= 1
+    while inflight:
+        got.append(b.wait()); inflight -= 1
+    assert len(got) == n
+    for i, ((Ra, ta), (Rb, tb)) in enumerate(zip(ref, got)):
+        assert np.array_equal(ta, tb) and np.array_equal(Ra, Rb), f"frame {i}"
+    assert a.counts() == b.counts()
+    assert b.get_state() == 2 and b.last_error() == ""

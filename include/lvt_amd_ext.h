@@ -57,6 +57,19 @@ LVT_API void lvt_amd_track_device(lvt_handle h, const void *d_left, const void *
 LVT_API void lvt_amd_track_device_async(lvt_handle h, const void *d_left, const void *d_right, int n_rows,
                                         int n_cols, int pitch_bytes);
 LVT_API void lvt_amd_wait(lvt_handle h, double R[3][3], double t[3]);
+/* ---- lock-step batch of independent sequences on ONE GPU ----------------------------------------------
+ * B sequences (e.g. several KITTI drives) advance frame by frame through a single launch chain (every kernel is
+ * launched with gridDim.z = B); the latency-bound serial kernels of the path (pose refinement, greedy resolvers)
+ * then occupy B compute units instead of one.  Sequences stay fully independent (no cross-sequence data). */
+LVT_API lvt_handle lvt_amd_batch_create(const lvt_amd_params *p, int sensor_type, int n_sequences);
+LVT_API int lvt_amd_batch_size(lvt_handle h);
+/* d_left / d_right: host arrays of B device pointers (one stereo pair per sequence, same size & pitch) */
+LVT_API void lvt_amd_batch_track_device_async(lvt_handle h, const void *const *d_left, const void *const *d_right,
+                                              int n_rows, int n_cols, int pitch_bytes);
+/* oldest un-collected frame: R = B x 9 doubles, t = B x 3 doubles, status = B ints (any may be NULL) */
+LVT_API void lvt_amd_batch_wait(lvt_handle h, double *R, double *t, int *status);
+LVT_API void lvt_amd_batch_get_counts(lvt_handle h, int seq, int out[32]);
+
 /* run all work of this handle on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream) */
 LVT_API void lvt_amd_set_stream(lvt_handle h, void *hip_stream);
 /* last HIP error string seen by this handle ("" if none); overflow / capacity diagnostics too */

@@ -29,6 +29,8 @@ ABI_SYMBOLS = [
     "lvt_amd_get_matches", "lvt_amd_get_row_matches", "lvt_amd_get_map", "lvt_amd_get_staged",
     "lvt_amd_get_pose", "lvt_amd_get_predicted_pose", "lvt_amd_get_plane", "lvt_amd_pnp",
     "lvt_amd_hamming_match_batched", "lvt_amd_profile_enable", "lvt_amd_profile_read", "lvt_amd_get_debug",
+    "lvt_amd_batch_create", "lvt_amd_batch_size", "lvt_amd_batch_track_device_async", "lvt_amd_batch_wait",
+    "lvt_amd_batch_get_counts",
 ]
 
 N_COUNTS = 32
@@ -83,6 +85,12 @@ def load_library():
     L.lvt_amd_hamming_match_batched.restype = C.c_float
     L.lvt_amd_hamming_match_batched.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp]
     L.lvt_amd_profile_enable.argtypes = [vp, C.c_int]
+    L.lvt_amd_batch_create.restype = vp
+    L.lvt_amd_batch_create.argtypes = [vp, C.c_int, C.c_int]
+    L.lvt_amd_batch_size.argtypes = [vp]
+    L.lvt_amd_batch_track_device_async.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int]
+    L.lvt_amd_batch_wait.argtypes = [vp, vp, vp, vp]
+    L.lvt_amd_batch_get_counts.argtypes = [vp, C.c_int, vp]
     L.lvt_amd_get_debug.argtypes = [vp, vp]
     L.lvt_amd_profile_read.argtypes = [vp, C.c_int, C.c_char_p, C.c_int, vp, vp]
     _lib = L
@@ -263,6 +271,46 @@ class LvtSystem:
         raw = buf.view(np.uint8)[:nbytes]
         a = raw.view(np.uint8 if what == 0 else np.uint16)
         return a.reshape(-1, pitch.value).copy()
+
+
+class LvtBatch:
+    """B independent sequences advanced in lock-step by one launch chain on one GPU (include/lvt_amd_ext.h)."""
+
+    def __init__(self, params: LvtParameters, n_sequences: int, sensor_type: int = eSensor_STEREO):
+        L = load_library()
+        pod = params.to_pod()
+        self._h = L.lvt_amd_batch_create(C.byref(pod), sensor_type, n_sequences)
+        if not self._h:
+            raise RuntimeError("lvt_amd_batch_create failed (no usable HIP device -- no CPU fallback)")
+        self.B = n_sequences
+
+    def close(self):
+        if self._h:
+            load_library().lvt_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def track_device_async(self, d_left, d_right, rows, cols, pitch):
+        a = (C.c_void_p * self.B)(*[int(x) for x in d_left]); b = (C.c_void_p * self.B)(*[int(x) for x in d_right])
+        load_library().lvt_amd_batch_track_device_async(self._h, a, b, rows, cols, pitch)
+
+    def wait(self):
+        R = np.zeros((self.B, 3, 3)); t = np.zeros((self.B, 3)); st = np.zeros(self.B, np.int32)
+        load_library().lvt_amd_batch_wait(self._h, _p(R), _p(t), _p(st))
+        return R, t, st
+
+    def counts(self, seq):
+        a = np.zeros(N_COUNTS, dtype=np.int32)
+        load_library().lvt_amd_batch_get_counts(self._h, seq, _p(a))
+        return {n: int(a[i]) for i, n in enumerate(COUNT_NAMES)}
+
+    def last_error(self) -> str:
+        return load_library().lvt_amd_last_error(self._h).decode()
 
 
 def pnp(params: LvtParameters, q_in, p_in, pts, obs):

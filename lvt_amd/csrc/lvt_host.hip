@@ -610,6 +610,64 @@ LVT_API void lvt_amd_track_device_async(lvt_handle h, const void *d_left, const 
     }
 }
 
+// ---- lock-step batch: B independent sequences advance through ONE launch chain (gridDim.z = B) ------------
+LVT_API lvt_handle lvt_amd_batch_create(const lvt_amd_params *p, int sensor_type, int n_sequences) {
+    try {
+        if (n_sequences < 1 || n_sequences > 256) return nullptr;
+        return static_cast<lvt_handle>(create_context(*p, sensor_type, n_sequences));
+    } catch (...) {
+    }
+    return nullptr;
+}
+LVT_API int lvt_amd_batch_size(lvt_handle h) { return static_cast<Context *>(h)->B; }
+
+LVT_API void lvt_amd_batch_track_device_async(lvt_handle h, const void *const *d_left, const void *const *d_right, int n_rows, int n_cols,
+                                              int pitch_bytes) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        if (!size_ok(c, n_rows, n_cols) || (pitch_bytes & 15)) {
+            c->set_error("lvt_amd_batch_track_device: image size / pitch mismatch");
+            return;
+        }
+        make_room(c);
+        for (int s = 0; s < c->B; s++) {
+            FrameArgs &f = c->h_fargs[(size_t)(c->enq % RING) * c->B + s];
+            f.img[0] = static_cast<const uint8_t *>(d_left[s]);
+            f.img[1] = static_cast<const uint8_t *>(d_right[s]);
+            f.depth = nullptr;
+            f.img_pitch = pitch_bytes;
+            f.depth_pitch = 0;
+            f.ext_corners = 0;
+            f.n_ext[0] = f.n_ext[1] = 0;
+        }
+        enqueue_frame(c);
+    } catch (...) {
+    }
+}
+// poses of the oldest un-collected batch frame: R = B x 9 doubles (row-major 3x3 each), t = B x 3, status = B ints
+LVT_API void lvt_amd_batch_wait(lvt_handle h, double *R, double *t, int *status) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        if (c->done < c->enq) collect_oldest(c);
+        for (int s = 0; s < c->B; s++) {
+            const Ctl &k = last_ctl(c, s);
+            if (R) for (int i = 0; i < 9; i++) R[9 * s + i] = k.out_R[i];
+            if (t) for (int i = 0; i < 3; i++) t[3 * s + i] = k.out_t[i];
+            if (status) status[s] = k.state;
+        }
+    } catch (...) {
+    }
+}
+LVT_API void lvt_amd_batch_get_counts(lvt_handle h, int seq, int out[LVT_AMD_C__COUNT]) {
+    Context *c = static_cast<Context *>(h);
+    try {
+        drain(c);
+        if (seq < 0 || seq >= c->B) return;
+        for (int i = 0; i < LVT_AMD_C__COUNT; i++) out[i] = last_ctl(c, seq).counts[i];
+    } catch (...) {
+    }
+}
+
 LVT_API void lvt_amd_wait(lvt_handle h, double R[3][3], double t[3]) {
     Context *c = static_cast<Context *>(h);
     try {

@@ -156,3 +156,32 @@ def test_async_pipeline_equals_synchronous(hip_lib):
         assert np.array_equal(ta, tb) and np.array_equal(Ra, Rb), f"frame {i}"
     assert a.counts() == b.counts()
     assert b.get_state() == 2 and b.last_error() == ""
+
+
+def test_lockstep_batch_equals_independent_handles(hip_lib):
+    """B sequences through ONE launch chain (lvt_amd_batch_*) == B independent handles, pose for pose"""
+    import torch
+    B, n = 3, 10
+    worlds = [make_case("kitti", 20 + s, 0.5)[0] for s in range(B)]
+    prm = make_case("kitti", 20, 0.5)[1]
+    W, H = worlds[0].W, worlds[0].H
+    pitch = ((W + 63) // 64) * 64
+    dev = torch.zeros((B, n, 2, H, pitch), dtype=torch.uint8, device="cuda")
+    for s in range(B):
+        for i in range(n):
+            L, R = worlds[s].render_stereo(i)
+            dev[s, i, 0, :, :W] = torch.from_numpy(L).cuda(); dev[s, i, 1, :, :W] = torch.from_numpy(R).cuda()
+    torch.cuda.synchronize()
+    singles = [hip_lib.LvtSystem.create(prm, 1) for _ in range(B)]
+    batch = hip_lib.LvtBatch(prm, B)
+    for i in range(n):
+        lp = [dev[s, i, 0].data_ptr() for s in range(B)]; rp = [dev[s, i, 1].data_ptr() for s in range(B)]
+        batch.track_device_async(lp, rp, H, W, pitch)
+        Rb, tb, st = batch.wait()
+        for s in range(B):
+            Rs, ts = singles[s].track_device(lp[s], rp[s], H, W, pitch)
+            assert np.array_equal(ts, tb[s]) and np.array_equal(Rs, Rb[s]), f"sequence {s} frame {i}"
+            assert st[s] == 2
+    for s in range(B):
+        assert batch.counts(s) == singles[s].counts()
+    assert batch.last_error() == ""

@@ -52,6 +52,14 @@ def load_library():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C lvt_amd/csrc` "
                            "(there is no CPU fallback for the tracking path)")
+    # PyTorch wheels bundle their own libamdhip64.so (SONAME libamdhip64.so.7, same as /opt/rocm's).  If this library
+    # were loaded first, a later `import torch` would bring a SECOND HIP runtime into the process and whichever
+    # initialises last reports "no ROCm-capable device".  Importing torch first makes the dynamic loader resolve our
+    # DT_NEEDED libamdhip64.so.7 to the copy that is already mapped: one runtime per process.
+    try:
+        import torch  # noqa: F401
+    except Exception:  # torch is optional: plain C / ctypes callers simply use the system runtime
+        pass
     L = C.CDLL(LIB_PATH)
     vp = C.c_void_p
     L.lvt_create.restype = vp

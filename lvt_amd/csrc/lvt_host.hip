@@ -955,7 +955,10 @@ LVT_API int lvt_amd_pnp(const lvt_amd_params *pin, const double q_in[4], const d
 LVT_API float lvt_amd_hamming_match_batched(const void *q_desc, const void *q_xy, const void *t_desc, const void *t_xy, const void *t_flag,
                                             int B, int M, int N, float r2, int mode, int img_rows, int img_cols, void *out,
                                             void *hip_stream) {
-    if (B <= 0 || M <= 0 || N <= 0 || N > 65535) return -1.0f;
+    if (B <= 0 || M <= 0 || N <= 0 || N > HB_NMAX) {
+        std::fprintf(stderr, "lvt_amd_hamming_match_batched: bad sizes B=%d M=%d N=%d (N <= %d)\n", B, M, N, HB_NMAX);
+        return -1.0f;
+    }
     HammingArgs a;
     a.q_desc = static_cast<const uint64_t *>(q_desc);
     a.q_xy = static_cast<const float2 *>(q_xy);
@@ -964,6 +967,9 @@ LVT_API float lvt_amd_hamming_match_batched(const void *q_desc, const void *q_xy
     a.t_flag = static_cast<const uint8_t *>(t_flag);
     a.out = static_cast<int4 *>(out);
     a.M = M, a.N = N, a.r2 = r2, a.img_rows = img_rows, a.img_cols = img_cols;
+    a.dbg = nullptr;
+    long long *d_dbg = nullptr;
+    if (std::getenv("LVT_AMD_HAMMING_DEBUG") && hipMalloc((void **)&d_dbg, 64) == hipSuccess) a.dbg = d_dbg;
     if (mode == 1) {
         a.nbx = 1, a.nby = img_rows + 1, a.csr = 0;
     } else {
@@ -971,25 +977,48 @@ LVT_API float lvt_amd_hamming_match_batched(const void *q_desc, const void *q_xy
         a.csr = std::max(1, (int)std::ceil(std::sqrt(r2) / (float)HASH_CELL));
     }
     const size_t lds = hamming_lds_bytes(N, a.nbx * a.nby);
-    if (lds > 160 * 1024) return -1.0f;
+    if (lds > 160 * 1024) {
+        std::fprintf(stderr, "lvt_amd_hamming_match_batched: %zu bytes of LDS needed\n", lds);
+        return -1.0f;
+    }
     hipStream_t st = static_cast<hipStream_t>(hip_stream);
     hipEvent_t e0, e1;
-    if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return -1.0f;
-    float ms = -1.0f;
-    if (mode == 1) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hamming_batched<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipEventRecord(e0, st);
-        hipLaunchKernelGGL(k_hamming_batched<1>, dim3(B), dim3(256), lds, st, a);
-    } else {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hamming_batched<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipEventRecord(e0, st);
-        hipLaunchKernelGGL(k_hamming_batched<0>, dim3(B), dim3(256), lds, st, a);
+    {
+        const hipError_t c0 = hipEventCreate(&e0), c1 = hipEventCreate(&e1);
+        if (c0 != hipSuccess || c1 != hipSuccess) {
+            std::fprintf(stderr, "lvt_amd_hamming_match_batched: hipEventCreate failed: %s / %s\n", hipGetErrorString(c0), hipGetErrorString(c1));
+            return -1.0f;
+        }
     }
+    float ms = -1.0f;
+    hipError_t ea;
+    if (mode == 1) {
+        ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hamming_batched<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipEventRecord(e0, st);
+        hipLaunchKernelGGL(k_hamming_batched<1>, dim3(B), dim3(HB_THREADS), lds, st, a);
+    } else {
+        ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hamming_batched<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        (void)hipEventRecord(e0, st);
+        hipLaunchKernelGGL(k_hamming_batched<0>, dim3(B), dim3(HB_THREADS), lds, st, a);
+    }
+    const hipError_t elaunch = hipGetLastError();
     (void)hipEventRecord(e1, st);
-    if (hipEventSynchronize(e1) == hipSuccess && hipGetLastError() == hipSuccess) (void)hipEventElapsedTime(&ms, e0, e1);
+    const hipError_t es = hipEventSynchronize(e1);
+    hipError_t ee = hipErrorUnknown;
+    if (es == hipSuccess && elaunch == hipSuccess) ee = hipEventElapsedTime(&ms, e0, e1);
+    if (ee != hipSuccess || ms < 0)
+        std::fprintf(stderr, "lvt_amd_hamming_match_batched: attr=%s launch=%s sync=%s elapsed=%s ms=%f (B=%d M=%d N=%d lds=%zu)\n",
+                     hipGetErrorString(ea), hipGetErrorString(elaunch), hipGetErrorString(es), hipGetErrorString(ee), ms, B, M, N, lds);
     (void)hipEventDestroy(e0);
     (void)hipEventDestroy(e1);
-    return ms < 0 ? -1.0f : ms * 1000.0f;
+    if (d_dbg) {
+        long long hd[8] = {};
+        (void)hipMemcpy(hd, d_dbg, 48, hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "hamming phases (cycles): load+zero %lld count %lld scan %lld scatter %lld queries %lld total %lld\n", hd[1] - hd[0], hd[2] - hd[1],
+                     hd[3] - hd[2], hd[4] - hd[3], hd[5] - hd[4], hd[5] - hd[0]);
+        (void)hipFree(d_dbg);
+    }
+    return (ee != hipSuccess || ms < 0) ? -1.0f : ms * 1000.0f;
 }
 
 }  // extern "C"

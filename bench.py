@@ -178,6 +178,8 @@ def main():
         # ---- per-kernel timing pass (HIP events on the launch stream) over the next P frames
         kernels = []
         roofline = None
+        roofline_dom = None
+        frame_bytes = None
         if P > 0:
             vo.profile_enable(True)
             nl = nr = mp = 0
@@ -205,10 +207,10 @@ def main():
             dom_us = 1e3 * dom[1] / max(dom[2], 1)
             ab = alg.get(dom[0], 0.0)
             ach = ab / (dom_us * 1e-6) / 1e9 if dom_us > 0 else 0.0
-            roofline = {"kernel": dom[0], "bound": "hbm", "achieved": round(ach, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(ach / HBM_PEAK_GBS, 6), "traffic": None, "avg_us": round(dom_us, 3),
-                        "algorithmic_bytes_per_launch": round(ab, 1),
-                        "note": "latency-bound single-sequence launch; see roofline_hamming_batched for the batched matcher"}
+            roofline_dom = {"kernel": dom[0], "bound": "latency (serial Levenberg-Marquardt / greedy scan on one CU)", "achieved": round(ach, 4),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 8), "traffic": None,
+                            "avg_us": round(dom_us, 3), "algorithmic_bytes_per_launch": round(ab, 1)}
+            frame_bytes = 2.0 * W * H + (nl + nr) * 40.0 + bmatch(mp, nl) + bmatch(nl, nr) + 24.0 * mp + 56.0
         # ---- batched Hamming matcher micro-benchmark (the kernel north_star prices against the HBM roof)
         hb = None
         try:
@@ -228,8 +230,11 @@ def main():
             med = us[len(us) // 2]
             byts = float(B) * bmatch(M, N)
             ach = byts / (med * 1e-6) / 1e9
-            hb = {"kernel": "k_hamming_batched<radius>", "bound": "hbm", "B": B, "M": M, "N": N, "avg_us": round(med, 2),
-                  "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None}
+            hb = {"kernel": "lvt::k_hamming_batched<0> (masked 2-NN Hamming matcher, radius mode)", "bound": "hbm", "achieved": round(ach, 1),
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                  "avg_us": round(med, 2), "launch": {"B": B, "M": M, "N": N, "algorithmic_bytes": byts},
+                  "note": "B independent KITTI-nominal problems per launch; algorithmic bytes 40(M+N)+N+16M each (SURVEY 8d); timed with "
+                          "HIP events on the launch stream inside bench.py; PMC traffic in profiles/"}
         except Exception as e:  # noqa: BLE001
             hb = {"error": str(e)}
         # ---- CPU baseline: the oracle (port of the reference path), 2 threads like the reference, same frames
@@ -261,7 +266,10 @@ def main():
                        "sequences_per_gpu": 1, "frames_in_flight": DEPTH, "parallelism": f"{world_size} independent sequences, no collective"},
             "tracking": {"lost_frames": n_lost, "features_left": counts["n_left"], "map_size": counts["map_size"],
                          "matches": counts["n_matches"], "error": err},
-            "roofline": roofline, "roofline_hamming_batched": hb, "kernels": kernels, "cpu_baseline": cpu,
+            "roofline": hb, "roofline_pipeline_dominant": roofline_dom,
+            "frame_algorithmic_bytes": None if frame_bytes is None else round(frame_bytes),
+            "frame_hbm_frac": None if frame_bytes is None else round(frame_bytes * fps / world_size / 1e9 / HBM_PEAK_GBS, 6),
+            "kernels": kernels, "cpu_baseline": cpu,
         }
     if dist:
         dist.barrier()

@@ -1,17 +1,44 @@
 #!/bin/bash
-# rocprofv3 kernel-trace summary of the benchmark (run on the GPU box through gpurun).
-# Raw traces stay in /tmp; only the per-kernel stats tables are copied under gpurun_out/ (-> profiles/).
+# rocprofv3 evidence for bench.py (run on the GPU box through gpurun).  Raw traces stay in /tmp; compact per-kernel
+# summaries of OUR kernels (lvt::*) go to gpurun_out/prof_<tag>/ and from there into profiles/.
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 TAG=${1:-r01}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/prof_single /tmp/prof_batch
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_single -o bench -- python $ROOT/bench.py --steps 300 --warmup 20 --no-cpu --profile-steps 0 --depth 2 > $OUT/bench_single.json 2> $OUT/bench_single.err
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_batch -o bench -- python $ROOT/bench.py --steps 100 --warmup 10 --seqs-per-gpu 16 --depth 2 > $OUT/bench_batch16.json 2> $OUT/bench_batch16.err
-for d in single batch; do
-  f=$(find /tmp/prof_$d -name "*kernel_stats.csv" | head -1)
-  [ -n "$f" ] && cp "$f" $OUT/kernel_stats_$d.csv && echo "== $d: $f" && head -32 "$f"
-done
-tail -c 600 $OUT/bench_single.json; echo; tail -c 400 $OUT/bench_batch16.json; echo
-find /tmp/prof_single | head -20
+rm -rf /tmp/prof_*
+BENCH="python $ROOT/bench.py --steps 400 --warmup 20 --no-cpu --profile-steps 0"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_trace -o bench -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_batch -o bench -- python $ROOT/bench.py --steps 100 --warmup 10 --seqs-per-gpu 16 --depth 2 > $OUT/bench_batch16_under_rocprof.json 2> /dev/null
+# PMC: separate passes, counters only (no trace domains) -- FETCH_SIZE and WRITE_SIZE cannot share a pass
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -o bench -- python $ROOT/bench.py --steps 60 --warmup 5 --no-cpu --profile-steps 0 > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -o bench -- python $ROOT/bench.py --steps 60 --warmup 5 --no-cpu --profile-steps 0 > /dev/null 2>&1
+python - "$OUT" <<'PY'
+import csv, sys, glob, collections
+out = sys.argv[1]
+def stats(src, dst):
+    f = glob.glob(src + "/**/*kernel_stats.csv", recursive=True)
+    if not f: return
+    rows = list(csv.reader(open(f[0])))
+    keep = [rows[0]] + [r for r in rows[1:] if "lvt::" in r[0]]
+    csv.writer(open(dst, "w")).writerows(keep)
+    print("==", dst); [print(",".join(r[:4])) for r in keep]
+stats("/tmp/prof_trace", out + "/kernel_stats_single.csv")
+stats("/tmp/prof_batch", out + "/kernel_stats_batch16.csv")
+def pmc(src, name, dst):
+    f = glob.glob(src + "/**/*counter_collection.csv", recursive=True)
+    if not f: print("no counter file for", name); return
+    agg = collections.defaultdict(lambda: [0, 0.0])
+    rd = csv.DictReader(open(f[0]))
+    for r in rd:
+        k = r.get("Kernel_Name", "")
+        if "lvt::" not in k or r.get("Counter_Name") != name: continue
+        a = agg[k]; a[0] += 1; a[1] += float(r["Counter_Value"])
+    w = csv.writer(open(dst, "w")); w.writerow(["Kernel_Name", "Dispatches", name + "_sum", name + "_per_dispatch"])
+    print("==", dst)
+    for k, (n, v) in sorted(agg.items(), key=lambda x: -x[1][1]):
+        w.writerow([k, n, v, v / n]); print(k[:60], n, round(v / n, 2))
+pmc("/tmp/prof_fetch", "FETCH_SIZE", out + "/pmc_fetch_size.csv")
+pmc("/tmp/prof_write", "WRITE_SIZE", out + "/pmc_write_size.csv")
+PY
+tail -c 1500 $OUT/bench_under_rocprof.json

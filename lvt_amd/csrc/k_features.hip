@@ -1,5 +1,4 @@
 // k_features.hip -- per-frame feature extraction on gfx950:
-//   k_begin   : frame prologue + device-side state machine head (lvt_system.cpp:157-167,196-197)
 //   k_score   : OAST-9/16 corner score map + 9x9 box-sum map, one coalesced pass over the image rows
 //   k_cells   : per detection cell: raster compaction, AGAST NMS, LVT's ANMS (handler.cpp:34-83,131-154)
 //   k_gather  : concatenate cells, BRIEF border filter, RGB-D depth filter (handler.cpp:156-176,227-300)
@@ -13,38 +12,6 @@ namespace lvt {
 __constant__ signed char c_brief[256][4] = {
 #include "../../include/lvt_brief256_pattern.inc"
 };
-
-// =================================================================================================
-// k_begin
-// =================================================================================================
-__global__ void k_begin(Seq *seqs, int par) {
-    Seq &S = seqs[blockIdx.x];
-    if (threadIdx.x != 0) return;
-    Ctl &c = *S.ctl;
-    for (int i = 0; i < N_COUNTS; i++) c.counts[i] = 0;
-    c.counts[C_FRAME] = c.frame_number;
-    c.frame_number++;
-    c.active = (c.state != 3);
-    c.first_frame = (c.state == 1);
-    c.do_pass2 = 0;
-    c.n_pass1 = c.n_pass2 = 0;
-    c.n_matches = 0;
-    c.lost_now = 0;
-    c.need_tri = 0;
-    c.dont_stage = 0;
-    c.n_pairs = 0;
-    c.overflow = S.fb[par].fc->overflow;
-    c.counts[C_RETRY_LEFT] = S.fb[par].fc->retry[0];
-    c.counts[C_RETRY_RIGHT] = S.fb[par].fc->retry[1];
-    if (!c.active) {  // LOST: return the last pose forever (lvt_system.cpp:161-166)
-        pose_to_Rt(c.last_pose, c.out_R, c.out_t);
-        c.out_status = 3;
-        return;
-    }
-    if (!c.first_frame) {  // lvt_system.cpp:197 -> lvt_motion_model.cpp:42-65
-        motion_predict(c, c.last_pose, c.predicted);
-    }
-}
 
 // =================================================================================================
 // k_score : OAST-9/16 score + 9x9 box sums, tile 64x16, halo 4

@@ -21,38 +21,106 @@ namespace lvt {
 enum : int { MODE_MAP = 0, MODE_STAGED = 1, MODE_ROW = 2 };
 
 // =================================================================================================
-// k_project
+// k_project : frame prologue (the head of lvt_system::track, lvt_system.cpp:157-167,196-197) + is_point_visible /
+// projection of the map points.  Every block derives the per-frame facts it needs (active / first frame / predicted
+// pose) from the PERSISTENT part of Ctl, which nobody writes during this kernel; block 0 additionally publishes
+// them for the rest of the chain.  The motion model's next state goes to a shadow (mm_next) committed by k_track_mid.
 // =================================================================================================
-__global__ __launch_bounds__(256) void k_project(Seq *seqs, int mode, int par) {
+__device__ __forceinline__ void frame_prologue(Seq &S, Ctl &c, int par, const Pose &predicted, const double mm_next[14], bool active,
+                                               bool first) {
+    for (int i = 0; i < N_COUNTS; i++) c.counts[i] = 0;
+    c.counts[C_FRAME] = c.frame_number;
+    c.frame_number++;
+    c.active = active ? 1 : 0;
+    c.first_frame = first ? 1 : 0;
+    c.do_pass2 = 0;
+    c.n_pass1 = c.n_pass2 = 0;
+    c.n_matches = 0;
+    c.lost_now = 0;
+    c.need_tri = 0;
+    c.dont_stage = 0;
+    c.n_pairs = 0;
+    c.mm_pending = 0;
+    const FeatCtl &fc = *S.fb[par].fc;
+    c.overflow = fc.overflow;
+    c.counts[C_RETRY_LEFT] = fc.retry[0];
+    c.counts[C_RETRY_RIGHT] = fc.retry[1];
+    if (!active) {  // LOST: return the last pose forever (lvt_system.cpp:161-166)
+        pose_to_Rt(c.last_pose, c.out_R, c.out_t);
+        c.out_status = 3;
+        return;
+    }
+    if (!first) {  // lvt_system.cpp:197 -> lvt_motion_model.cpp:42-65
+        c.predicted = predicted;
+        for (int k = 0; k < 14; k++) c.mm_next[k] = mm_next[k];
+        c.mm_pending = 1;
+    }
+}
+
+__global__ __launch_bounds__(256) void k_project(Seq *seqs, int par) {
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
-    if (!ctl.active || ctl.first_frame) return;
-    if (mode == MODE_STAGED && (ctl.lost_now || S.prm.staged_th <= 0)) return;
+    const int state = ctl.state;  // persistent; not written by this kernel
+    const bool active = (state != 3), first = (state == 1);
     __shared__ double w2c[12];
-    if (threadIdx.x == 0) world_to_camera(mode == MODE_MAP ? ctl.predicted : ctl.optimized, w2c);
+    if (threadIdx.x == 0) {
+        Pose predicted;
+        double mmn[14];
+        if (active && !first) {
+            motion_predict(ctl, ctl.last_pose, predicted, mmn);
+            world_to_camera(predicted, w2c);
+        }
+        if (blockIdx.x == 0) frame_prologue(S, ctl, par, predicted, mmn, active, first);
+    }
+    if (!active || first) return;
     __syncthreads();
-    const int cur = (mode == MODE_MAP) ? *S.map_cur : *S.staged_cur;
-    const int M = (mode == MODE_MAP) ? *S.map_n : *S.staged_n;
-    MapSoA &P = (mode == MODE_MAP) ? S.map[cur] : S.staged[cur];
-    float *proj = (mode == MODE_MAP) ? S.proj : S.sproj;
-    int8_t *vis = (mode == MODE_MAP) ? S.vis : S.svis;
-    if (mode == MODE_MAP && blockIdx.x == 0 && threadIdx.x == 0) ctl.counts[C_MAP_SIZE_AT_MATCH] = M;
+    const int M = *S.map_n;
+    MapSoA &P = S.map[*S.map_cur];
+    if (blockIdx.x == 0 && threadIdx.x == 0) ctl.counts[C_MAP_SIZE_AT_MATCH] = M;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
         const double X[3] = {P.pos[3 * i], P.pos[3 * i + 1], P.pos[3 * i + 2]};
         double u, v;
         if (is_point_visible(X, w2c, S.prm, u, v)) {
-            proj[2 * i] = (float)u;
-            proj[2 * i + 1] = (float)v;
-            vis[i] = 1;
-            if (mode == MODE_MAP) S.match[i] = -1;
+            S.proj[2 * i] = (float)u;
+            S.proj[2 * i + 1] = (float)v;
+            S.vis[i] = 1;
+            S.match[i] = -1;
         } else {
-            vis[i] = 0;
-            if (mode == MODE_MAP) {
-                P.counter[i] += 1;  // lvt_local_map.cpp:154
-                S.match[i] = -2;
-            }
+            S.vis[i] = 0;
+            P.counter[i] += 1;  // lvt_local_map.cpp:154
+            S.match[i] = -2;
         }
     }
+}
+
+// staged points are projected with the optimised pose in the tail of k_pnp
+__device__ __forceinline__ void project_staged(Seq &S, const Pose &pose, double *w2c_lds) {
+    if (threadIdx.x == 0) world_to_camera(pose, w2c_lds);
+    __syncthreads();
+    const int M = *S.staged_n;
+    const MapSoA &P = S.staged[*S.staged_cur];
+    for (int i = threadIdx.x; i < M; i += blockDim.x) {
+        const double X[3] = {P.pos[3 * i], P.pos[3 * i + 1], P.pos[3 * i + 2]};
+        double u, v;
+        if (is_point_visible(X, w2c_lds, S.prm, u, v)) {
+            S.sproj[2 * i] = (float)u;
+            S.sproj[2 * i + 1] = (float)v;
+            S.svis[i] = 1;
+        } else
+            S.svis[i] = 0;
+    }
+}
+
+// map SoA copy helper
+__device__ __forceinline__ void copy_point(const MapSoA &src, int i, MapSoA &dst, int o) {
+    dst.pos[3 * o] = src.pos[3 * i];
+    dst.pos[3 * o + 1] = src.pos[3 * i + 1];
+    dst.pos[3 * o + 2] = src.pos[3 * i + 2];
+#pragma unroll
+    for (int k = 0; k < 4; k++) dst.desc[(size_t)o * 4 + k] = src.desc[(size_t)i * 4 + k];
+    dst.counter[o] = src.counter[i];
+    dst.age[o] = src.age[i];
+    dst.match_idx[o] = src.match_idx[i];
 }
 
 // =================================================================================================
@@ -116,6 +184,9 @@ __global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2, int pa
     if (MODE == MODE_ROW && (!ctl.need_tri || ctl.lost_now || S.prm.sensor != 1)) return;
 
     __shared__ uint32_t lbuf[4][KC];
+    // train-side predicate data staged once per block: x, y (f32) and the packed hash cell (cy << 16 | cx)
+    __shared__ float s_tx[NF_MAX], s_ty[NF_MAX];
+    __shared__ uint32_t s_tc[NF_MAX];
     const int lane = lane_id(), wv = wave_id();
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const Feat &T = (MODE == MODE_ROW) ? S.fb[par].feat[1] : S.fb[par].feat[0];
@@ -140,6 +211,13 @@ __global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2, int pa
         cand = S.rcand;
         ncand = S.rncand;
     }
+    if ((int)blockIdx.x * 4 >= M) return;  // no query for this block
+    for (int j = threadIdx.x; j < N; j += 256) {
+        s_tx[j] = T.x[j];
+        s_ty[j] = T.y[j];
+        if (MODE != MODE_ROW) s_tc[j] = ((uint32_t)(uint16_t)T.hcy[j] << 16) | (uint32_t)(uint16_t)T.hcx[j];
+    }
+    __syncthreads();
     const int radius = S.prm.tracking_radius * ((MODE == MODE_MAP && pass2) ? 2 : 1);
     uint32_t *buf = lbuf[wv];
     for (int i = blockIdx.x * 4 + wv; i < M; i += gridDim.x * 4) {
@@ -168,7 +246,20 @@ __global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2, int pa
         int cnt = 0;
         for (int base = 0; base < N; base += 64) {
             const int j = base + lane;
-            const bool ok = (j < N) && cand_pred<MODE>(q, T, j);
+            bool ok = false;
+            if (j < N) {
+                if (MODE == MODE_ROW) {
+                    const float fy = s_ty[j];
+                    ok = fy >= (float)q.sy && fy <= (float)q.ey;
+                } else {
+                    const uint32_t c = s_tc[j];
+                    const int cy = (int)(int16_t)(c >> 16), cx = (int)(int16_t)(c & 0xFFFFu);
+                    if (cy >= q.sy && cy < q.ey && cx >= q.sx && cx < q.ex) {
+                        const float dx = s_tx[j] - q.x, dy = s_ty[j] - q.y;
+                        ok = (dx * dx + dy * dy) < q.r2;
+                    }
+                }
+            }
             uint32_t key = 0;
             if (ok) {
                 uint64_t t[4];
@@ -408,16 +499,7 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
     L.flag = r_flag, L.tab0 = r_tab, L.tab1 = r_tab + NF_MAX, L.lists = r_lists, L.scan = r_scan, L.misc = r_misc;
 
 template <int MODE>
-__global__ __launch_bounds__(RES_THREADS) void k_resolve(Seq *seqs, int pass2, int par) {
-    Seq &S = seqs[blockIdx.z];
-    Ctl &ctl = *S.ctl;
-    if (!ctl.active) return;
-    if (MODE == MODE_MAP) {
-        if (ctl.first_frame) return;
-        if (pass2 && !ctl.do_pass2) return;
-    }
-    if (MODE == MODE_ROW && (!ctl.need_tri || ctl.lost_now || S.prm.sensor != 1)) return;
-    RESOLVE_LDS_DECL
+__device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int par, ResolveLds &L, uint32_t *r_tab) {
     const int tid = threadIdx.x;
     const Feat &T = (MODE == MODE_ROW) ? S.fb[par].feat[1] : S.fb[par].feat[0];
     const int N = *T.n;
@@ -516,20 +598,27 @@ __global__ __launch_bounds__(RES_THREADS) void k_resolve(Seq *seqs, int pass2, i
     }
 }
 
-// =================================================================================================
-// k_bookkeep : lvt_local_map.cpp:201-224 + lvt_system.cpp:266-274
-// =================================================================================================
-__global__ __launch_bounds__(1024) void k_bookkeep(Seq *seqs, int par) {
+template <int MODE>
+__global__ __launch_bounds__(RES_THREADS) void k_resolve(Seq *seqs, int pass2, int par) {
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
-    if (!ctl.active || ctl.first_frame) return;
-    __shared__ int scan[32];
+    if (!ctl.active) return;
+    if (MODE == MODE_MAP && ctl.first_frame) return;
+    if (MODE == MODE_ROW && (!ctl.need_tri || ctl.lost_now || S.prm.sensor != 1)) return;
+    RESOLVE_LDS_DECL
+    resolve_body<MODE>(S, ctl, pass2, par, L, r_tab);
+}
+
+// =================================================================================================
+// bookkeeping of find_matches + LOST decision : lvt_local_map.cpp:201-224 + lvt_system.cpp:266-274
+// =================================================================================================
+__device__ __forceinline__ void bookkeep_body(Seq &S, Ctl &ctl, int par, int *scan) {
     const int tid = threadIdx.x;
     const int M = *S.map_n;
     MapSoA &P = S.map[*S.map_cur];
     const Feat &F = S.fb[par].feat[0];
     int n_out = 0;
-    for (int base = 0; base < M; base += 1024) {
+    for (int base = 0; base < M; base += RES_THREADS) {
         const int i = base + tid;
         int m = -2;
         if (i < M) {
@@ -565,6 +654,58 @@ __global__ __launch_bounds__(1024) void k_bookkeep(Seq *seqs, int par) {
             ctl.last_matches[2] = n_out;
         }
     }
+}
+
+// clean_untracked_points (lvt_local_map.cpp:393-413): stable compaction into the other buffer.  It does not depend
+// on the pose, so it runs here, ahead of the pose refinement (the reference runs it right after).
+__device__ __forceinline__ void cull_body(Seq &S, Ctl &ctl, int par, int *scan) {
+    const int tid = threadIdx.x;
+    const int cur = *S.map_cur, M = *S.map_n;
+    MapSoA &A = S.map[cur], &B = S.map[cur ^ 1];
+    const int th = S.prm.untracked_th;
+    int n_out = 0;
+    for (int base = 0; base < M; base += RES_THREADS) {
+        const int i = base + tid;
+        bool keep = false;
+        if (i < M) {
+            keep = A.counter[i] < th;
+            if (!keep && A.match_idx[i] >= 0) S.fb[par].feat[0].flag[A.match_idx[i]] = 0;  // :402-405
+        }
+        int total;
+        const int off = n_out + block_excl_scan(keep ? 1 : 0, scan, &total);
+        if (keep) copy_point(A, i, B, off);
+        n_out += total;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        ctl.counts[C_N_CULLED] = M - n_out;
+        *S.map_cur = cur ^ 1;
+        *S.map_n = n_out;
+    }
+}
+
+// =================================================================================================
+// k_track_mid : [find_matches second pass, if pass 1 found < 50] + bookkeeping + LOST decision + cull
+// =================================================================================================
+__global__ __launch_bounds__(RES_THREADS) void k_track_mid(Seq *seqs, int par) {
+    Seq &S = seqs[blockIdx.z];
+    Ctl &ctl = *S.ctl;
+    if (!ctl.active) return;
+    if (threadIdx.x == 0 && ctl.mm_pending) {  // commit the motion model state shadowed by k_project
+        for (int k = 0; k < 4; k++) ctl.mm_last_q[k] = ctl.mm_next[k], ctl.mm_ang_vel[k] = ctl.mm_next[4 + k];
+        for (int k = 0; k < 3; k++) ctl.mm_last_p[k] = ctl.mm_next[8 + k], ctl.mm_lin_vel[k] = ctl.mm_next[11 + k];
+        ctl.mm_pending = 0;
+    }
+    if (ctl.first_frame) return;
+    RESOLVE_LDS_DECL
+    if (ctl.do_pass2) {
+        resolve_body<MODE_MAP>(S, ctl, 1, par, L, r_tab);
+        __syncthreads();
+    }
+    bookkeep_body(S, ctl, par, L.scan);
+    __syncthreads();
+    if (ctl.lost_now) return;
+    cull_body(S, ctl, par, L.scan);
 }
 
 // =================================================================================================
@@ -912,6 +1053,8 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs, int par) {
         ctl.counts[C_PNP_ITERS] = calls;
         ctl.counts[C_PNP_INLIERS] = inliers;
     }
+    // update_staged_map_points projects the staged points with the optimised pose (lvt_local_map.cpp:357-368)
+    if (S.prm.staged_th > 0) project_staged(S, res, red);
 }
 
 // stand-alone entry for differential tests (lvt_amd_pnp)
@@ -928,53 +1071,6 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp_standalone(Params prm, Pose
         *out = res;
         info[0] = calls;
         info[1] = inliers;
-    }
-}
-
-// =================================================================================================
-// map SoA copy helper
-// =================================================================================================
-__device__ __forceinline__ void copy_point(const MapSoA &src, int i, MapSoA &dst, int o) {
-    dst.pos[3 * o] = src.pos[3 * i];
-    dst.pos[3 * o + 1] = src.pos[3 * i + 1];
-    dst.pos[3 * o + 2] = src.pos[3 * i + 2];
-#pragma unroll
-    for (int k = 0; k < 4; k++) dst.desc[(size_t)o * 4 + k] = src.desc[(size_t)i * 4 + k];
-    dst.counter[o] = src.counter[i];
-    dst.age[o] = src.age[i];
-    dst.match_idx[o] = src.match_idx[i];
-}
-
-// =================================================================================================
-// k_cull : clean_untracked_points (lvt_local_map.cpp:393-413), stable compaction into the other buffer
-// =================================================================================================
-__global__ __launch_bounds__(1024) void k_cull(Seq *seqs, int par) {
-    Seq &S = seqs[blockIdx.z];
-    Ctl &ctl = *S.ctl;
-    if (!ctl.active || ctl.first_frame || ctl.lost_now) return;
-    __shared__ int scan[32];
-    const int tid = threadIdx.x;
-    const int cur = *S.map_cur, M = *S.map_n;
-    MapSoA &A = S.map[cur], &B = S.map[cur ^ 1];
-    const int th = S.prm.untracked_th;
-    int n_out = 0;
-    for (int base = 0; base < M; base += 1024) {
-        const int i = base + tid;
-        bool keep = false;
-        if (i < M) {
-            keep = A.counter[i] < th;
-            if (!keep && A.match_idx[i] >= 0) S.fb[par].feat[0].flag[A.match_idx[i]] = 0;  // :402-405
-        }
-        int total;
-        const int off = n_out + block_excl_scan(keep ? 1 : 0, scan, &total);
-        if (keep) copy_point(A, i, B, off);
-        n_out += total;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        ctl.counts[C_N_CULLED] = M - n_out;
-        *S.map_cur = cur ^ 1;
-        *S.map_n = n_out;
     }
 }
 
@@ -1186,11 +1282,12 @@ __device__ bool triangulate_pair(const Params &p, const double *cml, const doubl
 __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par) {
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
-    if (!ctl.active || ctl.lost_now || !ctl.need_tri) return;
     __shared__ double cml[12], cmr[12], R[9];
     __shared__ Pose cam;
     __shared__ int scan[32];
     const int tid = threadIdx.x;
+    const bool run = ctl.active && !ctl.lost_now && ctl.need_tri;  // block-uniform
+    if (run) {
     if (tid == 0) {
         if (ctl.first_frame) {
             cam.q[0] = 1, cam.q[1] = cam.q[2] = cam.q[3] = 0;
@@ -1260,30 +1357,26 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par) {
         ctl.counts[C_TRIANGULATED] = 1;
         ctl.counts[C_N_TRIANGULATED] = n_out;
     }
-}
-
-// =================================================================================================
-// k_finalize
-// =================================================================================================
-__global__ void k_finalize(Seq *seqs, int par) {
-    Seq &S = seqs[blockIdx.x];
-    if (threadIdx.x != 0) return;
-    Ctl &ctl = *S.ctl;
-    if (ctl.active && ctl.first_frame) {  // lvt_system.cpp:185-193
-        ctl.state = 2;
-        ctl.last_matches[0] = *S.map_n;
-        Pose id;
-        id.q[0] = 1, id.q[1] = id.q[2] = id.q[3] = 0;
-        id.p[0] = id.p[1] = id.p[2] = 0;
-        pose_to_Rt(id, ctl.out_R, ctl.out_t);
-        ctl.out_status = 2;
+    }  // run
+    __syncthreads();
+    // ---- epilogue of the frame (first-frame bookkeeping of lvt_system.cpp:185-193, result record)
+    if (tid == 0) {
+        if (ctl.active && ctl.first_frame) {
+            ctl.state = 2;
+            ctl.last_matches[0] = *S.map_n;
+            Pose id;
+            id.q[0] = 1, id.q[1] = id.q[2] = id.q[3] = 0;
+            id.p[0] = id.p[1] = id.p[2] = 0;
+            pose_to_Rt(id, ctl.out_R, ctl.out_t);
+            ctl.out_status = 2;
+        }
+        ctl.counts[C_N_LEFT] = *S.fb[par].feat[0].n;
+        ctl.counts[C_N_RIGHT] = *S.fb[par].feat[1].n;
+        ctl.counts[C_MAP_SIZE] = *S.map_n;
+        ctl.counts[C_STAGED_SIZE] = *S.staged_n;
+        ctl.overflow |= S.fb[par].fc->overflow;
+        ctl.counts[C_OVERFLOW] = ctl.overflow;
     }
-    ctl.counts[C_N_LEFT] = *S.fb[par].feat[0].n;
-    ctl.counts[C_N_RIGHT] = *S.fb[par].feat[1].n;
-    ctl.counts[C_MAP_SIZE] = *S.map_n;
-    ctl.counts[C_STAGED_SIZE] = *S.staged_n;
-    ctl.overflow |= S.fb[par].fc->overflow;
-    ctl.counts[C_OVERFLOW] = ctl.overflow;
 }
 
 // explicit instantiations used by the host

@@ -66,6 +66,8 @@ struct Ctl {
     int last_matches[3];
     Pose last_pose;
     double mm_last_q[4], mm_ang_vel[4], mm_last_p[3], mm_lin_vel[3];
+    double mm_next[14];  // motion-model state after this frame's prediction; committed by k_track_mid (k_project only reads mm_*)
+    int mm_pending;
     // per-frame control, written by k_begin / later kernels
     int active;         // 0: LOST at frame start -> every kernel exits
     int first_frame;    // state was NOT_INITIALIZED at frame start

@@ -389,9 +389,9 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
 
 // ---- the per-frame launch chain -------------------------------------------------------------------
 static const char *kProfNames[Context::PROF_SLOTS] = {
-    "k_feat_begin", "k_begin", "k_score", "k_cells(pass0)", "k_cells(retry)", "k_gather", "k_brief", "k_project(map)",
-    "k_candidates(map)", "k_resolve(map)", "k_candidates(map,pass2)", "k_resolve(map,pass2)", "k_bookkeep", "k_pnp", "k_cull",
-    "k_project(staged)", "k_candidates(staged)", "k_staged", "k_candidates(row)", "k_resolve(row)", "k_triangulate", "k_finalize",
+    "k_feat_begin", "", "k_score", "k_cells(pass0)", "k_cells(retry)", "k_gather", "k_brief", "k_project(begin+map)",
+    "k_candidates(map)", "k_resolve(map)", "k_candidates(map,pass2)", "", "k_track_mid(pass2+bookkeep+cull)", "k_pnp(+project staged)", "",
+    "", "k_candidates(staged)", "k_staged", "k_candidates(row)", "k_resolve(row)", "k_triangulate(+finalize)", "",
     "", ""};
 
 #define LAUNCH(slot, st, kern, grid, block, lds, ...)                              \
@@ -429,22 +429,17 @@ static void enqueue_frame(Context *c) {
     (void)hipEventRecord(c->ev_feat[par], sf);
     // ---- tracking chain (stream): strictly ordered frame after frame
     (void)hipStreamWaitEvent(st, c->ev_feat[par], 0);
-    LAUNCH(1, st, k_begin, dim3(B), dim3(64), 0, S, par);
-    LAUNCH(7, st, k_project, dim3(32, 1, B), dim3(256), 0, S, (int)MODE_MAP, par);
+    LAUNCH(7, st, k_project, dim3(32, 1, B), dim3(256), 0, S, par);
     LAUNCH(8, st, k_candidates<MODE_MAP>, dim3(256, 1, B), dim3(256), 0, S, 0, par);
     LAUNCH(9, st, k_resolve<MODE_MAP>, dim3(1, 1, B), dim3(RES_THREADS), 0, S, 0, par);
     LAUNCH(10, st, k_candidates<MODE_MAP>, dim3(256, 1, B), dim3(256), 0, S, 1, par);
-    LAUNCH(11, st, k_resolve<MODE_MAP>, dim3(1, 1, B), dim3(RES_THREADS), 0, S, 1, par);
-    LAUNCH(12, st, k_bookkeep, dim3(1, 1, B), dim3(1024), 0, S, par);
+    LAUNCH(12, st, k_track_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par);
     LAUNCH(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), 0, S, par);
-    LAUNCH(14, st, k_cull, dim3(1, 1, B), dim3(1024), 0, S, par);
-    LAUNCH(15, st, k_project, dim3(32, 1, B), dim3(256), 0, S, (int)MODE_STAGED, par);
     LAUNCH(16, st, k_candidates<MODE_STAGED>, dim3(64, 1, B), dim3(256), 0, S, 0, par);
     LAUNCH(17, st, k_staged, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par);
     LAUNCH(18, st, k_candidates<MODE_ROW>, dim3(256, 1, B), dim3(256), 0, S, 0, par);
     LAUNCH(19, st, k_resolve<MODE_ROW>, dim3(1, 1, B), dim3(RES_THREADS), 0, S, 0, par);
     LAUNCH(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, S, par);
-    LAUNCH(21, st, k_finalize, dim3(B), dim3(64), 0, S, par);
     for (int s = 0; s < B; s++)
         (void)hipMemcpyAsync(&c->h_ctl[(size_t)slot * B + s], c->d_ctl[s], sizeof(Ctl), hipMemcpyDeviceToHost, st);
     (void)hipEventRecord(c->ev_track[par], st);

@@ -84,8 +84,9 @@ __host__ __device__ inline void undistort_point(const Params &p, float x_in, flo
     y_out = (float)(y * fy + cy);
 }
 
-// lvt_motion_model.cpp:42-65 (Eigen 3.3 slerp / inverse / normalize semantics)
-__device__ inline void motion_predict(Ctl &c, const Pose &cur, Pose &out) {
+// lvt_motion_model.cpp:42-65 (Eigen 3.3 slerp / inverse / normalize semantics).  PURE: reads the model state from
+// `c`, returns the predicted pose and the model's next state {last_q[4], ang_vel[4], last_p[3], lin_vel[3]}.
+__device__ inline void motion_predict(const Ctl &c, const Pose &cur, Pose &out, double next[14]) {
     double nv[3];
     for (int k = 0; k < 3; k++) nv[k] = ((cur.p[k] - c.mm_last_p[k]) + c.mm_lin_vel[k]) * 0.5;
     double inv[4];
@@ -121,13 +122,13 @@ __device__ inline void motion_predict(Ctl &c, const Pose &cur, Pose &out) {
     }
     q_normalize(nav);
     for (int k = 0; k < 4; k++) {
-        c.mm_last_q[k] = cur.q[k];
-        c.mm_ang_vel[k] = nav[k];
+        next[k] = cur.q[k];
+        next[4 + k] = nav[k];
     }
     for (int k = 0; k < 3; k++) {
-        c.mm_last_p[k] = cur.p[k];
-        c.mm_lin_vel[k] = nv[k];
-        out.p[k] = c.mm_last_p[k] + c.mm_lin_vel[k];
+        next[8 + k] = cur.p[k];
+        next[11 + k] = nv[k];
+        out.p[k] = cur.p[k] + nv[k];
     }
     q_mul(cur.q, nav, out.q);
     q_normalize(out.q);

@@ -402,44 +402,52 @@ __device__ __forceinline__ int decide_query_slow(const Seq &S, const Feat &T, in
 
 // One super-chunk starting at query b0.  nfn(q) = candidate count of query q (0 = nothing to decide).
 // Returns the number of queries consumed (>= 1), or -1 when query b0 itself overflows KC (caller: slow path).
-// acc[u] = accepted feature (or -1) of local query 2*tid+u; marks in L.flag are updated.
+// Thread t owns local queries t and t + RES_THREADS; acc[u] = accepted feature (or -1).  Marks: a matched feature
+// carries the permanent stamp PERM in BOTH claim tables (one LDS read per candidate tells "marked or claimed");
+// L.flag mirrors them for the write-back.
+constexpr uint32_t PERM = 0xFFFFFFFFu;
+
 template <class NFn>
 __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint32_t *cand, ResolveLds &L, uint32_t &iter, float ratio,
                                              float desc_th, int acc[2]) {
     const int tid = threadIdx.x;
     int n[2], off[2];
-    const int lq0 = 2 * tid;
     if (tid == 0) L.misc[0] = QCAP;
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 2; u++) {
-        const int q = b0 + lq0 + u;
+        const int lq = tid + u * RES_THREADS, q = b0 + lq;
         n[u] = (q < M) ? nfn(q) : 0;
-        if (n[u] > KC) atomicMin(&L.misc[0], lq0 + u);
+        if (n[u] > KC) atomicMin(&L.misc[0], lq);
     }
     __syncthreads();
     int limit = min(min(QCAP, M - b0), L.misc[0]);
     if (limit == 0) return -1;
 #pragma unroll
     for (int u = 0; u < 2; u++)
-        if (lq0 + u >= limit) n[u] = 0;
-    int total;
-    const int ex = block_excl_scan(n[0] + n[1], L.scan, &total);
-    off[0] = ex;
-    off[1] = ex + n[0];
-    if (total > LCAP) {  // keep the longest prefix of queries whose lists fit
-        int fit = ((lq0 < limit && off[0] + n[0] <= LCAP) ? 1 : 0) + ((lq0 + 1 < limit && off[1] + n[1] <= LCAP) ? 1 : 0);
-        int nfit;
-        block_excl_scan(fit, L.scan, &nfit);
-        limit = nfit;
+        if (tid + u * RES_THREADS >= limit) n[u] = 0;
+    int t0, t1;
+    off[0] = block_excl_scan(n[0], L.scan, &t0);
+    if (limit > RES_THREADS) {
+        off[1] = t0 + block_excl_scan(n[1], L.scan, &t1);
+    } else {
+        off[1] = t0;
+        t1 = 0;
+    }
+    if (t0 + t1 > LCAP) {  // keep the longest prefix of queries whose lists fit
+        int f0 = (tid < limit && off[0] + n[0] <= LCAP) ? 1 : 0, f1 = (tid + RES_THREADS < limit && off[1] + n[1] <= LCAP) ? 1 : 0;
+        int c0, c1;
+        block_excl_scan(f0, L.scan, &c0);
+        block_excl_scan(f1, L.scan, &c1);
+        limit = (c0 < min(limit, RES_THREADS)) ? c0 : c0 + c1;   // fits are a prefix in query order
 #pragma unroll
         for (int u = 0; u < 2; u++)
-            if (lq0 + u >= limit) n[u] = 0;
+            if (tid + u * RES_THREADS >= limit) n[u] = 0;
     }
     // pack the lists into LDS (independent loads, 8 in flight per query)
 #pragma unroll
     for (int u = 0; u < 2; u++) {
-        const uint32_t *src = cand + (size_t)(b0 + lq0 + u) * KC;
+        const uint32_t *src = cand + (size_t)(b0 + tid + u * RES_THREADS) * KC;
         for (int e0 = 0; e0 < n[u]; e0 += 8) {
             uint32_t v[8];
 #pragma unroll
@@ -452,6 +460,8 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
     __syncthreads();
     int prev[2] = {-2, -2};
     acc[0] = acc[1] = -1;
+    const long long tj0 = clock64();
+    const uint32_t it0 = iter;
     while (true) {
         iter++;
         const uint32_t *rd = (iter & 1u) ? L.tab0 : L.tab1;  // written during iteration iter-1
@@ -460,19 +470,28 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
 #pragma unroll
         for (int u = 0; u < 2; u++) {
             if (n[u] == 0) continue;
-            const int lq = lq0 + u;
+            const int lq = tid + u * RES_THREADS;
             const uint32_t *list = L.lists + off[u];
             uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
             int cnt = 0;
-            for (int e = 0; e < n[u]; e++) {
-                const uint32_t c = list[e];
-                const uint32_t f = c & 0xFFFFu;
-                if (L.flag[f]) continue;
-                const uint32_t v = rd[f];
-                if ((v >> 11) == iter - 1u && (int)(2047u - (v & 2047u)) < lq) continue;  // taken by an earlier query
-                if (cnt == 0) k1 = c;
-                else k2 = c;
-                if (++cnt == 2) break;
+            // 4 candidates per step: the 4 list reads and then the 4 claim reads are independent, so their LDS latencies
+            // overlap; evaluation stays in list order
+            for (int e = 0; e < n[u] && cnt < 2; e += 4) {
+                uint32_t c[4], v[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) c[k] = list[min(e + k, n[u] - 1)];
+#pragma unroll
+                for (int k = 0; k < 4; k++) v[k] = rd[c[k] & 0xFFFFu];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    // unavailable: marked (PERM), or accepted in iteration iter-1 by an earlier query
+                    const bool un = (v[k] == PERM) || ((v[k] >> 11) == iter - 1u && (int)(2047u - (v[k] & 2047u)) < lq);
+                    if (e + k < n[u] && !un && cnt < 2) {
+                        if (cnt == 0) k1 = c[k];
+                        else k2 = c[k];
+                        cnt++;
+                    }
+                }
             }
             const bool ok = accept_match(cnt, k1, k2, ratio, desc_th);
             acc[u] = ok ? (int)(k1 & 0xFFFFu) : -1;
@@ -482,9 +501,17 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
         }
         if (!__syncthreads_or(changed ? 1 : 0)) break;
     }
+    if (threadIdx.x == 0) {
+        L.misc[4] = (int)(iter - it0);
+        L.misc[5] = (int)(clock64() - tj0);
+    }
 #pragma unroll
     for (int u = 0; u < 2; u++)
-        if (acc[u] >= 0) L.flag[acc[u]] = 1;
+        if (acc[u] >= 0) {
+            L.flag[acc[u]] = 1;
+            L.tab0[acc[u]] = PERM;
+            L.tab1[acc[u]] = PERM;
+        }
     __syncthreads();
     return limit;
 }
@@ -501,11 +528,15 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
 template <int MODE>
 __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int par, ResolveLds &L, uint32_t *r_tab) {
     const int tid = threadIdx.x;
+    const long long tk0 = clock64();
     const Feat &T = (MODE == MODE_ROW) ? S.fb[par].feat[1] : S.fb[par].feat[0];
     const int N = *T.n;
     // find_matches pass 2 starts from cleared marks (lvt_local_map.cpp:176)
-    for (int j = tid; j < N; j += RES_THREADS) L.flag[j] = (MODE == MODE_MAP && pass2) ? 0 : T.flag[j];
-    for (int j = tid; j < 2 * NF_MAX; j += RES_THREADS) r_tab[j] = 0;
+    for (int j = tid; j < NF_MAX; j += RES_THREADS) {
+        const uint8_t f = (j < N && !(MODE == MODE_MAP && pass2)) ? T.flag[j] : 0;
+        if (j < N) L.flag[j] = f;
+        r_tab[j] = r_tab[NF_MAX + j] = f ? PERM : 0u;
+    }
     int M;
     const uint64_t *qdesc;
     const uint32_t *cand;
@@ -540,6 +571,7 @@ __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int pa
                     if (MODE == MODE_MAP) S.match[b0] = idx;
                     if (idx >= 0) {
                         L.flag[idx] = 1;
+                        L.tab0[idx] = L.tab1[idx] = PERM;
                         if (MODE == MODE_ROW) {
                             S.pair_l[accepted] = b0;
                             S.pair_r[accepted] = idx;
@@ -555,19 +587,21 @@ __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int pa
             b0 += 1;
             continue;
         }
-        // results, in query order
-        const int lq0 = 2 * tid;
-        const int a0 = (lq0 < used && acc[0] >= 0) ? 1 : 0, a1 = (lq0 + 1 < used && acc[1] >= 0) ? 1 : 0;
-        int tot;
-        const int ex = block_excl_scan(a0 + a1, L.scan, &tot);
+        // results, in query order (local query = tid + u * RES_THREADS)
+        const int a0 = (tid < used && acc[0] >= 0) ? 1 : 0, a1 = (tid + RES_THREADS < used && acc[1] >= 0) ? 1 : 0;
+        int tot0, tot1 = 0;
+        const int ex0 = block_excl_scan(a0, L.scan, &tot0);
+        int ex1 = 0;
+        if (used > RES_THREADS) ex1 = block_excl_scan(a1, L.scan, &tot1);
+        const int tot = tot0 + tot1;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            const int lq = lq0 + u, q = b0 + lq;
+            const int lq = tid + u * RES_THREADS, q = b0 + lq;
             if (lq >= used) continue;
             if (MODE == MODE_MAP) {
                 if (ncand[q] > 0) S.match[q] = acc[u];  // invisible / candidate-less points keep -2 / -1 (k_project)
             } else if (acc[u] >= 0) {
-                const int slot = accepted + ex + (u ? a0 : 0);
+                const int slot = accepted + (u ? tot0 + ex1 : ex0);
                 S.pair_l[slot] = q;
                 S.pair_r[slot] = acc[u];
                 S.fb[par].feat[0].flag[q] = 1;  // handler.cpp:319
@@ -583,6 +617,9 @@ __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int pa
         for (int j = tid; j < N; j += RES_THREADS) S.fb[par].feat[0].flag[j] = L.flag[j];
         if (tid == 0) {
             if (!pass2) {
+                ctl.dbg[18] = L.misc[4];
+                ctl.dbg[19] = L.misc[5];
+                ctl.dbg[23] = clock64() - tk0;
                 ctl.n_pass1 = accepted;
                 ctl.do_pass2 = (accepted < N_MATCHES_TH) ? 1 : 0;  // lvt_local_map.cpp:173
                 ctl.counts[C_SECOND_PASS] = ctl.do_pass2;
@@ -768,25 +805,29 @@ __device__ __forceinline__ double wave_sum(double v) {
 
 constexpr int PNP_THREADS = 256;
 
-// block-wide sum of NV doubles per thread (PNP_THREADS = 256); result valid in all threads.
-// Large NV: partials go through LDS ([NV][256] doubles), wave w sums values w, w+4, ... (4 partials per lane,
-// then one 64-lane butterfly), so the number of cross-lane steps is NV*6/4 instead of NV*6 per wave.
+// block-wide sum of NV doubles per thread; result valid in all threads.
+// Large NV: partials go through LDS ([NV][PNP_THREADS] doubles), wave w sums values w, w+NW, ... (PNP_THREADS/64
+// partials per lane, then one 64-lane butterfly), interleaved so the butterfly chains overlap.
+constexpr int PNP_NW = PNP_THREADS / 64;
 template <int NV>
 __device__ __forceinline__ void block_sum(double (&v)[NV], double *red) {
     const int w = wave_id(), l = lane_id(), tid = threadIdx.x;
     if (NV >= 8) {
-        double *part = red + 128;  // [NV][256]
+        double *part = red + 128;  // [NV][PNP_THREADS]
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < NV; k++) part[k * PNP_THREADS + tid] = v[k];
         __syncthreads();
-        constexpr int PER = (NV + 3) / 4;
+        constexpr int PER = (NV + PNP_NW - 1) / PNP_NW;
         double sacc[PER];
 #pragma unroll
         for (int u = 0; u < PER; u++) {  // branch-free so the PER butterfly chains interleave
-            const int k = min(w + 4 * u, NV - 1);
+            const int k = min(w + PNP_NW * u, NV - 1);
             const double *p = part + k * PNP_THREADS;
-            sacc[u] = (p[l] + p[l + 64]) + (p[l + 128] + p[l + 192]);
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < PNP_NW; m++) s += p[l + 64 * m];
+            sacc[u] = s;
         }
 #pragma unroll
         for (int d = 32; d >= 1; d >>= 1) {
@@ -795,7 +836,7 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red) {
         }
 #pragma unroll
         for (int u = 0; u < PER; u++)
-            if (l == 0 && w + 4 * u < NV) red[w + 4 * u] = sacc[u];
+            if (l == 0 && w + PNP_NW * u < NV) red[w + PNP_NW * u] = sacc[u];
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < NV; k++) v[k] = red[k];
@@ -809,19 +850,97 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red) {
         }
         __syncthreads();
 #pragma unroll
-        for (int k = 0; k < NV; k++) v[k] = ((red[k] + red[NV + k]) + red[2 * NV + k]) + red[3 * NV + k];
+        for (int k = 0; k < NV; k++) {
+            double s = 0.0;
+#pragma unroll
+            for (int m = 0; m < PNP_NW; m++) s += red[m * NV + k];
+            v[k] = s;
+        }
     }
 }
 
 struct PnpShared {
     double r[4], t[3];   // current estimate, published by thread 0
-    int cont, ok;
+    int cont, ok, accepted;
 };
 
+// One sweep over the active edges at the camera `cam`: errors (stored), robust chi2 partial in acc[27], and -- when
+// WANT_H -- the edge's contribution to H (upper triangle, acc[0..20]) and b (acc[21..26]) linearised at the same
+// estimate (EdgeProjectP2MC::computeError / linearizeOplus / constructQuadraticForm with the Cauchy weight, A.6).
+template <bool WANT_H>
+__device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3], double fx, double fy, double dsqr, double dsqrReci,
+                                          const double *X, const float *obs, double *err, const int8_t *level, int n, double (&acc)[28]) {
+#pragma unroll
+    for (int k = 0; k < 28; k++) acc[k] = 0.0;
+    for (int i = threadIdx.x; i < n; i += PNP_THREADS) {
+        if (level[i] != 0) continue;
+        const double x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2];
+        const double *c = cam.w2i;
+        const double px = ((c[0] * x + c[1] * y) + c[2] * z) + c[3];
+        const double py = ((c[4] * x + c[5] * y) + c[6] * z) + c[7];
+        const double pz = ((c[8] * x + c[9] * y) + c[10] * z) + c[11];
+        const double e0 = px / pz - (double)obs[2 * i], e1 = py / pz - (double)obs[2 * i + 1];
+        err[2 * i] = e0;
+        err[2 * i + 1] = e1;
+        const double aux = dsqrReci * (e0 * e0 + e1 * e1) + 1.0;
+        acc[27] += dsqr * log(aux);
+        if (WANT_H) {
+            const double *w = cam.w2n;
+            const double pcx = ((w[0] * x + w[1] * y) + w[2] * z) + w[3];
+            const double pcy = ((w[4] * x + w[5] * y) + w[6] * z) + w[7];
+            const double pcz = ((w[8] * x + w[9] * y) + w[10] * z) + w[11];
+            const double ipz2 = 1.0 / (pcz * pcz);
+            const double ipz2fx = ipz2 * fx, ipz2fy = ipz2 * fy;
+            const double pwt[3] = {x - ct[0], y - ct[1], z - ct[2]};
+            double J0[6], J1[6];
+            // dp = dRd{x,y,z} * pwt with dRd* = dRid* * w2n[:, :3]  
+            const double a0 = (w[0] * pwt[0] + w[1] * pwt[1]) + w[2] * pwt[2];
+            const double a1 = (w[4] * pwt[0] + w[5] * pwt[1]) + w[6] * pwt[2];
+            const double a2 = (w[8] * pwt[0] + w[9] * pwt[1]) + w[10] * pwt[2];
+            {
+                const double dp0 = 0.0, dp1 = 2.0 * a2, dp2 = -2.0 * a1;  // dRdx
+                J0[3] = (pcz * dp0 - pcx * dp2) * ipz2fx;
+                J1[3] = (pcz * dp1 - pcy * dp2) * ipz2fy;
+            }
+            {
+                const double dp0 = -2.0 * a2, dp1 = 0.0, dp2 = 2.0 * a0;  // dRdy
+                J0[4] = (pcz * dp0 - pcx * dp2) * ipz2fx;
+                J1[4] = (pcz * dp1 - pcy * dp2) * ipz2fy;
+            }
+            {
+                const double dp0 = 2.0 * a1, dp1 = -2.0 * a0, dp2 = 0.0;  // dRdz
+                J0[5] = (pcz * dp0 - pcx * dp2) * ipz2fx;
+                J1[5] = (pcz * dp1 - pcy * dp2) * ipz2fy;
+            }
+#pragma unroll
+            for (int cc = 0; cc < 3; cc++) {
+                const double dp0 = -w[cc], dp1 = -w[4 + cc], dp2 = -w[8 + cc];
+                J0[cc] = (pcz * dp0 - pcx * dp2) * ipz2fx;
+                J1[cc] = (pcz * dp1 - pcy * dp2) * ipz2fy;
+            }
+            const double rho1 = 1.0 / aux;
+            const double wr0 = -e0 * rho1, wr1 = -e1 * rho1;
+            int k = 0;
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+#pragma unroll
+                for (int cc = a; cc < 6; cc++) acc[k++] += (J0[a] * rho1) * J0[cc] + (J1[a] * rho1) * J1[cc];
+            }
+#pragma unroll
+            for (int a = 0; a < 6; a++) acc[21 + a] += J0[a] * wr0 + J1[a] * wr1;
+        }
+    }
+}
+
+// g2o's OptimizationAlgorithmLevenberg as configured by lvt_pnp_solver.cpp:44-53,60-128, one workgroup.
+// solve(i) = computeActiveErrors + buildSystem + trial loop.  The sweep that evaluates a trial's errors also
+// accumulates H and b at the trial estimate: when the trial is ACCEPTED, the next solve()'s computeActiveErrors and
+// buildSystem would recompute exactly those values (same estimate, same active edges, same arithmetic), so they are
+// reused; a rejected last trial or a new pass falls back to a fresh sweep.
 __device__ void pnp_run(const Params &prm, const Pose &prior, const double *X, const float *obs, double *err, int8_t *level,
                         int n, PnpShared &sh, double *red, Pose &result, int &inliers, int &solve_calls, long long *dbg = nullptr) {
     const int tid = threadIdx.x;
-    long long t_err = 0, t_build = 0, t_solve = 0, t_dec = 0, t_all = clock64();
+    long long t_sweep = 0, t_solve = 0, t_dec = 0, t_all = clock64();
     const double fx = prm.fx, fy = prm.fy, cx = prm.cx, cy = prm.cy;
     const double mono_chi = sqrt(REPROJ_TH2);
     const double dsqr = mono_chi * mono_chi;
@@ -846,100 +965,31 @@ __device__ void pnp_run(const Params &prm, const Pose &prior, const double *X, c
     load_cam();
     int calls = 0;
 
-    // errors of ACTIVE edges at the current estimate + robust chi2 (computeActiveErrors / activeRobustChi2)
-    auto errors_and_chi = [&]() -> double {
-        double chi[1] = {0.0};
-        for (int i = tid; i < n; i += PNP_THREADS) {
-            if (level[i] != 0) continue;
-            const double *c = cam.w2i;
-            const double x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2];
-            const double px = ((c[0] * x + c[1] * y) + c[2] * z) + c[3];
-            const double py = ((c[4] * x + c[5] * y) + c[6] * z) + c[7];
-            const double pz = ((c[8] * x + c[9] * y) + c[10] * z) + c[11];
-            const double e0 = px / pz - (double)obs[2 * i], e1 = py / pz - (double)obs[2 * i + 1];
-            err[2 * i] = e0;
-            err[2 * i + 1] = e1;
-            const double aux = dsqrReci * (e0 * e0 + e1 * e1) + 1.0;
-            chi[0] += dsqr * log(aux);
-        }
-        block_sum<1>(chi, red);
-        return chi[0];
-    };
-
     for (int pass = 0; pass < 2; pass++) {
         double na[1] = {0.0};
         for (int i = tid; i < n; i += PNP_THREADS) na[0] += (level[i] == 0) ? 1.0 : 0.0;
         block_sum<1>(na, red);
         const bool any_active = na[0] > 0.0;
-        bool ok = true;          // uniform across the block (decisions are broadcast through sh)
+        bool ok = true;             // uniform across the block (decisions are broadcast through sh)
         double lambda = 0, ni = 2;  // meaningful on thread 0
+        bool have_sys = false;      // acc[] holds chi2 / H / b at the current estimate
+        double acc[28];
         for (int iter = 0; iter < 5 && ok && any_active; iter++) {
             calls++;
             long long c0 = clock64();
-            double currentChi = errors_and_chi();
-            t_err += clock64() - c0;
-            c0 = clock64();
-            // buildSystem(): H (upper triangle, 21) and b (6)
-            double acc[27];
-#pragma unroll
-            for (int k = 0; k < 27; k++) acc[k] = 0.0;
-            for (int i = tid; i < n; i += PNP_THREADS) {
-                if (level[i] != 0) continue;
-                const double *w = cam.w2n;
-                const double x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2];
-                const double pcx = ((w[0] * x + w[1] * y) + w[2] * z) + w[3];
-                const double pcy = ((w[4] * x + w[5] * y) + w[6] * z) + w[7];
-                const double pcz = ((w[8] * x + w[9] * y) + w[10] * z) + w[11];
-                const double ipz2 = 1.0 / (pcz * pcz);
-                const double ipz2fx = ipz2 * fx, ipz2fy = ipz2 * fy;
-                const double pwt[3] = {x - ct[0], y - ct[1], z - ct[2]};
-                double J0[6], J1[6];
-                // dp = dRd{x,y,z} * pwt with dRd* = dRid* * w2n[:, :3]  
-                const double a0 = (w[0] * pwt[0] + w[1] * pwt[1]) + w[2] * pwt[2];     // row 0 of w2n . pwt
-                const double a1 = (w[4] * pwt[0] + w[5] * pwt[1]) + w[6] * pwt[2];     // row 1
-                const double a2 = (w[8] * pwt[0] + w[9] * pwt[1]) + w[10] * pwt[2];    // row 2
-                {
-                    const double dp0 = 0.0, dp1 = 2.0 * a2, dp2 = -2.0 * a1;  // dRdx
-                    J0[3] = (pcz * dp0 - pcx * dp2) * ipz2fx;
-                    J1[3] = (pcz * dp1 - pcy * dp2) * ipz2fy;
-                }
-                {
-                    const double dp0 = -2.0 * a2, dp1 = 0.0, dp2 = 2.0 * a0;  // dRdy
-                    J0[4] = (pcz * dp0 - pcx * dp2) * ipz2fx;
-                    J1[4] = (pcz * dp1 - pcy * dp2) * ipz2fy;
-                }
-                {
-                    const double dp0 = 2.0 * a1, dp1 = -2.0 * a0, dp2 = 0.0;  // dRdz
-                    J0[5] = (pcz * dp0 - pcx * dp2) * ipz2fx;
-                    J1[5] = (pcz * dp1 - pcy * dp2) * ipz2fy;
-                }
-#pragma unroll
-                for (int c = 0; c < 3; c++) {
-                    const double dp0 = -w[c], dp1 = -w[4 + c], dp2 = -w[8 + c];
-                    J0[c] = (pcz * dp0 - pcx * dp2) * ipz2fx;
-                    J1[c] = (pcz * dp1 - pcy * dp2) * ipz2fy;
-                }
-                const double e0 = err[2 * i], e1 = err[2 * i + 1];
-                const double rho1 = 1.0 / (dsqrReci * (e0 * e0 + e1 * e1) + 1.0);
-                const double wr0 = -e0 * rho1, wr1 = -e1 * rho1;
-                int k = 0;
-#pragma unroll
-                for (int a = 0; a < 6; a++) {
-#pragma unroll
-                    for (int c = a; c < 6; c++) acc[k++] += (J0[a] * rho1) * J0[c] + (J1[a] * rho1) * J1[c];
-                }
-#pragma unroll
-                for (int a = 0; a < 6; a++) acc[21 + a] += J0[a] * wr0 + J1[a] * wr1;
+            if (!have_sys) {
+                pnp_sweep<true>(cam, ct, fx, fy, dsqr, dsqrReci, X, obs, err, level, n, acc);
+                block_sum<28>(acc, red);
             }
-            block_sum<27>(acc, red);
-            t_build += clock64() - c0;
+            t_sweep += clock64() - c0;
+            double currentChi = acc[27];
             double H[36], bb[6], dx[6];
             if (tid == 0) {
                 int k = 0;
                 for (int a = 0; a < 6; a++)
-                    for (int c = a; c < 6; c++) {
-                        H[6 * a + c] = acc[k];
-                        H[6 * c + a] = acc[k];
+                    for (int cc = a; cc < 6; cc++) {
+                        H[6 * a + cc] = acc[k];
+                        H[6 * cc + a] = acc[k];
                         k++;
                     }
                 for (int a = 0; a < 6; a++) bb[a] = acc[21 + a];
@@ -950,6 +1000,7 @@ __device__ void pnp_run(const Params &prm, const Pose &prior, const double *X, c
                     ni = 2;
                 }
             }
+            const bool speculate = (iter < 4);  // there is a next solve() in this pass that could reuse the system
             int qmax = 0;
             bool cont;
             do {
@@ -978,8 +1029,17 @@ __device__ void pnp_run(const Params &prm, const Pose &prior, const double *X, c
                 __syncthreads();
                 load_cam();
                 c1 = clock64();
-                double tempChi = errors_and_chi();
-                t_err += clock64() - c1;
+                if (speculate) {
+                    pnp_sweep<true>(cam, ct, fx, fy, dsqr, dsqrReci, X, obs, err, level, n, acc);
+                    block_sum<28>(acc, red);
+                } else {
+                    pnp_sweep<false>(cam, ct, fx, fy, dsqr, dsqrReci, X, obs, err, level, n, acc);
+                    double ch[1] = {acc[27]};
+                    block_sum<1>(ch, red);
+                    acc[27] = ch[0];
+                }
+                double tempChi = acc[27];
+                t_sweep += clock64() - c1;
                 c1 = clock64();
                 if (tid == 0) {
                     if (!ok2) tempChi = 1.7976931348623157e308;
@@ -988,14 +1048,13 @@ __device__ void pnp_run(const Params &prm, const Pose &prior, const double *X, c
                     for (int j = 0; j < 6; j++) scale += dx[j] * (lambda * dx[j] + bb[j]);
                     scale += 1e-3;
                     rho /= scale;
-                    bool accept = (rho > 0 && isfinite(tempChi));
+                    const bool accept = (rho > 0 && isfinite(tempChi));
                     if (accept) {
                         double alpha = 1. - pow((2 * rho - 1), 3.0);
                         alpha = fmin(alpha, 2.0 / 3.0);
                         const double scaleFactor = fmax(1.0 / 3.0, alpha);
                         lambda *= scaleFactor;
                         ni = 2;
-                        currentChi = tempChi;
                     } else {
                         lambda *= ni;
                         ni *= 2;
@@ -1006,12 +1065,14 @@ __device__ void pnp_run(const Params &prm, const Pose &prior, const double *X, c
                     const int c = (rho < 0 && qmax < 10) ? 1 : 0;
                     sh.cont = c;
                     sh.ok = (!c && (qmax == 10 || rho == 0)) ? 0 : 1;  // Terminate
+                    sh.accepted = accept ? 1 : 0;
                 }
                 t_dec += clock64() - c1;
                 __syncthreads();
                 load_cam();
                 cont = sh.cont != 0;
                 ok = sh.ok != 0;
+                have_sys = speculate && (sh.accepted != 0);  // acc[] = system at the (accepted) current estimate
                 __syncthreads();  // sh.cont / sh.r consumed before thread 0 publishes again
             } while (cont);
         }
@@ -1030,7 +1091,7 @@ __device__ void pnp_run(const Params &prm, const Pose &prior, const double *X, c
     for (int k = 0; k < 4; k++) result.q[k] = cr[k];
     for (int k = 0; k < 3; k++) result.p[k] = ct[k];
     if (dbg && tid == 0) {
-        dbg[12] = t_err, dbg[13] = t_build, dbg[14] = t_solve, dbg[15] = t_dec, dbg[16] = clock64() - t_all, dbg[17] = calls;
+        dbg[12] = t_sweep, dbg[13] = 0, dbg[14] = t_solve, dbg[15] = t_dec, dbg[16] = clock64() - t_all, dbg[17] = calls;
     }
     __syncthreads();
 }
@@ -1040,7 +1101,7 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs, int par) {
     Ctl &ctl = *S.ctl;
     if (!ctl.active || ctl.first_frame || ctl.lost_now) return;
     __shared__ PnpShared sh;
-    __shared__ double red[128 + 27 * PNP_THREADS];
+    __shared__ double red[128 + 28 * PNP_THREADS];
     Pose res;
     int inliers, calls;
     // err must be defined for every edge before the first gate: all edges are active in pass 1
@@ -1061,7 +1122,7 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs, int par) {
 __global__ __launch_bounds__(PNP_THREADS) void k_pnp_standalone(Params prm, Pose prior, const double *X, const float *obs, double *err,
                                                                 int8_t *level, int n, Pose *out, int *info) {
     __shared__ PnpShared sh;
-    __shared__ double red[128 + 27 * PNP_THREADS];
+    __shared__ double red[128 + 28 * PNP_THREADS];
     for (int i = threadIdx.x; i < n; i += PNP_THREADS) level[i] = 0;
     __syncthreads();
     Pose res;
@@ -1093,8 +1154,11 @@ __global__ __launch_bounds__(RES_THREADS) void k_staged(Seq *seqs, int par) {
         const int scur = *S.staged_cur, SM = *S.staged_n;
         MapSoA &A = S.staged[scur], &B = S.staged[scur ^ 1];
         MapSoA &MP = S.map[*S.map_cur];
-        for (int j = tid; j < N; j += RES_THREADS) L.flag[j] = T.flag[j];
-        for (int j = tid; j < 2 * NF_MAX; j += RES_THREADS) r_tab[j] = 0;
+        for (int j = tid; j < NF_MAX; j += RES_THREADS) {
+            const uint8_t f = (j < N) ? T.flag[j] : 0;
+            if (j < N) L.flag[j] = f;
+            r_tab[j] = r_tab[NF_MAX + j] = f ? PERM : 0u;
+        }
         const int map_n0 = *S.map_n;
         uint32_t iter = 0;
         int matched_before = 0, promoted_before = 0, erased = 0;  // block-uniform running totals
@@ -1109,7 +1173,10 @@ __global__ __launch_bounds__(RES_THREADS) void k_staged(Seq *seqs, int par) {
                     const int idx = decide_query_slow<MODE_STAGED>(S, T, N, L.flag, A.desc, b0, S.sproj[2 * b0], S.sproj[2 * b0 + 1],
                                                                    S.prm.tracking_radius, S.prm.track_ratio, S.prm.desc_th);
                     if (lane_id() == 0) {
-                        if (idx >= 0) L.flag[idx] = 1;
+                        if (idx >= 0) {
+                            L.flag[idx] = 1;
+                            L.tab0[idx] = L.tab1[idx] = PERM;
+                        }
                         L.misc[1] = idx;
                     }
                 }
@@ -1119,35 +1186,38 @@ __global__ __launch_bounds__(RES_THREADS) void k_staged(Seq *seqs, int par) {
                 used = 1;
                 __syncthreads();
             }
-            const int lq0 = 2 * tid;
             int m[2], c[2], pr[2];
 #pragma unroll
-            for (int u = 0; u < 2; u++) m[u] = (lq0 + u < used && acc[u] >= 0) ? 1 : 0;
-            int mtot;
-            const int mex = block_excl_scan(m[0] + m[1], L.scan, &mtot);
+            for (int u = 0; u < 2; u++) m[u] = (tid + u * RES_THREADS < used && acc[u] >= 0) ? 1 : 0;
+            int mt0, mt1 = 0, me1 = 0;
+            const int me0 = block_excl_scan(m[0], L.scan, &mt0);
+            if (used > RES_THREADS) me1 = block_excl_scan(m[1], L.scan, &mt1);
+            const int mtot = mt0 + mt1;
 #pragma unroll
             for (int u = 0; u < 2; u++) {
                 pr[u] = 0;
                 c[u] = 0;
                 if (m[u]) {
-                    const int i = b0 + lq0 + u;
+                    const int i = b0 + tid + u * RES_THREADS;
                     c[u] = A.counter[i] + 1;
-                    const int mb = matched_before + mex + (u ? m[0] : 0);
+                    const int mb = matched_before + (u ? mt0 + me1 : me0);
                     pr[u] = (c[u] == S.prm.staged_th || map_n0 + mb < N_MAP_POINTS) ? 1 : 0;  // :377
                 }
             }
-            int ptot;
-            const int pex = block_excl_scan(pr[0] + pr[1], L.scan, &ptot);
+            int pt0, pt1 = 0, pe1 = 0;
+            const int pe0 = block_excl_scan(pr[0], L.scan, &pt0);
+            if (used > RES_THREADS) pe1 = block_excl_scan(pr[1], L.scan, &pt1);
+            const int ptot = pt0 + pt1;
 #pragma unroll
             for (int u = 0; u < 2; u++) {
-                const int lq = lq0 + u, i = b0 + lq;
+                const int lq = tid + u * RES_THREADS, i = b0 + lq;
                 if (lq >= used) continue;
                 bool del = true;
                 if (m[u]) {
                     A.counter[i] = c[u];
                     del = false;
                     if (pr[u]) {
-                        const int dst = map_n0 + promoted_before + pex + (u ? pr[0] : 0);
+                        const int dst = map_n0 + promoted_before + (u ? pt0 + pe1 : pe0);
                         if (dst < MAP_MAX) {
                             copy_point(A, i, MP, dst);
                             MP.counter[dst] = c[u];

@@ -171,22 +171,20 @@ __device__ __forceinline__ bool cand_pred(const Query &q, const Feat &F, int j) 
 // =================================================================================================
 // k_candidates : one wavefront per query; output sorted ascending by (distance << 16 | index)
 // =================================================================================================
-template <int MODE>
-__global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2, int par) {
-    Seq &S = seqs[blockIdx.z];
-    const Ctl &ctl = *S.ctl;
-    if (!ctl.active) return;
-    if (MODE == MODE_MAP) {
-        if (ctl.first_frame) return;
-        if (pass2 && !ctl.do_pass2) return;
-    }
-    if (MODE == MODE_STAGED && (ctl.first_frame || ctl.lost_now || S.prm.staged_th <= 0)) return;
-    if (MODE == MODE_ROW && (!ctl.need_tri || ctl.lost_now || S.prm.sensor != 1)) return;
+// LDS of the candidate generator: per-wave list buffer + the train-side predicate data staged once per block
+struct CandLds {
+    uint32_t *lbuf;          // [waves][KC]
+    float *tx, *ty;          // [NF_MAX]
+    uint32_t *tc;            // [NF_MAX] packed hash cell (cy << 16 | cx)
+};
 
-    __shared__ uint32_t lbuf[4][KC];
-    // train-side predicate data staged once per block: x, y (f32) and the packed hash cell (cy << 16 | cx)
-    __shared__ float s_tx[NF_MAX], s_ty[NF_MAX];
-    __shared__ uint32_t s_tc[NF_MAX];
+// wave `wave0 + k * wave_stride` handles query wave0 + k * wave_stride; all `nthreads` threads of the block stage the
+// train data.  MODE_ROW lists are built for EVERY left feature (they depend on the two feature sets only, so the
+// kernel runs on the feature stream); the resolver skips the left features tracking has already matched.
+template <int MODE>
+__device__ __forceinline__ void candidates_body(Seq &S, int pass2, int par, CandLds &C, int wave0, int wave_stride, int nthreads) {
+    uint32_t *s_tc = C.tc;
+    float *s_tx = C.tx, *s_ty = C.ty;
     const int lane = lane_id(), wv = wave_id();
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const Feat &T = (MODE == MODE_ROW) ? S.fb[par].feat[1] : S.fb[par].feat[0];
@@ -208,19 +206,19 @@ __global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2, int pa
     } else {
         M = *S.fb[par].feat[0].n;
         qdesc = S.fb[par].feat[0].desc;
-        cand = S.rcand;
-        ncand = S.rncand;
+        cand = S.rcand + (size_t)par * NF_MAX * KC;
+        ncand = S.rncand + par * NF_MAX;
     }
-    if ((int)blockIdx.x * 4 >= M) return;  // no query for this block
-    for (int j = threadIdx.x; j < N; j += 256) {
+    if (wave0 - wv >= M) return;  // no query for this block (block-uniform: wave0 - wv is the block's first query)
+    for (int j = threadIdx.x; j < N; j += nthreads) {
         s_tx[j] = T.x[j];
         s_ty[j] = T.y[j];
         if (MODE != MODE_ROW) s_tc[j] = ((uint32_t)(uint16_t)T.hcy[j] << 16) | (uint32_t)(uint16_t)T.hcx[j];
     }
     __syncthreads();
     const int radius = S.prm.tracking_radius * ((MODE == MODE_MAP && pass2) ? 2 : 1);
-    uint32_t *buf = lbuf[wv];
-    for (int i = blockIdx.x * 4 + wv; i < M; i += gridDim.x * 4) {
+    uint32_t *buf = C.lbuf + wv * KC;
+    for (int i = wave0; i < M; i += wave_stride) {
         Query q;
         if (MODE == MODE_MAP) {
             if (!S.vis[i]) {
@@ -235,10 +233,6 @@ __global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2, int pa
             }
             make_query_track(S.prm, S.sproj[2 * i], S.sproj[2 * i + 1], radius, q);
         } else {
-            if (S.fb[par].feat[0].flag[i]) {  // already matched by tracking (handler.cpp:307)
-                if (lane == 0) ncand[i] = 0;
-                continue;
-            }
             make_query_row(S.prm, S.fb[par].feat[0].x[i], S.fb[par].feat[0].y[i], q);
         }
 #pragma unroll
@@ -287,6 +281,23 @@ __global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2, int pa
         if (lane == 0) ncand[i] = cnt;  // > KC => resolvers take the exact slow path
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
     }
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2, int par) {
+    Seq &S = seqs[blockIdx.z];
+    if (MODE != MODE_ROW) {
+        const Ctl &ctl = *S.ctl;
+        if (!ctl.active || ctl.first_frame) return;
+        if (MODE == MODE_STAGED && (ctl.lost_now || S.prm.staged_th <= 0)) return;
+    } else if (S.prm.sensor != 1)
+        return;
+    __shared__ uint32_t lbuf[4 * KC];
+    __shared__ float s_tx[NF_MAX], s_ty[NF_MAX];
+    __shared__ uint32_t s_tc[NF_MAX];
+    CandLds C;
+    C.lbuf = lbuf, C.tx = s_tx, C.ty = s_ty, C.tc = s_tc;
+    candidates_body<MODE>(S, pass2, par, C, blockIdx.x * 4 + wave_id(), gridDim.x * 4, 256);
 }
 
 // =================================================================================================
@@ -549,8 +560,8 @@ __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int pa
     } else {
         M = *S.fb[par].feat[0].n;
         qdesc = S.fb[par].feat[0].desc;
-        cand = S.rcand;
-        ncand = S.rncand;
+        cand = S.rcand + (size_t)par * NF_MAX * KC;
+        ncand = S.rncand + par * NF_MAX;
     }
     const float ratio = (MODE == MODE_ROW) ? S.prm.tri_ratio : S.prm.track_ratio;
     const float desc_th = S.prm.desc_th;
@@ -560,7 +571,8 @@ __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int pa
     __syncthreads();
     for (int b0 = 0; b0 < M;) {
         int acc[2];
-        const int used = resolve_super(b0, M, [&](int q) { return ncand[q]; }, cand, L, iter, ratio, desc_th, acc);
+        const uint8_t *lflag = S.fb[par].feat[0].flag;
+        const int used = resolve_super(b0, M, [&](int q) { return (MODE == MODE_ROW && lflag[q]) ? 0 : ncand[q]; }, cand, L, iter, ratio, desc_th, acc);
         if (used < 0) {  // query b0 overflowed KC: exact scan of all train features by wavefront 0
             if (wave_id() == 0) {
                 float qx, qy;
@@ -735,7 +747,16 @@ __global__ __launch_bounds__(RES_THREADS) void k_track_mid(Seq *seqs, int par) {
     }
     if (ctl.first_frame) return;
     RESOLVE_LDS_DECL
-    if (ctl.do_pass2) {
+    if (ctl.do_pass2) {  // rare (< 50 matches): doubled-radius candidate lists are built by this one block
+        {
+            CandLds C;  // carve the (not yet used) list area of the resolver
+            C.lbuf = r_lists;                                      // 16 waves x KC words
+            C.tx = reinterpret_cast<float *>(r_lists + 16 * KC);   // NF_MAX
+            C.ty = C.tx + NF_MAX;
+            C.tc = reinterpret_cast<uint32_t *>(C.ty + NF_MAX);
+            candidates_body<MODE_MAP>(S, 1, par, C, wave_id(), RES_THREADS / 64, RES_THREADS);
+        }
+        __syncthreads();
         resolve_body<MODE_MAP>(S, ctl, 1, par, L, r_tab);
         __syncthreads();
     }
@@ -869,9 +890,11 @@ struct PnpShared {
 // estimate (EdgeProjectP2MC::computeError / linearizeOplus / constructQuadraticForm with the Cauchy weight, A.6).
 template <bool WANT_H>
 __device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3], double fx, double fy, double dsqr, double dsqrReci,
-                                          const double *X, const float *obs, double *err, const int8_t *level, int n, double (&acc)[28]) {
+                                          const double *__restrict__ X, const float *__restrict__ obs, double *__restrict__ err,
+                                          const int8_t *__restrict__ level, int n, double (&acc)[28]) {
 #pragma unroll
     for (int k = 0; k < 28; k++) acc[k] = 0.0;
+#pragma unroll 2
     for (int i = threadIdx.x; i < n; i += PNP_THREADS) {
         if (level[i] != 0) continue;
         const double x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2];

@@ -147,7 +147,7 @@ struct Seq {
     // pnp input
     double *pnp_X; float *pnp_obs; int *pnp_feat; double *pnp_err; int8_t *pnp_level;
     // row matching / triangulation
-    uint32_t *rcand; int *rncand;   // [NF_MAX][KC]
+    uint32_t *rcand; int *rncand;   // [2 parities][NF_MAX][KC]: built on the feature stream
     int *pair_l, *pair_r;           // [NF_MAX]
     double *tri_X; int8_t *tri_ok;  // [NF_MAX][3]
 };

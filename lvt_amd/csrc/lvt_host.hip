@@ -369,8 +369,8 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
             S.pnp_feat = c->dalloc<int>(NF_MAX);
             S.pnp_err = c->dalloc<double>((size_t)NF_MAX * 2);
             S.pnp_level = c->dalloc<int8_t>(NF_MAX);
-            S.rcand = c->dalloc<uint32_t>((size_t)NF_MAX * KC);
-            S.rncand = c->dalloc<int>(NF_MAX);
+            S.rcand = c->dalloc<uint32_t>((size_t)2 * NF_MAX * KC);  // per frame parity
+            S.rncand = c->dalloc<int>(2 * NF_MAX);
             S.pair_l = c->dalloc<int>(NF_MAX), S.pair_r = c->dalloc<int>(NF_MAX);
             S.tri_X = c->dalloc<double>((size_t)NF_MAX * 3);
             S.tri_ok = c->dalloc<int8_t>(NF_MAX);
@@ -390,8 +390,8 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
 // ---- the per-frame launch chain -------------------------------------------------------------------
 static const char *kProfNames[Context::PROF_SLOTS] = {
     "k_feat_begin", "", "k_score", "k_cells(pass0)", "k_cells(retry)", "k_gather", "k_brief", "k_project(begin+map)",
-    "k_candidates(map)", "k_resolve(map)", "k_candidates(map,pass2)", "", "k_track_mid(pass2+bookkeep+cull)", "k_pnp(+project staged)", "",
-    "", "k_candidates(staged)", "k_staged", "k_candidates(row)", "k_resolve(row)", "k_triangulate(+finalize)", "",
+    "k_candidates(map)", "k_resolve(map)", "", "", "k_track_mid(pass2+bookkeep+cull)", "k_pnp(+project staged)", "",
+    "", "k_candidates(staged)", "k_staged", "k_candidates(row) [feature stream]", "k_resolve(row)", "k_triangulate(+finalize)", "",
     "", ""};
 
 #define LAUNCH(slot, st, kern, grid, block, lds, ...)                              \
@@ -426,18 +426,17 @@ static void enqueue_frame(Context *c) {
     }
     LAUNCH(5, sf, k_gather, dim3(1, 2, B), dim3(1024), 0, S, par);
     LAUNCH(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, S, par);
+    LAUNCH(18, sf, k_candidates<MODE_ROW>, dim3(256, 1, B), dim3(256), 0, S, 0, par);
     (void)hipEventRecord(c->ev_feat[par], sf);
     // ---- tracking chain (stream): strictly ordered frame after frame
     (void)hipStreamWaitEvent(st, c->ev_feat[par], 0);
     LAUNCH(7, st, k_project, dim3(32, 1, B), dim3(256), 0, S, par);
     LAUNCH(8, st, k_candidates<MODE_MAP>, dim3(256, 1, B), dim3(256), 0, S, 0, par);
     LAUNCH(9, st, k_resolve<MODE_MAP>, dim3(1, 1, B), dim3(RES_THREADS), 0, S, 0, par);
-    LAUNCH(10, st, k_candidates<MODE_MAP>, dim3(256, 1, B), dim3(256), 0, S, 1, par);
     LAUNCH(12, st, k_track_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par);
     LAUNCH(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), 0, S, par);
     LAUNCH(16, st, k_candidates<MODE_STAGED>, dim3(64, 1, B), dim3(256), 0, S, 0, par);
     LAUNCH(17, st, k_staged, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par);
-    LAUNCH(18, st, k_candidates<MODE_ROW>, dim3(256, 1, B), dim3(256), 0, S, 0, par);
     LAUNCH(19, st, k_resolve<MODE_ROW>, dim3(1, 1, B), dim3(RES_THREADS), 0, S, 0, par);
     LAUNCH(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, S, par);
     for (int s = 0; s < B; s++)

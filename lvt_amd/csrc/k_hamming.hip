@@ -1,16 +1,21 @@
 // k_hamming.hip -- batched masked 2-NN Hamming matcher (the matcher of lvt_image_features_struct.cpp:68-148
 // + cv::BFMatcher::knnMatch(k=2, mask)) as ONE launch over B independent problems.
 //
-// One 512-thread workgroup per problem, two workgroups per CU (72 KB of LDS each at N = 1500).
-//   1. every thread fetches "its" train features (coordinates, flag, 32-B descriptor) and its first queries into
+// One 512-thread workgroup per problem, two workgroups per CU (78 KB of LDS each at N = 1500, M = 1000), so the
+// HBM phase of one problem overlaps the LDS/VALU phase of the other.
+//   1. every thread fetches "its" train features (coordinates, flag, 32-B descriptor) and its query coordinates into
 //      registers -- all global loads of the problem are in flight at once;
-//   2. the train set is counting-sorted into the reference's 25-px hash cells (tracking mode) or image rows (row
-//      mode): the LDS atomicAdd that counts a bin also returns the feature's rank inside it, so one scan of the
-//      bin counts later each feature is stored at start[bin] + rank -- coordinates, packed (flag | index) word and
-//      descriptor all in BIN ORDER, the query loop then walks contiguous LDS with no indirection;
-//   3. each lane owns queries (descriptor in 4 x u64 VGPR pairs), visits only the bins its mask admits, evaluates
-//      4 x (xor, popcount) on the few candidates that pass the coordinate test, and keeps the running top-2 as
-//      packed (distance << 16 | index) keys so ties resolve to the lowest index exactly as batchDistance does.
+//   2. the unflagged train features are counting-sorted into the reference's 25-px hash cells (tracking mode) or
+//      image rows (row mode): the LDS atomicAdd that counts a bin also returns the feature's rank inside it, so after
+//      one in-place scan of the counts each feature is stored at start[bin] + rank -- coordinates, index and
+//      descriptor all in BIN ORDER; the candidates of a query are then <= 2*csr+1 contiguous LDS ranges;
+//   3. the queries are counting-sorted by their candidate count (known from the bin starts alone), so the 64 queries
+//      a wavefront works on in one round need the same number of steps -- without this a wavefront runs at the pace
+//      of its busiest lane, ~2x the mean at KITTI densities;
+//   4. each lane owns one query per round (descriptor in 4 x u64 VGPR pairs), walks its ranges as ONE flattened
+//      index space (virtual index -> LDS position is two compares and an add), evaluates 4 x (xor, popcount) per
+//      candidate and keeps the running top-2 as packed (distance << 16 | index) keys, so ties resolve to the lowest
+//      index exactly as batchDistance does.
 // Algorithmic HBM bytes per problem: 40*(M+N) + N + 16*M; every byte is read or written exactly once.
 #include "lvt_dev.h"
 
@@ -27,26 +32,34 @@ struct HammingArgs {
     float r2;
     int img_rows, img_cols;
     int nbx, nby, csr;       // bins: hash cells (mode 0) or rows (mode 1: nbx = 1, nby = rows + 1)
-    long long *dbg;          // optional: phase cycle stamps of workgroup 0
+    long long *dbg;          // optional: phase cycle stamps of one workgroup
 };
 
 constexpr int HB_THREADS = 512;
+constexpr int HB_WAVES = HB_THREADS / 64;
 constexpr int HB_TPT = 4;          // train features per thread  => N <= 2048
+constexpr int HB_QPT = 4;          // queries per thread         => M <= 2048
 constexpr int HB_NMAX = HB_THREADS * HB_TPT;
+constexpr int HB_MMAX = HB_THREADS * HB_QPT;
+constexpr int HB_HIST = 64;        // query classes by candidate count (>= 63 candidates share the first class)
 
-template <int MODE>
-__global__ __launch_bounds__(HB_THREADS) void k_hamming_batched(HammingArgs a) {
+// NSP = number of candidate ranges a query keeps in registers: 1 (row mode), 3 (csr 1), 5 (csr 2); 0 = any csr, the
+// ranges are walked one after the other (no flattening)
+template <int MODE, int NSP>
+__global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_hamming_batched(HammingArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int N = a.N, M = a.M;
     const int nbins = a.nbx * a.nby;
-    // carve: desc_s [N][2] uint4 | rec_s [N] {x, y, flag|index, -} (16 B) | start [nbins+1] | cursor [nbins]
+    // carve: desc [N][2] uint4 | xy [N] float2 | start [nbins + 1] | idx [N] u16 | order [M] u16
     uint4 *s_desc = reinterpret_cast<uint4 *>(smem);
-    float4 *s_rec = reinterpret_cast<float4 *>(s_desc + (size_t)N * 2);
-    int *s_start = reinterpret_cast<int *>(s_rec + N);
-    int *s_cur = s_start + nbins + 1;
+    float2 *s_xy = reinterpret_cast<float2 *>(s_desc + (size_t)N * 2);
+    int *s_start = reinterpret_cast<int *>(s_xy + N);
+    uint16_t *s_idx = reinterpret_cast<uint16_t *>(s_start + nbins + 1);
+    uint16_t *s_order = s_idx + ((N + 1) & ~1);
     __shared__ int s_scan[32];
+    __shared__ int s_hist[HB_HIST];
 
-    const int b = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint4 *td = reinterpret_cast<const uint4 *>(a.t_desc + (size_t)b * N * 4);
     const float2 *txy = a.t_xy + (size_t)b * N;
     const uint8_t *tf = a.t_flag + (size_t)b * N;
@@ -56,161 +69,240 @@ __global__ __launch_bounds__(HB_THREADS) void k_hamming_batched(HammingArgs a) {
 
     long long *dbg = (a.dbg && blockIdx.x == gridDim.x / 2 && tid == 0) ? a.dbg : nullptr;
     if (dbg) dbg[0] = clock64();
+
+    // ---- 1. everything this thread needs from HBM for the sort, issued back to back (indices clamped: no branches)
+    float2 tp[HB_TPT];
+    bool tv[HB_TPT];
+    uint4 tdlo[HB_TPT], tdhi[HB_TPT];
+    float2 qp[HB_QPT];
+#pragma unroll
+    for (int k = 0; k < HB_TPT; k++) {
+        const int j = tid + k * HB_THREADS;
+        const int jc = max(min(j, N - 1), 0);
+        tv[k] = false;
+        tp[k] = make_float2(0.f, 0.f);
+        tdlo[k] = tdhi[k] = make_uint4(0, 0, 0, 0);
+        if (N > 0) {
+            tp[k] = txy[jc];
+            tv[k] = (j < N) && (tf[jc] == 0);
+            tdlo[k] = td[2 * jc];
+            tdhi[k] = td[2 * jc + 1];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < HB_QPT; k++) qp[k] = qxy[min(tid + k * HB_THREADS, M - 1)];
+    for (int i = tid; i <= nbins; i += HB_THREADS) s_start[i] = 0;
+    if (tid < HB_HIST) s_hist[tid] = 0;
+    __syncthreads();
+    if (dbg) dbg[1] = clock64();
+
+    // ---- 2. counting sort of the unflagged train features: the counting atomic returns the rank inside the bin
     auto bin_of = [&](float x, float y) -> int {
         if (MODE == 1) return min(max((int)floorf(y), 0), a.nby - 1);
         const int cy = min(max((int)floorf(y / (float)HASH_CELL), 0), a.nby - 1);
         const int cx = min(max((int)floorf(x / (float)HASH_CELL), 0), a.nbx - 1);
         return cy * a.nbx + cx;
     };
-
-    // ---- 1. everything this thread will need from HBM, issued back to back
-    float2 tp[HB_TPT];
-    uint8_t tfl[HB_TPT];
-    uint4 tdlo[HB_TPT], tdhi[HB_TPT];
-#pragma unroll
-    for (int k = 0; k < HB_TPT; k++) {
-        const int j = tid + k * HB_THREADS;
-        if (j < N) {
-            tp[k] = txy[j];
-            tfl[k] = tf[j];
-            tdlo[k] = td[2 * j];
-            tdhi[k] = td[2 * j + 1];
-        }
-    }
-    uint4 q0lo = make_uint4(0, 0, 0, 0), q0hi = q0lo;
-    float2 q0p = make_float2(0, 0);
-    if (tid < M) {
-        q0lo = qd[2 * tid];
-        q0hi = qd[2 * tid + 1];
-        q0p = qxy[tid];
-    }
-    for (int i = tid; i < nbins; i += HB_THREADS) s_cur[i] = 0;
-    __syncthreads();
-    if (dbg) dbg[1] = clock64();
-    // ---- 2. counting sort into bins: the counting atomic returns the rank inside the bin
     int tbin[HB_TPT], trank[HB_TPT];
 #pragma unroll
     for (int k = 0; k < HB_TPT; k++) {
-        const int j = tid + k * HB_THREADS;
-        if (j < N) {
-            tbin[k] = bin_of(tp[k].x, tp[k].y);
-            trank[k] = atomicAdd(&s_cur[tbin[k]], 1);
-        }
+        tbin[k] = bin_of(tp[k].x, tp[k].y);
+        trank[k] = 0;
+        if (tv[k]) trank[k] = atomicAdd(&s_start[tbin[k]], 1);
     }
     __syncthreads();
     if (dbg) dbg[2] = clock64();
-    {
-        int run = 0;
-        for (int base = 0; base < nbins; base += HB_THREADS) {
-            const int i = base + tid;
-            const int v = (i < nbins) ? s_cur[i] : 0;
-            int total;
-            const int ex = run + block_excl_scan(v, s_scan, &total);
-            if (i < nbins) s_start[i] = ex;
-            run += total;
+    {  // counts -> exclusive starts, in place; entry nbins receives the total.  One contiguous chunk per thread.
+        const int chunk = (nbins + 1 + HB_THREADS - 1) / HB_THREADS;
+        const int i0 = min(tid * chunk, nbins + 1), i1 = min(i0 + chunk, nbins + 1);
+        int sum = 0;
+        for (int i = i0; i < i1; i++) sum += s_start[i];
+        int total;
+        int run = block_excl_scan(sum, s_scan, &total);
+        for (int i = i0; i < i1; i++) {
+            const int v = s_start[i];
+            s_start[i] = run;
+            run += v;
         }
-        if (tid == 0) s_start[nbins] = run;
     }
     __syncthreads();
     if (dbg) dbg[3] = clock64();
 #pragma unroll
     for (int k = 0; k < HB_TPT; k++) {
-        const int j = tid + k * HB_THREADS;
-        if (j < N) {
+        if (tv[k]) {
             const int pos = s_start[tbin[k]] + trank[k];
-            s_rec[pos] = make_float4(tp[k].x, tp[k].y, __uint_as_float((uint32_t)j | (tfl[k] ? 0x80000000u : 0u)), 0.0f);
+            s_xy[pos] = tp[k];
+            s_idx[pos] = (uint16_t)(tid + k * HB_THREADS);
             s_desc[2 * pos] = tdlo[k];
             s_desc[2 * pos + 1] = tdhi[k];
         }
     }
+
+    // candidate ranges of one query (named scalars, not arrays: they must stay in VGPRs).  l_k = 0 for a range that
+    // does not exist.
+    constexpr int NS = NSP > 0 ? NSP : 1;
+    struct Ranges {
+        int s0, l0, s1, l1, s2, l2, s3, l3, s4, l4;
+        int y0, y1, x0, x1;
+    };
+    auto ranges = [&](float2 p) -> Ranges {
+        Ranges R;
+        R.s0 = R.l0 = R.s1 = R.l1 = R.s2 = R.l2 = R.s3 = R.l3 = R.s4 = R.l4 = 0;
+        if (MODE == 1) {  // struct.cpp:124-131: rows [int(y)-2, int(y)+2] clipped to [0, rows] are contiguous bins
+            R.y0 = max((int)p.y - ROW_RADIUS, 0);
+            R.y1 = min(min((int)p.y + ROW_RADIUS, a.img_rows), a.nby - 1);
+            R.x0 = R.x1 = 0;
+            const bool ok = R.y0 <= R.y1;
+            R.s0 = s_start[ok ? R.y0 : 0];
+            R.l0 = s_start[ok ? R.y1 + 1 : 0] - R.s0;
+        } else {  // struct.cpp:71-83: the cells of one window row are contiguous
+            const int hy = (int)floorf(p.y / (float)HASH_CELL), hx = (int)floorf(p.x / (float)HASH_CELL);
+            R.y0 = max(hy - a.csr, 0);
+            R.y1 = min(hy + a.csr, a.nby - 1);
+            R.x0 = max(hx - a.csr, 0);
+            R.x1 = min(hx + a.csr, a.nbx - 1);
+#define LVT_RANGE(k, S, L)                                                     \
+    if (NSP > k) {                                                             \
+        const bool ok = (R.y0 + k <= R.y1) && (R.x0 <= R.x1);                  \
+        const int row = ok ? (R.y0 + k) * a.nbx : 0;                           \
+        S = s_start[row + (ok ? R.x0 : 0)];                                    \
+        L = s_start[row + (ok ? R.x1 + 1 : 0)] - S;                            \
+    }
+            LVT_RANGE(0, R.s0, R.l0)
+            LVT_RANGE(1, R.s1, R.l1)
+            LVT_RANGE(2, R.s2, R.l2)
+            LVT_RANGE(3, R.s3, R.l3)
+            LVT_RANGE(4, R.s4, R.l4)
+#undef LVT_RANGE
+        }
+        return R;
+    };
+    auto count_of = [&](float2 p) -> int {
+        const Ranges R = ranges(p);
+        int c = 0;
+        if (MODE == 0 && NSP == 0) {
+            if (R.x0 <= R.x1)
+                for (int by = R.y0; by <= R.y1; by++) c += s_start[by * a.nbx + R.x1 + 1] - s_start[by * a.nbx + R.x0];
+        } else
+            c = R.l0 + R.l1 + R.l2 + R.l3 + R.l4;
+        return c;
+    };
+
+    // ---- 3. queries sorted by candidate count, heaviest first (needs the bin starts only: overlaps the scatter)
+    int qkey[HB_QPT], qrank[HB_QPT];
+#pragma unroll
+    for (int k = 0; k < HB_QPT; k++) {
+        const int q = tid + k * HB_THREADS;
+        qkey[k] = 0, qrank[k] = 0;
+        if (q < M) {
+            qkey[k] = HB_HIST - 1 - min(count_of(qp[k]), HB_HIST - 1);
+            qrank[k] = atomicAdd(&s_hist[qkey[k]], 1);
+        }
+    }
     __syncthreads();
     if (dbg) dbg[4] = clock64();
-
-    // ---- 3. queries
-    for (int q = tid; q < M; q += HB_THREADS) {
-        uint4 w0, w1;
-        float2 p;
-        if (q == tid) {
-            w0 = q0lo, w1 = q0hi, p = q0p;
-        } else {
-            w0 = qd[2 * q];
-            w1 = qd[2 * q + 1];
-            p = qxy[q];
-        }
-        const uint64_t d0 = ((uint64_t)w0.y << 32) | w0.x, d1 = ((uint64_t)w0.w << 32) | w0.z;
-        const uint64_t d2 = ((uint64_t)w1.y << 32) | w1.x, d3 = ((uint64_t)w1.w << 32) | w1.z;
-        uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
-        int y0, y1, x0, x1;
-        if (MODE == 1) {  // struct.cpp:124-131: [int(y)-2, int(y)+2] clipped to [0, rows]
-            y0 = max((int)p.y - ROW_RADIUS, 0);
-            y1 = min((int)p.y + ROW_RADIUS, a.img_rows);
-            x0 = x1 = 0;
-        } else {  // struct.cpp:71-83
-            const int hy = (int)floorf(p.y / (float)HASH_CELL), hx = (int)floorf(p.x / (float)HASH_CELL);
-            y0 = max(hy - a.csr, 0);
-            y1 = min(hy + a.csr, a.nby - 1);
-            x0 = max(hx - a.csr, 0);
-            x1 = min(hx + a.csr, a.nbx - 1);
-        }
-        // one candidate, branch-free: every LDS read is unconditional so the loads of the next candidates pipeline
-        auto eval = [&](int it, bool valid, float fy0, float fy1) {
-            const float4 r = s_rec[it];
-            const uint4 a0 = s_desc[2 * it], a1 = s_desc[2 * it + 1];
-            const uint32_t m = __float_as_uint(r.z);
-            bool ok;
-            if (MODE == 1) ok = (r.y >= fy0) && (r.y <= fy1);
-            else {
-                const float dx = r.x - p.x, dy = r.y - p.y;
-                ok = (dx * dx + dy * dy) < a.r2;
-            }
-            ok = ok && valid && !(m >> 31);
-            const int d = __popcll(d0 ^ (((uint64_t)a0.y << 32) | a0.x)) + __popcll(d1 ^ (((uint64_t)a0.w << 32) | a0.z)) +
-                          __popcll(d2 ^ (((uint64_t)a1.y << 32) | a1.x)) + __popcll(d3 ^ (((uint64_t)a1.w << 32) | a1.z));
-            const uint32_t key = ok ? (((uint32_t)d << 16) | (m & 0xFFFFu)) : 0xFFFFFFFFu;
-            k2 = min(k2, max(k1, key));
-            k1 = min(k1, key);
-        };
-        auto span = [&](int s, int e, float fy0, float fy1) {
-#pragma unroll 2
-            for (int it = s; it < e; it += 2) {
-                eval(it, true, fy0, fy1);
-                eval(min(it + 1, e - 1), it + 1 < e, fy0, fy1);
-            }
-        };
-        if (MODE == 1) {
-            // rows y0..y1 are contiguous bins: one span
-            y1 = min(y1, a.nby - 1);
-            const int s = (y0 <= y1) ? s_start[y0] : 0, e = (y0 <= y1) ? s_start[y1 + 1] : 0;
-            span(s, e, (float)y0, (float)min((int)p.y + ROW_RADIUS, a.img_rows));
-        } else {
-            // the bins of one window row are contiguous in the CSR: at most 2*csr+1 spans; their bounds are read up front
-            int ss[3], ee[3];
-            const bool small = (y1 - y0) <= 2;
-            if (small) {
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const int by = min(y0 + k, y1);
-                    ss[k] = s_start[by * a.nbx + x0];
-                    ee[k] = (y0 + k <= y1) ? s_start[by * a.nbx + x1 + 1] : ss[k];
-                }
-#pragma unroll
-                for (int k = 0; k < 3; k++) span(ss[k], ee[k], 0.f, 0.f);
-            } else {
-                for (int by = y0; by <= y1; by++) span(s_start[by * a.nbx + x0], s_start[by * a.nbx + x1 + 1], 0.f, 0.f);
-            }
-        }
-        int4 o;
-        o.x = (k1 == 0xFFFFFFFFu) ? -1 : (int)(k1 & 0xFFFFu);
-        o.y = (k1 == 0xFFFFFFFFu) ? 0x7FFFFFFF : (int)(k1 >> 16);
-        o.z = (k2 == 0xFFFFFFFFu) ? -1 : (int)(k2 & 0xFFFFu);
-        o.w = (k2 == 0xFFFFFFFFu) ? 0x7FFFFFFF : (int)(k2 >> 16);
-        out[q] = o;
+    if (wv == 0) {
+        const int v = s_hist[lane];
+        s_hist[lane] = wave_incl_scan(v) - v;
     }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < HB_QPT; k++) {
+        const int q = tid + k * HB_THREADS;
+        if (q < M) s_order[s_hist[qkey[k]] + qrank[k]] = (uint16_t)q;
+    }
+    __syncthreads();
     if (dbg) dbg[5] = clock64();
+
+    // ---- 4. rounds of 512 queries in sorted order; odd rounds reverse the wave order so every wave gets a similar sum
+    const int rounds = (M + HB_THREADS - 1) / HB_THREADS;
+    auto slot_query = [&](int j) -> int {
+        const int slot = j * HB_THREADS + ((j & 1) ? (HB_WAVES - 1 - wv) : wv) * 64 + lane;
+        return (j < rounds && slot < M) ? (int)s_order[slot] : -1;
+    };
+    int q = slot_query(0);
+    uint4 w0 = qd[2 * max(q, 0)], w1 = qd[2 * max(q, 0) + 1];
+    float2 p = qxy[max(q, 0)];
+    for (int j = 0; j < rounds; j++) {
+        const int qn = slot_query(j + 1);
+        const uint4 nw0 = qd[2 * max(qn, 0)], nw1 = qd[2 * max(qn, 0) + 1];  // next round's query: in flight during this round
+        const float2 np = qxy[max(qn, 0)];
+        if (q >= 0) {
+            const uint64_t d0 = ((uint64_t)w0.y << 32) | w0.x, d1 = ((uint64_t)w0.w << 32) | w0.z;
+            const uint64_t d2 = ((uint64_t)w1.y << 32) | w1.x, d3 = ((uint64_t)w1.w << 32) | w1.z;
+            uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+            const Ranges R = ranges(p);
+            const int y0 = R.y0, y1 = R.y1, x0 = R.x0, x1 = R.x1;
+            const float fy0 = (float)y0, fy1 = (float)min((int)p.y + ROW_RADIUS, a.img_rows);
+            // one candidate; the LDS reads of the next one are issued before this one is reduced
+            auto eval = [&](const float2 r, const uint4 a0, const uint4 a1, const uint32_t id) {
+                bool ok;
+                if (MODE == 1) ok = (r.y >= fy0) && (r.y <= fy1);
+                else {
+                    const float dx = r.x - p.x, dy = r.y - p.y;
+                    ok = (dx * dx + dy * dy) < a.r2;
+                }
+                const int d = __popcll(d0 ^ (((uint64_t)a0.y << 32) | a0.x)) + __popcll(d1 ^ (((uint64_t)a0.w << 32) | a0.z)) +
+                              __popcll(d2 ^ (((uint64_t)a1.y << 32) | a1.x)) + __popcll(d3 ^ (((uint64_t)a1.w << 32) | a1.z));
+                const uint32_t key = ok ? (((uint32_t)d << 16) | id) : 0xFFFFFFFFu;
+                k2 = min(k2, max(k1, key));
+                k1 = min(k1, key);
+            };
+            // positions of the flattened index space: v in [c_k, c_{k+1}) lies in range k at LDS position v + o_k
+            // (scalars, not arrays: they must stay in VGPRs).  Software-pipelined by one candidate.
+            auto walk = [&](int total, int o0, int c1, int o1, int c2, int o2, int c3, int o3, int c4, int o4) {
+                if (total <= 0) return;
+#define LVT_POS_OF(dst, v)                          \
+    {                                               \
+        int o_ = o0;                                \
+        if (NS > 1) o_ = ((v) >= c1) ? o1 : o_;     \
+        if (NS > 2) o_ = ((v) >= c2) ? o2 : o_;     \
+        if (NS > 3) o_ = ((v) >= c3) ? o3 : o_;     \
+        if (NS > 4) o_ = ((v) >= c4) ? o4 : o_;     \
+        dst = (v) + o_;                             \
+    }
+                int it;
+                LVT_POS_OF(it, 0)
+                float2 r = s_xy[it];
+                uint4 a0 = s_desc[2 * it], a1 = s_desc[2 * it + 1];
+                uint32_t id = s_idx[it];
+                for (int v = 0; v < total; v++) {
+                    const int vn = min(v + 1, total - 1);
+                    int itn;
+                    LVT_POS_OF(itn, vn)
+                    const float2 rn = s_xy[itn];
+                    const uint4 b0 = s_desc[2 * itn], b1 = s_desc[2 * itn + 1];
+                    const uint32_t idn = s_idx[itn];
+                    eval(r, a0, a1, id);
+                    r = rn, a0 = b0, a1 = b1, id = idn;
+                }
+#undef LVT_POS_OF
+            };
+            if (MODE == 0 && NSP == 0) {
+                if (x0 <= x1)
+                    for (int by = y0; by <= y1; by++) {
+                        const int s = s_start[by * a.nbx + x0];
+                        walk(s_start[by * a.nbx + x1 + 1] - s, s, 0, 0, 0, 0, 0, 0, 0, 0);
+                    }
+            } else {
+                static_assert(NS <= 5, "range registers");
+                const int c1 = R.l0, c2 = c1 + R.l1, c3 = c2 + R.l2, c4 = c3 + R.l3;
+                walk(c4 + R.l4, R.s0, c1, R.s1 - c1, c2, R.s2 - c2, c3, R.s3 - c3, c4, R.s4 - c4);
+            }
+            int4 o;
+            o.x = (k1 == 0xFFFFFFFFu) ? -1 : (int)(k1 & 0xFFFFu);
+            o.y = (k1 == 0xFFFFFFFFu) ? 0x7FFFFFFF : (int)(k1 >> 16);
+            o.z = (k2 == 0xFFFFFFFFu) ? -1 : (int)(k2 & 0xFFFFu);
+            o.w = (k2 == 0xFFFFFFFFu) ? 0x7FFFFFFF : (int)(k2 >> 16);
+            out[q] = o;
+        }
+        q = qn, w0 = nw0, w1 = nw1, p = np;
+    }
+    if (dbg) dbg[6] = clock64();
 }
 
-static inline size_t hamming_lds_bytes(int N, int nbins) {
-    return (size_t)N * 32 + (size_t)N * 16 + (size_t)(2 * nbins + 1) * 4 + 64;
+static inline size_t hamming_lds_bytes(int N, int M, int nbins) {
+    return (size_t)N * 32 + (size_t)N * 8 + (size_t)(nbins + 1) * 4 + (size_t)((N + 1) & ~1) * 2 + (size_t)((M + 1) & ~1) * 2 + 16;
 }
 
 }  // namespace lvt

@@ -949,8 +949,8 @@ LVT_API int lvt_amd_pnp(const lvt_amd_params *pin, const double q_in[4], const d
 LVT_API float lvt_amd_hamming_match_batched(const void *q_desc, const void *q_xy, const void *t_desc, const void *t_xy, const void *t_flag,
                                             int B, int M, int N, float r2, int mode, int img_rows, int img_cols, void *out,
                                             void *hip_stream) {
-    if (B <= 0 || M <= 0 || N <= 0 || N > HB_NMAX) {
-        std::fprintf(stderr, "lvt_amd_hamming_match_batched: bad sizes B=%d M=%d N=%d (N <= %d)\n", B, M, N, HB_NMAX);
+    if (B <= 0 || M <= 0 || N <= 0 || N > HB_NMAX || M > HB_MMAX) {
+        std::fprintf(stderr, "lvt_amd_hamming_match_batched: bad sizes B=%d M=%d N=%d (N <= %d, M <= %d)\n", B, M, N, HB_NMAX, HB_MMAX);
         return -1.0f;
     }
     HammingArgs a;
@@ -970,7 +970,7 @@ LVT_API float lvt_amd_hamming_match_batched(const void *q_desc, const void *q_xy
         a.nbx = (int)std::ceil(img_cols / (float)HASH_CELL), a.nby = (int)std::ceil(img_rows / (float)HASH_CELL);
         a.csr = std::max(1, (int)std::ceil(std::sqrt(r2) / (float)HASH_CELL));
     }
-    const size_t lds = hamming_lds_bytes(N, a.nbx * a.nby);
+    const size_t lds = hamming_lds_bytes(N, M, a.nbx * a.nby);
     if (lds > 160 * 1024) {
         std::fprintf(stderr, "lvt_amd_hamming_match_batched: %zu bytes of LDS needed\n", lds);
         return -1.0f;
@@ -985,16 +985,11 @@ LVT_API float lvt_amd_hamming_match_batched(const void *q_desc, const void *q_xy
         }
     }
     float ms = -1.0f;
-    hipError_t ea;
-    if (mode == 1) {
-        ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hamming_batched<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipEventRecord(e0, st);
-        hipLaunchKernelGGL(k_hamming_batched<1>, dim3(B), dim3(HB_THREADS), lds, st, a);
-    } else {
-        ea = hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hamming_batched<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        (void)hipEventRecord(e0, st);
-        hipLaunchKernelGGL(k_hamming_batched<0>, dim3(B), dim3(HB_THREADS), lds, st, a);
-    }
+    // the variant fixes how many candidate ranges a query keeps in registers (k_hamming.hip)
+    void (*kern)(HammingArgs) = (mode == 1) ? k_hamming_batched<1, 1> : (a.csr == 1) ? k_hamming_batched<0, 3> : (a.csr == 2) ? k_hamming_batched<0, 5> : k_hamming_batched<0, 0>;
+    const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipEventRecord(e0, st);
+    hipLaunchKernelGGL(kern, dim3(B), dim3(HB_THREADS), lds, st, a);
     const hipError_t elaunch = hipGetLastError();
     (void)hipEventRecord(e1, st);
     const hipError_t es = hipEventSynchronize(e1);
@@ -1007,9 +1002,9 @@ LVT_API float lvt_amd_hamming_match_batched(const void *q_desc, const void *q_xy
     (void)hipEventDestroy(e1);
     if (d_dbg) {
         long long hd[8] = {};
-        (void)hipMemcpy(hd, d_dbg, 48, hipMemcpyDeviceToHost);
-        std::fprintf(stderr, "hamming phases (cycles): load+zero %lld count %lld scan %lld scatter %lld queries %lld total %lld\n", hd[1] - hd[0], hd[2] - hd[1],
-                     hd[3] - hd[2], hd[4] - hd[3], hd[5] - hd[4], hd[5] - hd[0]);
+        (void)hipMemcpy(hd, d_dbg, 56, hipMemcpyDeviceToHost);
+        std::fprintf(stderr, "hamming phases (cycles): load+zero %lld count %lld scan %lld scatter+qcount %lld qsort %lld queries %lld total %lld\n", hd[1] - hd[0],
+                     hd[2] - hd[1], hd[3] - hd[2], hd[4] - hd[3], hd[5] - hd[4], hd[6] - hd[5], hd[6] - hd[0]);
         (void)hipFree(d_dbg);
     }
     return (ee != hipSuccess || ms < 0) ? -1.0f : ms * 1000.0f;

@@ -43,17 +43,28 @@ constexpr int HB_NMAX = HB_THREADS * HB_TPT;
 constexpr int HB_MMAX = HB_THREADS * HB_QPT;
 constexpr int HB_HIST = 64;        // query classes by candidate count (>= 63 candidates share the first class)
 
+// y / 25.0f, correctly rounded, in three instructions instead of the ~10 of the IEEE division expansion: with
+// c = RN(1/25), q0 = RN(y c), r = y - 25 q0 (exact in one fma), RN(q0 + r c) is the correctly rounded quotient
+// (Markstein).  Checked against y / 25.0f for every finite float (tests/test_div25.py runs a sample of that sweep).
+static_assert(HASH_CELL == 25, "div_cell is specialised to the reference's 25-px hash cell");
+__device__ __forceinline__ float div_cell(float y) {
+    const float c = 0.04f;
+    const float q0 = y * c;
+    return __builtin_fmaf(__builtin_fmaf(-25.0f, q0, y), c, q0);
+}
+
 // NSP = number of candidate ranges a query keeps in registers: 1 (row mode), 3 (csr 1), 5 (csr 2); 0 = any csr, the
 // ranges are walked one after the other (no flattening)
-template <int MODE, int NSP>
+template <int MODE, int NSP, int QPT, int TPT>  // QPT = ceil(M / 512) rounds of queries, TPT = ceil(N / 512) train features per thread
 __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_hamming_batched(HammingArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int N = a.N, M = a.M;
     const int nbins = a.nbx * a.nby;
-    // carve: desc [N][2] uint4 | xy [N] float2 | start [nbins + 1] | idx [N] u16 | order [M] u16
+    // carve: desc [N][2] uint4 | xy [N] float2 | mask [M] uint2 | start [nbins + 1] | idx [N] u16 | order [M] u16
     uint4 *s_desc = reinterpret_cast<uint4 *>(smem);
     float2 *s_xy = reinterpret_cast<float2 *>(s_desc + (size_t)N * 2);
-    int *s_start = reinterpret_cast<int *>(s_xy + N);
+    uint2 *s_mask = reinterpret_cast<uint2 *>(s_xy + N);
+    int *s_start = reinterpret_cast<int *>(s_mask + M);
     uint16_t *s_idx = reinterpret_cast<uint16_t *>(s_start + nbins + 1);
     uint16_t *s_order = s_idx + ((N + 1) & ~1);
     __shared__ int s_scan[32];
@@ -69,14 +80,16 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
 
     long long *dbg = (a.dbg && blockIdx.x == gridDim.x / 2 && tid == 0) ? a.dbg : nullptr;
     if (dbg) dbg[0] = clock64();
+    __builtin_amdgcn_s_setprio(3);  // the load / sort phases are latency-bound: let them through ahead of the other
+                                    // workgroup's VALU-bound query phases
 
     // ---- 1. everything this thread needs from HBM for the sort, issued back to back (indices clamped: no branches)
-    float2 tp[HB_TPT];
-    bool tv[HB_TPT];
-    uint4 tdlo[HB_TPT], tdhi[HB_TPT];
-    float2 qp[HB_QPT];
+    float2 tp[TPT];
+    bool tv[TPT];
+    uint4 tdlo[TPT], tdhi[TPT];
+    float2 qp[QPT];
 #pragma unroll
-    for (int k = 0; k < HB_TPT; k++) {
+    for (int k = 0; k < TPT; k++) {
         const int j = tid + k * HB_THREADS;
         const int jc = max(min(j, N - 1), 0);
         tv[k] = false;
@@ -90,7 +103,7 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         }
     }
 #pragma unroll
-    for (int k = 0; k < HB_QPT; k++) qp[k] = qxy[min(tid + k * HB_THREADS, M - 1)];
+    for (int k = 0; k < QPT; k++) qp[k] = qxy[min(tid + k * HB_THREADS, M - 1)];
     for (int i = tid; i <= nbins; i += HB_THREADS) s_start[i] = 0;
     if (tid < HB_HIST) s_hist[tid] = 0;
     __syncthreads();
@@ -99,13 +112,13 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     // ---- 2. counting sort of the unflagged train features: the counting atomic returns the rank inside the bin
     auto bin_of = [&](float x, float y) -> int {
         if (MODE == 1) return min(max((int)floorf(y), 0), a.nby - 1);
-        const int cy = min(max((int)floorf(y / (float)HASH_CELL), 0), a.nby - 1);
-        const int cx = min(max((int)floorf(x / (float)HASH_CELL), 0), a.nbx - 1);
+        const int cy = min(max((int)floorf(div_cell(y)), 0), a.nby - 1);
+        const int cx = min(max((int)floorf(div_cell(x)), 0), a.nbx - 1);
         return cy * a.nbx + cx;
     };
-    int tbin[HB_TPT], trank[HB_TPT];
+    int tbin[TPT], trank[TPT];
 #pragma unroll
-    for (int k = 0; k < HB_TPT; k++) {
+    for (int k = 0; k < TPT; k++) {
         tbin[k] = bin_of(tp[k].x, tp[k].y);
         trank[k] = 0;
         if (tv[k]) trank[k] = atomicAdd(&s_start[tbin[k]], 1);
@@ -128,7 +141,7 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     __syncthreads();
     if (dbg) dbg[3] = clock64();
 #pragma unroll
-    for (int k = 0; k < HB_TPT; k++) {
+    for (int k = 0; k < TPT; k++) {
         if (tv[k]) {
             const int pos = s_start[tbin[k]] + trank[k];
             s_xy[pos] = tp[k];
@@ -156,7 +169,7 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
             R.s0 = s_start[ok ? R.y0 : 0];
             R.l0 = s_start[ok ? R.y1 + 1 : 0] - R.s0;
         } else {  // struct.cpp:71-83: the cells of one window row are contiguous
-            const int hy = (int)floorf(p.y / (float)HASH_CELL), hx = (int)floorf(p.x / (float)HASH_CELL);
+            const int hy = (int)floorf(div_cell(p.y)), hx = (int)floorf(div_cell(p.x));
             R.y0 = max(hy - a.csr, 0);
             R.y1 = min(hy + a.csr, a.nby - 1);
             R.x0 = max(hx - a.csr, 0);
@@ -189,9 +202,9 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     };
 
     // ---- 3. queries sorted by candidate count, heaviest first (needs the bin starts only: overlaps the scatter)
-    int qkey[HB_QPT], qrank[HB_QPT];
+    int qkey[QPT], qrank[QPT];
 #pragma unroll
-    for (int k = 0; k < HB_QPT; k++) {
+    for (int k = 0; k < QPT; k++) {
         const int q = tid + k * HB_THREADS;
         qkey[k] = 0, qrank[k] = 0;
         if (q < M) {
@@ -207,51 +220,22 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < HB_QPT; k++) {
+    for (int k = 0; k < QPT; k++) {
         const int q = tid + k * HB_THREADS;
         if (q < M) s_order[s_hist[qkey[k]] + qrank[k]] = (uint16_t)q;
     }
     __syncthreads();
     if (dbg) dbg[5] = clock64();
 
+    __builtin_amdgcn_s_setprio(0);
     // ---- 4. rounds of 512 queries in sorted order; odd rounds reverse the wave order so every wave gets a similar sum
-    const int rounds = (M + HB_THREADS - 1) / HB_THREADS;
-    auto slot_query = [&](int j) -> int {
+    constexpr int rounds = QPT;
+    auto slot_query = [&](int j, int count) -> int {
         const int slot = j * HB_THREADS + ((j & 1) ? (HB_WAVES - 1 - wv) : wv) * 64 + lane;
-        return (j < rounds && slot < M) ? (int)s_order[slot] : -1;
+        return (j < rounds && slot < count) ? (int)s_order[slot] : -1;
     };
-    int q = slot_query(0);
-    uint4 w0 = qd[2 * max(q, 0)], w1 = qd[2 * max(q, 0) + 1];
-    float2 p = qxy[max(q, 0)];
-    for (int j = 0; j < rounds; j++) {
-        const int qn = slot_query(j + 1);
-        const uint4 nw0 = qd[2 * max(qn, 0)], nw1 = qd[2 * max(qn, 0) + 1];  // next round's query: in flight during this round
-        const float2 np = qxy[max(qn, 0)];
-        if (q >= 0) {
-            const uint64_t d0 = ((uint64_t)w0.y << 32) | w0.x, d1 = ((uint64_t)w0.w << 32) | w0.z;
-            const uint64_t d2 = ((uint64_t)w1.y << 32) | w1.x, d3 = ((uint64_t)w1.w << 32) | w1.z;
-            uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
-            const Ranges R = ranges(p);
-            const int y0 = R.y0, y1 = R.y1, x0 = R.x0, x1 = R.x1;
-            const float fy0 = (float)y0, fy1 = (float)min((int)p.y + ROW_RADIUS, a.img_rows);
-            // one candidate; the LDS reads of the next one are issued before this one is reduced
-            auto eval = [&](const float2 r, const uint4 a0, const uint4 a1, const uint32_t id) {
-                bool ok;
-                if (MODE == 1) ok = (r.y >= fy0) && (r.y <= fy1);
-                else {
-                    const float dx = r.x - p.x, dy = r.y - p.y;
-                    ok = (dx * dx + dy * dy) < a.r2;
-                }
-                const int d = __popcll(d0 ^ (((uint64_t)a0.y << 32) | a0.x)) + __popcll(d1 ^ (((uint64_t)a0.w << 32) | a0.z)) +
-                              __popcll(d2 ^ (((uint64_t)a1.y << 32) | a1.x)) + __popcll(d3 ^ (((uint64_t)a1.w << 32) | a1.z));
-                const uint32_t key = ok ? (((uint32_t)d << 16) | id) : 0xFFFFFFFFu;
-                k2 = min(k2, max(k1, key));
-                k1 = min(k1, key);
-            };
-            // positions of the flattened index space: v in [c_k, c_{k+1}) lies in range k at LDS position v + o_k
-            // (scalars, not arrays: they must stay in VGPRs).  Software-pipelined by one candidate.
-            auto walk = [&](int total, int o0, int c1, int o1, int c2, int o2, int c3, int o3, int c4, int o4) {
-                if (total <= 0) return;
+    // positions of the flattened index space: v in [c_k, c_{k+1}) lies in range k at LDS position v + o_k
+    // (scalars and a macro, not arrays and a lambda: they must stay in VGPRs)
 #define LVT_POS_OF(dst, v)                          \
     {                                               \
         int o_ = o0;                                \
@@ -261,48 +245,201 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         if (NS > 4) o_ = ((v) >= c4) ? o4 : o_;     \
         dst = (v) + o_;                             \
     }
-                int it;
-                LVT_POS_OF(it, 0)
-                float2 r = s_xy[it];
-                uint4 a0 = s_desc[2 * it], a1 = s_desc[2 * it + 1];
-                uint32_t id = s_idx[it];
-                for (int v = 0; v < total; v++) {
-                    const int vn = min(v + 1, total - 1);
-                    int itn;
-                    LVT_POS_OF(itn, vn)
-                    const float2 rn = s_xy[itn];
-                    const uint4 b0 = s_desc[2 * itn], b1 = s_desc[2 * itn + 1];
-                    const uint32_t idn = s_idx[itn];
-                    eval(r, a0, a1, id);
-                    r = rn, a0 = b0, a1 = b1, id = idn;
-                }
-#undef LVT_POS_OF
-            };
-            if (MODE == 0 && NSP == 0) {
-                if (x0 <= x1)
-                    for (int by = y0; by <= y1; by++) {
-                        const int s = s_start[by * a.nbx + x0];
-                        walk(s_start[by * a.nbx + x1 + 1] - s, s, 0, 0, 0, 0, 0, 0, 0, 0);
-                    }
-            } else {
-                static_assert(NS <= 5, "range registers");
-                const int c1 = R.l0, c2 = c1 + R.l1, c3 = c2 + R.l2, c4 = c3 + R.l3;
-                walk(c4 + R.l4, R.s0, c1, R.s1 - c1, c2, R.s2 - c2, c3, R.s3 - c3, c4, R.s4 - c4);
+    // all candidates of the ranges, filter and distance in one pass (row mode, any-csr mode, over-long windows)
+    auto walk_all = [&](float2 p, float fy0, float fy1, uint64_t d0, uint64_t d1, uint64_t d2, uint64_t d3, uint32_t &k1, uint32_t &k2,
+                        int total, int o0, int c1, int o1, int c2, int o2, int c3, int o3, int c4, int o4) {
+        if (total <= 0) return;
+        int it;
+        LVT_POS_OF(it, 0)
+        float2 r = s_xy[it];
+        uint4 a0 = s_desc[2 * it], a1 = s_desc[2 * it + 1];
+        uint32_t id = s_idx[it];
+        for (int v = 0; v < total; v++) {  // software-pipelined by one candidate; the last prefetch reads one past (valid LDS)
+            int itn;
+            LVT_POS_OF(itn, v + 1)
+            const float2 rn = s_xy[itn];
+            const uint4 b0 = s_desc[2 * itn], b1 = s_desc[2 * itn + 1];
+            const uint32_t idn = s_idx[itn];
+            bool ok;
+            if (MODE == 1) ok = (r.y >= fy0) && (r.y <= fy1);
+            else {
+                const float dx = r.x - p.x, dy = r.y - p.y;
+                ok = (dx * dx + dy * dy) < a.r2;
             }
-            int4 o;
-            o.x = (k1 == 0xFFFFFFFFu) ? -1 : (int)(k1 & 0xFFFFu);
-            o.y = (k1 == 0xFFFFFFFFu) ? 0x7FFFFFFF : (int)(k1 >> 16);
-            o.z = (k2 == 0xFFFFFFFFu) ? -1 : (int)(k2 & 0xFFFFu);
-            o.w = (k2 == 0xFFFFFFFFu) ? 0x7FFFFFFF : (int)(k2 >> 16);
-            out[q] = o;
+            const int d = __popcll(d0 ^ (((uint64_t)a0.y << 32) | a0.x)) + __popcll(d1 ^ (((uint64_t)a0.w << 32) | a0.z)) +
+                          __popcll(d2 ^ (((uint64_t)a1.y << 32) | a1.x)) + __popcll(d3 ^ (((uint64_t)a1.w << 32) | a1.z));
+            const uint32_t key = ok ? (((uint32_t)d << 16) | id) : 0xFFFFFFFFu;
+            k2 = min(k2, max(k1, key));
+            k1 = min(k1, key);
+            r = rn, a0 = b0, a1 = b1, id = idn;
         }
-        q = qn, w0 = nw0, w1 = nw1, p = np;
+    };
+    auto match_all = [&](int q, float2 p, uint4 w0, uint4 w1, const Ranges &R) {
+        const uint64_t d0 = ((uint64_t)w0.y << 32) | w0.x, d1 = ((uint64_t)w0.w << 32) | w0.z;
+        const uint64_t d2 = ((uint64_t)w1.y << 32) | w1.x, d3 = ((uint64_t)w1.w << 32) | w1.z;
+        uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+        const float fy0 = (float)R.y0, fy1 = (float)min((int)p.y + ROW_RADIUS, a.img_rows);
+        if (MODE == 0 && NSP == 0) {
+            if (R.x0 <= R.x1)
+                for (int by = R.y0; by <= R.y1; by++) {
+                    const int s = s_start[by * a.nbx + R.x0];
+                    walk_all(p, fy0, fy1, d0, d1, d2, d3, k1, k2, s_start[by * a.nbx + R.x1 + 1] - s, s, 0, 0, 0, 0, 0, 0, 0, 0);
+                }
+        } else {
+            static_assert(NS <= 5, "range registers");
+            const int c1 = R.l0, c2 = c1 + R.l1, c3 = c2 + R.l2, c4 = c3 + R.l3;
+            walk_all(p, fy0, fy1, d0, d1, d2, d3, k1, k2, c4 + R.l4, R.s0, c1, R.s1 - c1, c2, R.s2 - c2, c3, R.s3 - c3, c4, R.s4 - c4);
+        }
+        int4 o;
+        o.x = (k1 == 0xFFFFFFFFu) ? -1 : (int)(k1 & 0xFFFFu);
+        o.y = (k1 == 0xFFFFFFFFu) ? 0x7FFFFFFF : (int)(k1 >> 16);
+        o.z = (k2 == 0xFFFFFFFFu) ? -1 : (int)(k2 & 0xFFFFu);
+        o.w = (k2 == 0xFFFFFFFFu) ? 0x7FFFFFFF : (int)(k2 >> 16);
+        out[q] = o;
+    };
+
+    constexpr bool TWO_STAGE = (MODE == 0 && NSP > 0);
+    if (!TWO_STAGE) {
+        int q = slot_query(0, M);
+        uint4 w0 = qd[2 * max(q, 0)], w1 = qd[2 * max(q, 0) + 1];
+        float2 p = qxy[max(q, 0)];
+        for (int j = 0; j < rounds; j++) {
+            const int qn = slot_query(j + 1, M);
+            const uint4 nw0 = qd[2 * max(qn, 0)], nw1 = qd[2 * max(qn, 0) + 1];  // next round's query: in flight during this round
+            const float2 np = qxy[max(qn, 0)];
+            if (q >= 0) match_all(q, p, w0, w1, ranges(p));
+            q = qn, w0 = nw0, w1 = nw1, p = np;
+        }
+    } else {
+        // ---- 4a. the radius test alone over every window candidate (8 B of LDS and ~12 instructions each): one bit per
+        //          candidate of the flattened index space.  Only ~1/3 of a 3x3-cell window lies inside the circle, so
+        //          the descriptor work (40 B, ~30 instructions) is kept for stage 4b.
+        if (tid < HB_HIST) s_hist[tid] = 0;
+        int aq[QPT], akey[QPT], arank[QPT];
+        {
+            int q = slot_query(0, M);
+            float2 p = qxy[max(q, 0)];
+#pragma unroll
+            for (int j = 0; j < QPT; j++) {
+                aq[j] = -1, akey[j] = 0, arank[j] = 0;
+                {
+                    const int qn = slot_query(j + 1, M);
+                    const float2 np = qxy[max(qn, 0)];
+                    if (q >= 0) {
+                        const Ranges R = ranges(p);
+                        const int c1 = R.l0, c2 = c1 + R.l1, c3 = c2 + R.l2, c4 = c3 + R.l3, total = c4 + R.l4;
+                        const int o0 = R.s0, o1 = R.s1 - c1, o2 = R.s2 - c2, o3 = R.s3 - c3, o4 = R.s4 - c4;
+                        if (total > 64) {  // does not fit the mask: matched here and now (rare)
+                            match_all(q, p, qd[2 * q], qd[2 * q + 1], R);
+                        } else {
+                            uint32_t lo = 0, hi = 0;
+                            const int t0 = min(total, 32);
+#pragma unroll 4
+                            for (int v = 0; v < t0; v++) {
+                                int it;
+                                LVT_POS_OF(it, v)
+                                const float2 r = s_xy[it];
+                                const float dx = r.x - p.x, dy = r.y - p.y;
+                                lo |= ((dx * dx + dy * dy) < a.r2) ? (1u << v) : 0u;
+                            }
+                            for (int v = 32; v < total; v++) {
+                                int it;
+                                LVT_POS_OF(it, v)
+                                const float2 r = s_xy[it];
+                                const float dx = r.x - p.x, dy = r.y - p.y;
+                                hi |= ((dx * dx + dy * dy) < a.r2) ? (1u << (v - 32)) : 0u;
+                            }
+                            s_mask[q] = make_uint2(lo, hi);
+                            aq[j] = q;
+                            akey[j] = HB_HIST - 1 - min(__popc(lo) + __popc(hi), HB_HIST - 1);
+                        }
+                    }
+                    q = qn, p = np;
+                }
+            }
+        }
+        // ---- 4b. the queries again, now sorted by the number of candidates inside the circle
+        __syncthreads();  // s_hist zeroed, every stage-4a read of s_order done
+#pragma unroll
+        for (int j = 0; j < QPT; j++)
+            if (aq[j] >= 0) arank[j] = atomicAdd(&s_hist[akey[j]], 1);
+        __syncthreads();
+        if (wv == 0) {
+            const int v = s_hist[lane];
+            const int incl = wave_incl_scan(v);
+            s_hist[lane] = incl - v;
+            if (lane == 63) s_scan[0] = incl;
+        }
+        __syncthreads();
+        const int M2 = s_scan[0];
+#pragma unroll
+        for (int j = 0; j < QPT; j++)
+            if (aq[j] >= 0) s_order[s_hist[akey[j]] + arank[j]] = (uint16_t)aq[j];
+        __syncthreads();
+        if (dbg) dbg[7] = clock64();
+
+        int q = slot_query(0, M2);
+        uint4 w0 = qd[2 * max(q, 0)], w1 = qd[2 * max(q, 0) + 1];
+        float2 p = qxy[max(q, 0)];
+        for (int j = 0; j < rounds; j++) {
+            const int qn = slot_query(j + 1, M2);
+            const uint4 nw0 = qd[2 * max(qn, 0)], nw1 = qd[2 * max(qn, 0) + 1];
+            const float2 np = qxy[max(qn, 0)];
+            if (q >= 0) {
+                const uint64_t d0 = ((uint64_t)w0.y << 32) | w0.x, d1 = ((uint64_t)w0.w << 32) | w0.z;
+                const uint64_t d2 = ((uint64_t)w1.y << 32) | w1.x, d3 = ((uint64_t)w1.w << 32) | w1.z;
+                uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+                const Ranges R = ranges(p);
+                const int c1 = R.l0, c2 = c1 + R.l1, c3 = c2 + R.l2, c4 = c3 + R.l3;
+                const int o0 = R.s0, o1 = R.s1 - c1, o2 = R.s2 - c2, o3 = R.s3 - c3, o4 = R.s4 - c4;
+                const uint2 mk = s_mask[q];
+                auto walk_bits = [&](uint32_t m, int base) {  // set bits of m, software-pipelined by one candidate
+                    if (m == 0) return;
+                    int it;
+                    {
+                        const int v = base + __ffs((int)m) - 1;
+                        LVT_POS_OF(it, v)
+                    }
+                    m &= m - 1;
+                    uint4 a0 = s_desc[2 * it], a1 = s_desc[2 * it + 1];
+                    uint32_t id = s_idx[it];
+                    for (;;) {
+                        const bool more = m != 0;
+                        int itn;
+                        {
+                            const int v = base + ((__ffs((int)m) - 1) & 31);
+                            LVT_POS_OF(itn, v)
+                        }
+                        m &= m - 1;
+                        const uint4 b0 = s_desc[2 * itn], b1 = s_desc[2 * itn + 1];
+                        const uint32_t idn = s_idx[itn];
+                        const int d = __popcll(d0 ^ (((uint64_t)a0.y << 32) | a0.x)) + __popcll(d1 ^ (((uint64_t)a0.w << 32) | a0.z)) +
+                                      __popcll(d2 ^ (((uint64_t)a1.y << 32) | a1.x)) + __popcll(d3 ^ (((uint64_t)a1.w << 32) | a1.z));
+                        const uint32_t key = ((uint32_t)d << 16) | id;
+                        k2 = min(k2, max(k1, key));
+                        k1 = min(k1, key);
+                        if (!more) break;
+                        a0 = b0, a1 = b1, id = idn;
+                    }
+                };
+                walk_bits(mk.x, 0);
+                walk_bits(mk.y, 32);
+                int4 o;
+                o.x = (k1 == 0xFFFFFFFFu) ? -1 : (int)(k1 & 0xFFFFu);
+                o.y = (k1 == 0xFFFFFFFFu) ? 0x7FFFFFFF : (int)(k1 >> 16);
+                o.z = (k2 == 0xFFFFFFFFu) ? -1 : (int)(k2 & 0xFFFFu);
+                o.w = (k2 == 0xFFFFFFFFu) ? 0x7FFFFFFF : (int)(k2 >> 16);
+                out[q] = o;
+            }
+            q = qn, w0 = nw0, w1 = nw1, p = np;
+        }
     }
+#undef LVT_POS_OF
     if (dbg) dbg[6] = clock64();
 }
 
 static inline size_t hamming_lds_bytes(int N, int M, int nbins) {
-    return (size_t)N * 32 + (size_t)N * 8 + (size_t)(nbins + 1) * 4 + (size_t)((N + 1) & ~1) * 2 + (size_t)((M + 1) & ~1) * 2 + 16;
+    return (size_t)N * 32 + (size_t)N * 8 + (size_t)M * 8 + (size_t)(nbins + 1) * 4 + (size_t)((N + 1) & ~1) * 2 + (size_t)((M + 1) & ~1) * 2 + 16;
 }
 
 }  // namespace lvt

@@ -963,7 +963,7 @@ LVT_API float lvt_amd_hamming_match_batched(const void *q_desc, const void *q_xy
     a.M = M, a.N = N, a.r2 = r2, a.img_rows = img_rows, a.img_cols = img_cols;
     a.dbg = nullptr;
     long long *d_dbg = nullptr;
-    if (std::getenv("LVT_AMD_HAMMING_DEBUG") && hipMalloc((void **)&d_dbg, 64) == hipSuccess) a.dbg = d_dbg;
+    if (std::getenv("LVT_AMD_HAMMING_DEBUG") && hipMalloc((void **)&d_dbg, 64) == hipSuccess && hipMemset(d_dbg, 0, 64) == hipSuccess) a.dbg = d_dbg;
     if (mode == 1) {
         a.nbx = 1, a.nby = img_rows + 1, a.csr = 0;
     } else {
@@ -986,7 +986,23 @@ LVT_API float lvt_amd_hamming_match_batched(const void *q_desc, const void *q_xy
     }
     float ms = -1.0f;
     // the variant fixes how many candidate ranges a query keeps in registers (k_hamming.hip)
-    void (*kern)(HammingArgs) = (mode == 1) ? k_hamming_batched<1, 1> : (a.csr == 1) ? k_hamming_batched<0, 3> : (a.csr == 2) ? k_hamming_batched<0, 5> : k_hamming_batched<0, 0>;
+    void (*kern)(HammingArgs) = nullptr;
+    {
+        const int qpt = (M + HB_THREADS - 1) / HB_THREADS;
+        const int tpt = (N + HB_THREADS - 1) / HB_THREADS;
+#define LVT_PICK_T(MODE_, NSP_, Q_)                                                                                               \
+    ((tpt == 1) ? k_hamming_batched<MODE_, NSP_, Q_, 1> : (tpt == 2) ? k_hamming_batched<MODE_, NSP_, Q_, 2> :                   \
+     (tpt == 3) ? k_hamming_batched<MODE_, NSP_, Q_, 3> : k_hamming_batched<MODE_, NSP_, Q_, 4>)
+#define LVT_PICK(MODE_, NSP_)                                                                                                     \
+    kern = (qpt == 1) ? LVT_PICK_T(MODE_, NSP_, 1) : (qpt == 2) ? LVT_PICK_T(MODE_, NSP_, 2) : (qpt == 3) ? LVT_PICK_T(MODE_, NSP_, 3) \
+                                                                                                          : LVT_PICK_T(MODE_, NSP_, 4)
+        if (mode == 1) LVT_PICK(1, 1);
+        else if (a.csr == 1) LVT_PICK(0, 3);
+        else if (a.csr == 2) LVT_PICK(0, 5);
+        else LVT_PICK(0, 0);
+#undef LVT_PICK_T
+#undef LVT_PICK
+    }
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipEventRecord(e0, st);
     hipLaunchKernelGGL(kern, dim3(B), dim3(HB_THREADS), lds, st, a);
@@ -1002,9 +1018,10 @@ LVT_API float lvt_amd_hamming_match_batched(const void *q_desc, const void *q_xy
     (void)hipEventDestroy(e1);
     if (d_dbg) {
         long long hd[8] = {};
-        (void)hipMemcpy(hd, d_dbg, 56, hipMemcpyDeviceToHost);
-        std::fprintf(stderr, "hamming phases (cycles): load+zero %lld count %lld scan %lld scatter+qcount %lld qsort %lld queries %lld total %lld\n", hd[1] - hd[0],
-                     hd[2] - hd[1], hd[3] - hd[2], hd[4] - hd[3], hd[5] - hd[4], hd[6] - hd[5], hd[6] - hd[0]);
+        (void)hipMemcpy(hd, d_dbg, 64, hipMemcpyDeviceToHost);
+        if (hd[7] == 0) hd[7] = hd[5];
+        std::fprintf(stderr, "hamming phases (cycles): load+zero %lld count %lld scan %lld scatter+qcount %lld qsort %lld radius+qsort2 %lld descriptors %lld total %lld\n",
+                     hd[1] - hd[0], hd[2] - hd[1], hd[3] - hd[2], hd[4] - hd[3], hd[5] - hd[4], hd[7] - hd[5], hd[6] - hd[7], hd[6] - hd[0]);
         (void)hipFree(d_dbg);
     }
     return (ee != hipSuccess || ms < 0) ? -1.0f : ms * 1000.0f;

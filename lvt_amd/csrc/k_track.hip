@@ -792,29 +792,33 @@ __device__ __forceinline__ void cam_refresh(CamRegs &c, const double r[4], const
     }
 }
 __device__ bool solve6_spd(const double *H /*6x6*/, const double *b, double *x) {
-    double L[36];
+    // Cholesky (Eigen LLT as used by g2o's dense linear solver).  One thread runs this, so the chain of fp64 divisions
+    // is the cost: each column's 1 / L_jj is formed once and reused by the column scaling and both substitutions
+    // (6 divisions instead of 27; the quotients differ from v / L_jj by at most one rounding).
+    double L[36], inv[6];
     for (int i = 0; i < 36; i++) L[i] = 0;
     for (int j = 0; j < 6; j++) {
         double s = H[6 * j + j];
         for (int k = 0; k < j; k++) s -= L[6 * j + k] * L[6 * j + k];
         if (!(s > 0) || !isfinite(s)) return false;
         L[6 * j + j] = sqrt(s);
+        inv[j] = 1.0 / L[6 * j + j];
         for (int i = j + 1; i < 6; i++) {
             double v = H[6 * i + j];
             for (int k = 0; k < j; k++) v -= L[6 * i + k] * L[6 * j + k];
-            L[6 * i + j] = v / L[6 * j + j];
+            L[6 * i + j] = v * inv[j];
         }
     }
     double y[6];
     for (int i = 0; i < 6; i++) {
         double v = b[i];
         for (int k = 0; k < i; k++) v -= L[6 * i + k] * y[k];
-        y[i] = v / L[6 * i + i];
+        y[i] = v * inv[i];
     }
     for (int i = 5; i >= 0; i--) {
         double v = y[i];
         for (int k = i + 1; k < 6; k++) v -= L[6 * k + i] * x[k];
-        x[i] = v / L[6 * i + i];
+        x[i] = v * inv[i];
     }
     return true;
 }
@@ -825,42 +829,57 @@ __device__ __forceinline__ double wave_sum(double v) {
 }
 
 constexpr int PNP_THREADS = 256;
+constexpr int PNP_ILP = 3;  // edges per thread in flight in one sweep iteration (KITTI: ~650 edges = one iteration)
 
-// block-wide sum of NV doubles per thread; result valid in all threads.
+// block-wide sum of NV doubles per thread.  NV < 8: result in v[] of every thread.  NV >= 8: result in dst[0..NV-1] (LDS).
 // Large NV: partials go through LDS ([NV][PNP_THREADS] doubles), wave w sums values w, w+NW, ... (PNP_THREADS/64
 // partials per lane, then one 64-lane butterfly), interleaved so the butterfly chains overlap.
 constexpr int PNP_NW = PNP_THREADS / 64;
 template <int NV>
-__device__ __forceinline__ void block_sum(double (&v)[NV], double *red) {
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *red, double *dst = nullptr, long long *bs = nullptr) {
     const int w = wave_id(), l = lane_id(), tid = threadIdx.x;
     if (NV >= 8) {
-        double *part = red + 128;  // [NV][PNP_THREADS]
+        // transposed partials part[k][tid], then thread (k, j) adds the 32 entries j, j + 8, j + 16, ... of row k (one
+        // address register, immediate offsets, no predicates), then thread k adds the 8 segment sums.  No cross-lane
+        // traffic, three barriers.  Row stride 264 doubles: rows k and k + 4 share banks, nothing else does.
+        constexpr int SEG = PNP_THREADS / 32, SLEN = PNP_THREADS / SEG;
+        constexpr int STRIDE = PNP_THREADS + 8;
+        static_assert(NV * SEG <= PNP_THREADS && PNP_THREADS % SEG == 0, "block_sum layout");
+        double *part = red + 384;  // [NV][STRIDE]
+        double *seg = red + 128;   // [NV][SEG]
+        long long b0 = clock64();
         __syncthreads();
+        long long b1 = clock64();
 #pragma unroll
-        for (int k = 0; k < NV; k++) part[k * PNP_THREADS + tid] = v[k];
+        for (int k = 0; k < NV; k++) part[k * STRIDE + tid] = v[k];
         __syncthreads();
-        constexpr int PER = (NV + PNP_NW - 1) / PNP_NW;
-        double sacc[PER];
+        long long b2 = clock64();
+        if (tid < NV * SEG) {
+            const double *p = part + (tid / SEG) * STRIDE + (tid % SEG);
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-        for (int u = 0; u < PER; u++) {  // branch-free so the PER butterfly chains interleave
-            const int k = min(w + PNP_NW * u, NV - 1);
-            const double *p = part + k * PNP_THREADS;
+            for (int u = 0; u < SLEN; u += 4) {
+                s0 += p[SEG * u];
+                s1 += p[SEG * (u + 1)];
+                s2 += p[SEG * (u + 2)];
+                s3 += p[SEG * (u + 3)];
+            }
+            seg[tid] = (s0 + s1) + (s2 + s3);
+        }
+        __syncthreads();
+        long long b3 = clock64();
+        if (tid < NV) {
             double s = 0.0;
 #pragma unroll
-            for (int m = 0; m < PNP_NW; m++) s += p[l + 64 * m];
-            sacc[u] = s;
+            for (int j = 0; j < SEG; j++) s += seg[tid * SEG + j];
+            dst[tid] = s;
         }
-#pragma unroll
-        for (int d = 32; d >= 1; d >>= 1) {
-#pragma unroll
-            for (int u = 0; u < PER; u++) sacc[u] += __shfl_xor(sacc[u], d, 64);
-        }
-#pragma unroll
-        for (int u = 0; u < PER; u++)
-            if (l == 0 && w + PNP_NW * u < NV) red[w + PNP_NW * u] = sacc[u];
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < NV; k++) v[k] = red[k];
+        long long b4 = clock64();  // the NV sums are in dst[0..NV-1]; v[] is NOT updated (only thread 0 wants them)
+        if (bs) {
+            long long b5 = clock64();
+            bs[0] += b1 - b0, bs[1] += b2 - b1, bs[2] += b3 - b2, bs[3] += b4 - b3, bs[4] += b5 - b4;
+        }
     } else {
 #pragma unroll
         for (int k = 0; k < NV; k++) v[k] = wave_sum(v[k]);
@@ -880,9 +899,16 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red) {
     }
 }
 
+// State of the solve.  Everything only thread 0 computes with lives HERE, not in registers: a 6x6 system, its
+// right-hand side and the step would otherwise sit in ~110 VGPRs of every lane across the sweeps.
 struct PnpShared {
-    double r[4], t[3];   // current estimate, published by thread 0
-    int cont, ok, accepted;
+    double r[4], t[3];    // current estimate, published by thread 0
+    double br[4], bt[3];  // push(): the estimate before the trial
+    double sys[2][28];    // H (upper triangle), b, chi2: [cur] at the current estimate, [cur ^ 1] receives a trial's
+    int cur;
+    double dx[6];
+    double lambda, ni;
+    int cont, ok, accepted, ok2;
 };
 
 // One sweep over the active edges at the camera `cam`: errors (stored), robust chi2 partial in acc[27], and -- when
@@ -894,26 +920,32 @@ __device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3]
                                           const int8_t *__restrict__ level, int n, double (&acc)[28]) {
 #pragma unroll
     for (int k = 0; k < 28; k++) acc[k] = 0.0;
-#pragma unroll 2
-    for (int i = threadIdx.x; i < n; i += PNP_THREADS) {
-        if (level[i] != 0) continue;
+    // One edge, straight-line: an inactive slot (past the end, or an edge of level 1) runs the same instructions on a
+    // clamped index with its weights selected to zero, so the PNP_ILP edges of one iteration sit in one basic block
+    // and their fp64 dependency chains interleave (there is one wavefront per SIMD: nothing else hides the latency).
+    auto edge = [&](int i_raw) {
+        const int i = min(i_raw, n - 1);
+        const bool active = (i_raw < n) && (level[i] == 0);
         const double x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2];
         const double *c = cam.w2i;
         const double px = ((c[0] * x + c[1] * y) + c[2] * z) + c[3];
         const double py = ((c[4] * x + c[5] * y) + c[6] * z) + c[7];
         const double pz = ((c[8] * x + c[9] * y) + c[10] * z) + c[11];
         const double e0 = px / pz - (double)obs[2 * i], e1 = py / pz - (double)obs[2 * i + 1];
-        err[2 * i] = e0;
-        err[2 * i + 1] = e1;
+        if (active) {
+            err[2 * i] = e0;
+            err[2 * i + 1] = e1;
+        }
         const double aux = dsqrReci * (e0 * e0 + e1 * e1) + 1.0;
-        acc[27] += dsqr * log(aux);
+        const double chi = dsqr * log(aux);
+        acc[27] += active ? chi : 0.0;
         if (WANT_H) {
             const double *w = cam.w2n;
             const double pcx = ((w[0] * x + w[1] * y) + w[2] * z) + w[3];
             const double pcy = ((w[4] * x + w[5] * y) + w[6] * z) + w[7];
             const double pcz = ((w[8] * x + w[9] * y) + w[10] * z) + w[11];
             const double ipz2 = 1.0 / (pcz * pcz);
-            const double ipz2fx = ipz2 * fx, ipz2fy = ipz2 * fy;
+            const double ipz2fx = active ? ipz2 * fx : 0.0, ipz2fy = active ? ipz2 * fy : 0.0;
             const double pwt[3] = {x - ct[0], y - ct[1], z - ct[2]};
             double J0[6], J1[6];
             // dp = dRd{x,y,z} * pwt with dRd* = dRid* * w2n[:, :3]  
@@ -941,8 +973,8 @@ __device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3]
                 J0[cc] = (pcz * dp0 - pcx * dp2) * ipz2fx;
                 J1[cc] = (pcz * dp1 - pcy * dp2) * ipz2fy;
             }
-            const double rho1 = 1.0 / aux;
-            const double wr0 = -e0 * rho1, wr1 = -e1 * rho1;
+            const double rho1 = active ? 1.0 / aux : 0.0;
+            const double wr0 = active ? -e0 * rho1 : 0.0, wr1 = active ? -e1 * rho1 : 0.0;
             int k = 0;
 #pragma unroll
             for (int a = 0; a < 6; a++) {
@@ -952,6 +984,11 @@ __device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3]
 #pragma unroll
             for (int a = 0; a < 6; a++) acc[21 + a] += J0[a] * wr0 + J1[a] * wr1;
         }
+    };
+    if (n <= 0) return;
+    for (int i = threadIdx.x; i < n; i += PNP_ILP * PNP_THREADS) {
+#pragma unroll
+        for (int u = 0; u < PNP_ILP; u++) edge(i + u * PNP_THREADS);
     }
 }
 
@@ -960,10 +997,11 @@ __device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3]
 // accumulates H and b at the trial estimate: when the trial is ACCEPTED, the next solve()'s computeActiveErrors and
 // buildSystem would recompute exactly those values (same estimate, same active edges, same arithmetic), so they are
 // reused; a rejected last trial or a new pass falls back to a fresh sweep.
-__device__ void pnp_run(const Params &prm, const Pose &prior, const double *X, const float *obs, double *err, int8_t *level,
+__device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, const double *X, const float *obs, double *err, int8_t *level,
                         int n, PnpShared &sh, double *red, Pose &result, int &inliers, int &solve_calls, long long *dbg = nullptr) {
     const int tid = threadIdx.x;
-    long long t_sweep = 0, t_solve = 0, t_dec = 0, t_all = clock64();
+    long long t_sweep = 0, t_solve = 0, t_dec = 0, t_red = 0, t_all = clock64();
+    long long bs[5] = {0, 0, 0, 0, 0};
     const double fx = prm.fx, fy = prm.fy, cx = prm.cx, cy = prm.cy;
     const double mono_chi = sqrt(REPROJ_TH2);
     const double dsqr = mono_chi * mono_chi;
@@ -976,6 +1014,7 @@ __device__ void pnp_run(const Params &prm, const Pose &prior, const double *X, c
         q_normalize(r);
         for (int k = 0; k < 4; k++) sh.r[k] = r[k];
         for (int k = 0; k < 3; k++) sh.t[k] = prior.p[k];
+        sh.cur = 0;
     }
     __syncthreads();
     CamRegs cam;
@@ -993,97 +1032,107 @@ __device__ void pnp_run(const Params &prm, const Pose &prior, const double *X, c
         for (int i = tid; i < n; i += PNP_THREADS) na[0] += (level[i] == 0) ? 1.0 : 0.0;
         block_sum<1>(na, red);
         const bool any_active = na[0] > 0.0;
-        bool ok = true;             // uniform across the block (decisions are broadcast through sh)
-        double lambda = 0, ni = 2;  // meaningful on thread 0
-        bool have_sys = false;      // acc[] holds chi2 / H / b at the current estimate
-        double acc[28];
+        bool ok = true;         // uniform across the block (decisions are broadcast through sh)
+        bool have_sys = false;  // sh.sys holds chi2 / H / b at the current estimate
         for (int iter = 0; iter < 5 && ok && any_active; iter++) {
             calls++;
             long long c0 = clock64();
             if (!have_sys) {
+                double acc[28];
                 pnp_sweep<true>(cam, ct, fx, fy, dsqr, dsqrReci, X, obs, err, level, n, acc);
-                block_sum<28>(acc, red);
+                block_sum<28>(acc, red, sh.sys[sh.cur]);
             }
             t_sweep += clock64() - c0;
-            double currentChi = acc[27];
-            double H[36], bb[6], dx[6];
-            if (tid == 0) {
+            if (tid == 0 && iter == 0) {
+                double maxDiag = 0;
                 int k = 0;
-                for (int a = 0; a < 6; a++)
-                    for (int cc = a; cc < 6; cc++) {
-                        H[6 * a + cc] = acc[k];
-                        H[6 * cc + a] = acc[k];
-                        k++;
-                    }
-                for (int a = 0; a < 6; a++) bb[a] = acc[21 + a];
-                if (iter == 0) {
-                    double maxDiag = 0;
-                    for (int j = 0; j < 6; j++) maxDiag = fmax(fabs(H[6 * j + j]), maxDiag);
-                    lambda = 1e-5 * maxDiag;
-                    ni = 2;
+                for (int a = 0; a < 6; a++) {
+                    maxDiag = fmax(fabs(sh.sys[sh.cur][k]), maxDiag);  // diagonal entries of the packed upper triangle
+                    k += 6 - a;
                 }
+                sh.lambda = 1e-5 * maxDiag;
+                sh.ni = 2;
             }
             const bool speculate = (iter < 4);  // there is a next solve() in this pass that could reuse the system
             int qmax = 0;
             bool cont;
             do {
-                double br[4], bt[3];  // push()
-                bool ok2 = true;
                 long long c1 = clock64();
                 if (tid == 0) {
-                    for (int k = 0; k < 4; k++) br[k] = cr[k];
-                    for (int k = 0; k < 3; k++) bt[k] = ct[k];
-                    double Hl[36];
-                    for (int a = 0; a < 36; a++) Hl[a] = H[a];
+                    for (int k = 0; k < 4; k++) sh.br[k] = cr[k];  // push()
+                    for (int k = 0; k < 3; k++) sh.bt[k] = ct[k];
+                    double Hl[36], bb[6], dx[6];
+                    const double *sys = sh.sys[sh.cur];
+                    int k = 0;
+                    for (int a = 0; a < 6; a++)
+                        for (int cc = a; cc < 6; cc++) {
+                            Hl[6 * a + cc] = sys[k];
+                            Hl[6 * cc + a] = sys[k];
+                            k++;
+                        }
+                    const double lambda = sh.lambda;
                     for (int a = 0; a < 6; a++) Hl[7 * a] += lambda;
-                    for (int a = 0; a < 6; a++) dx[a] = 0;
-                    ok2 = solve6_spd(Hl, bb, dx);
+                    for (int a = 0; a < 6; a++) bb[a] = sys[21 + a], dx[a] = 0;
+                    sh.ok2 = solve6_spd(Hl, bb, dx) ? 1 : 0;
+                    for (int a = 0; a < 6; a++) sh.dx[a] = dx[a];
                     // SBACam::update
                     double nt[3], qr[4], nr[4];
-                    for (int k = 0; k < 3; k++) nt[k] = ct[k] + dx[k];
+                    for (int k2 = 0; k2 < 3; k2++) nt[k2] = ct[k2] + dx[k2];
                     qr[1] = dx[3], qr[2] = dx[4], qr[3] = dx[5];
                     qr[0] = sqrt(1.0 - (dx[3] * dx[3] + dx[4] * dx[4] + dx[5] * dx[5]));
                     q_mul(cr, qr, nr);
                     q_normalize(nr);
-                    for (int k = 0; k < 4; k++) sh.r[k] = nr[k];
-                    for (int k = 0; k < 3; k++) sh.t[k] = nt[k];
+                    for (int k2 = 0; k2 < 4; k2++) sh.r[k2] = nr[k2];
+                    for (int k2 = 0; k2 < 3; k2++) sh.t[k2] = nt[k2];
                 }
                 t_solve += clock64() - c1;
                 __syncthreads();
                 load_cam();
                 c1 = clock64();
-                if (speculate) {
-                    pnp_sweep<true>(cam, ct, fx, fy, dsqr, dsqrReci, X, obs, err, level, n, acc);
-                    block_sum<28>(acc, red);
-                } else {
-                    pnp_sweep<false>(cam, ct, fx, fy, dsqr, dsqrReci, X, obs, err, level, n, acc);
-                    double ch[1] = {acc[27]};
-                    block_sum<1>(ch, red);
-                    acc[27] = ch[0];
+                double tempChi;
+                {
+                    double acc[28];
+                    if (speculate) {
+                        pnp_sweep<true>(cam, ct, fx, fy, dsqr, dsqrReci, X, obs, err, level, n, acc);
+                        const long long c2 = clock64();
+                        block_sum<28>(acc, red, sh.sys[sh.cur ^ 1], bs);  // the trial's system goes to the spare slot
+                        t_red += clock64() - c2;
+                        tempChi = sh.sys[sh.cur ^ 1][27];
+                    } else {
+                        pnp_sweep<false>(cam, ct, fx, fy, dsqr, dsqrReci, X, obs, err, level, n, acc);
+                        double ch[1] = {acc[27]};
+                        block_sum<1>(ch, red);
+                        tempChi = ch[0];
+                    }
                 }
-                double tempChi = acc[27];
                 t_sweep += clock64() - c1;
                 c1 = clock64();
                 if (tid == 0) {
-                    if (!ok2) tempChi = 1.7976931348623157e308;
+                    if (!sh.ok2) tempChi = 1.7976931348623157e308;
+                    const double *sys = sh.sys[sh.cur];
+                    const double currentChi = sys[27];
+                    double lambda = sh.lambda, ni = sh.ni;
                     double rho = currentChi - tempChi;
                     double scale = 0;
-                    for (int j = 0; j < 6; j++) scale += dx[j] * (lambda * dx[j] + bb[j]);
+                    for (int j = 0; j < 6; j++) scale += sh.dx[j] * (lambda * sh.dx[j] + sys[21 + j]);
                     scale += 1e-3;
                     rho /= scale;
                     const bool accept = (rho > 0 && isfinite(tempChi));
                     if (accept) {
-                        double alpha = 1. - pow((2 * rho - 1), 3.0);
+                        const double tr = 2 * rho - 1;
+                        double alpha = 1. - tr * tr * tr;  // g2o: pow(2 rho - 1, 3)
                         alpha = fmin(alpha, 2.0 / 3.0);
                         const double scaleFactor = fmax(1.0 / 3.0, alpha);
                         lambda *= scaleFactor;
                         ni = 2;
+                        if (speculate) sh.cur ^= 1;  // the trial's system IS the system of the next solve()
                     } else {
                         lambda *= ni;
                         ni *= 2;
-                        for (int k = 0; k < 4; k++) sh.r[k] = br[k];  // pop(): edge errors stay those of the rejected trial
-                        for (int k = 0; k < 3; k++) sh.t[k] = bt[k];
+                        for (int k = 0; k < 4; k++) sh.r[k] = sh.br[k];  // pop(): edge errors stay those of the rejected trial
+                        for (int k = 0; k < 3; k++) sh.t[k] = sh.bt[k];
                     }
+                    sh.lambda = lambda, sh.ni = ni;
                     qmax++;
                     const int c = (rho < 0 && qmax < 10) ? 1 : 0;
                     sh.cont = c;
@@ -1092,10 +1141,10 @@ __device__ void pnp_run(const Params &prm, const Pose &prior, const double *X, c
                 }
                 t_dec += clock64() - c1;
                 __syncthreads();
-                load_cam();
+                if (!sh.accepted) load_cam();  // pop() restored the old estimate; an accepted trial's camera is already loaded
                 cont = sh.cont != 0;
                 ok = sh.ok != 0;
-                have_sys = speculate && (sh.accepted != 0);  // acc[] = system at the (accepted) current estimate
+                have_sys = speculate && (sh.accepted != 0);  // sh.sys = system at the (accepted) current estimate
                 __syncthreads();  // sh.cont / sh.r consumed before thread 0 publishes again
             } while (cont);
         }
@@ -1114,9 +1163,33 @@ __device__ void pnp_run(const Params &prm, const Pose &prior, const double *X, c
     for (int k = 0; k < 4; k++) result.q[k] = cr[k];
     for (int k = 0; k < 3; k++) result.p[k] = ct[k];
     if (dbg && tid == 0) {
-        dbg[12] = t_sweep, dbg[13] = 0, dbg[14] = t_solve, dbg[15] = t_dec, dbg[16] = clock64() - t_all, dbg[17] = calls;
+        dbg[12] = t_sweep, dbg[13] = t_red, dbg[14] = t_solve, dbg[15] = t_dec, dbg[16] = clock64() - t_all, dbg[17] = calls;
+        for (int k = 0; k < 5; k++) dbg[18 + k] = bs[k];
     }
     __syncthreads();
+}
+
+// The ten sweeps of one solve read every edge again: for up to PNP_STAGE_MAX edges (KITTI: ~650) the points,
+// observations, levels and errors live in LDS for the whole solve instead of costing an L2 round trip per sweep.
+constexpr int PNP_STAGE_MAX = 1536;
+constexpr int PNP_DYN_BYTES = PNP_STAGE_MAX * (24 + 16 + 8 + 1);
+
+__device__ __forceinline__ void pnp_solve(const Params &prm, const Pose &prior, const double *X, const float *obs, double *err, int8_t *level,
+                                          int n, PnpShared &sh, double *red, uint8_t *dyn, Pose &res, int &inliers, int &calls, long long *dbg) {
+    if (n <= PNP_STAGE_MAX) {
+        double *sX = reinterpret_cast<double *>(dyn);
+        double *sErr = sX + 3 * PNP_STAGE_MAX;
+        float *sObs = reinterpret_cast<float *>(sErr + 2 * PNP_STAGE_MAX);
+        int8_t *sLvl = reinterpret_cast<int8_t *>(sObs + 2 * PNP_STAGE_MAX);
+        for (int i = threadIdx.x; i < 3 * n; i += PNP_THREADS) sX[i] = X[i];
+        for (int i = threadIdx.x; i < 2 * n; i += PNP_THREADS) sObs[i] = obs[i];
+        for (int i = threadIdx.x; i < n; i += PNP_THREADS) sLvl[i] = level[i];
+        __syncthreads();
+        pnp_run(prm, prior, sX, sObs, sErr, sLvl, n, sh, red, res, inliers, calls, dbg);
+        for (int i = threadIdx.x; i < 2 * n; i += PNP_THREADS) err[i] = sErr[i];
+        for (int i = threadIdx.x; i < n; i += PNP_THREADS) level[i] = sLvl[i];
+    } else
+        pnp_run(prm, prior, X, obs, err, level, n, sh, red, res, inliers, calls, dbg);
 }
 
 __global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs, int par) {
@@ -1124,11 +1197,12 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs, int par) {
     Ctl &ctl = *S.ctl;
     if (!ctl.active || ctl.first_frame || ctl.lost_now) return;
     __shared__ PnpShared sh;
-    __shared__ double red[128 + 28 * PNP_THREADS];
+    __shared__ double red[384 + 28 * (PNP_THREADS + 8)];
+    extern __shared__ __attribute__((aligned(16))) uint8_t pnp_dyn[];
     Pose res;
     int inliers, calls;
     // err must be defined for every edge before the first gate: all edges are active in pass 1
-    pnp_run(S.prm, ctl.predicted, S.pnp_X, S.pnp_obs, S.pnp_err, S.pnp_level, ctl.n_matches, sh, red, res, inliers, calls, ctl.dbg);
+    pnp_solve(S.prm, ctl.predicted, S.pnp_X, S.pnp_obs, S.pnp_err, S.pnp_level, ctl.n_matches, sh, red, pnp_dyn, res, inliers, calls, ctl.dbg);
     if (threadIdx.x == 0) {
         ctl.optimized = res;
         ctl.last_pose = res;  // lvt_system.cpp:205
@@ -1145,12 +1219,13 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs, int par) {
 __global__ __launch_bounds__(PNP_THREADS) void k_pnp_standalone(Params prm, Pose prior, const double *X, const float *obs, double *err,
                                                                 int8_t *level, int n, Pose *out, int *info) {
     __shared__ PnpShared sh;
-    __shared__ double red[128 + 28 * PNP_THREADS];
+    __shared__ double red[384 + 28 * (PNP_THREADS + 8)];
+    extern __shared__ __attribute__((aligned(16))) uint8_t pnp_dyn[];
     for (int i = threadIdx.x; i < n; i += PNP_THREADS) level[i] = 0;
     __syncthreads();
     Pose res;
     int inliers, calls;
-    pnp_run(prm, prior, X, obs, err, level, n, sh, red, res, inliers, calls);
+    pnp_solve(prm, prior, X, obs, err, level, n, sh, red, pnp_dyn, res, inliers, calls, nullptr);
     if (threadIdx.x == 0) {
         *out = res;
         info[0] = calls;

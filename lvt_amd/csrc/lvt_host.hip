@@ -379,6 +379,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
         HIPCHK(c, hipMemcpy(c->d_seqs, c->h_seqs.data(), sizeof(Seq) * B, hipMemcpyHostToDevice));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       CELLS_LDS_BYTES));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pnp), hipFuncAttributeMaxDynamicSharedMemorySize, PNP_DYN_BYTES));
         reset_state(c);
     } catch (...) {
         delete c;
@@ -434,7 +435,7 @@ static void enqueue_frame(Context *c) {
     LAUNCH(8, st, k_candidates<MODE_MAP>, dim3(256, 1, B), dim3(256), 0, S, 0, par);
     LAUNCH(9, st, k_resolve<MODE_MAP>, dim3(1, 1, B), dim3(RES_THREADS), 0, S, 0, par);
     LAUNCH(12, st, k_track_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par);
-    LAUNCH(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), 0, S, par);
+    LAUNCH(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), PNP_DYN_BYTES, S, par);
     LAUNCH(16, st, k_candidates<MODE_STAGED>, dim3(64, 1, B), dim3(256), 0, S, 0, par);
     LAUNCH(17, st, k_staged, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par);
     LAUNCH(19, st, k_resolve<MODE_ROW>, dim3(1, 1, B), dim3(RES_THREADS), 0, S, 0, par);
@@ -929,7 +930,8 @@ LVT_API int lvt_amd_pnp(const lvt_amd_params *pin, const double q_in[4], const d
         Pose prior;
         for (int k = 0; k < 4; k++) prior.q[k] = q_in[k];
         for (int k = 0; k < 3; k++) prior.p[k] = p_in[k];
-        hipLaunchKernelGGL(k_pnp_standalone, dim3(1), dim3(PNP_THREADS), 0, 0, prm, prior, dX, dObs, dErr, dLevel, n, dOut, dInfo);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pnp_standalone), hipFuncAttributeMaxDynamicSharedMemorySize, PNP_DYN_BYTES);
+        hipLaunchKernelGGL(k_pnp_standalone, dim3(1), dim3(PNP_THREADS), PNP_DYN_BYTES, 0, prm, prior, dX, dObs, dErr, dLevel, n, dOut, dInfo);
         Pose out;
         int info[2] = {0, 0};
         if (hipMemcpy(&out, dOut, sizeof(Pose), hipMemcpyDeviceToHost) == hipSuccess &&

@@ -423,6 +423,7 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
                                              float desc_th, int acc[2]) {
     const int tid = threadIdx.x;
     int n[2], off[2];
+    const long long ts0 = clock64();
     if (tid == 0) L.misc[0] = QCAP;
     __syncthreads();
 #pragma unroll
@@ -455,6 +456,7 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
         for (int u = 0; u < 2; u++)
             if (tid + u * RES_THREADS >= limit) n[u] = 0;
     }
+    const long long ts1 = clock64();
     // pack the lists into LDS (independent loads, 8 in flight per query)
 #pragma unroll
     for (int u = 0; u < 2; u++) {
@@ -471,6 +473,7 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
     __syncthreads();
     int prev[2] = {-2, -2};
     acc[0] = acc[1] = -1;
+    int dbg_steps = 0;
     const long long tj0 = clock64();
     const uint32_t it0 = iter;
     while (true) {
@@ -505,17 +508,24 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
                 }
             }
             const bool ok = accept_match(cnt, k1, k2, ratio, desc_th);
+            dbg_steps = max(dbg_steps, n[u]);
             acc[u] = ok ? (int)(k1 & 0xFFFFu) : -1;
             if (ok) atomicMax(&wr[acc[u]], (iter << 11) | (uint32_t)(2047 - lq));
             changed = changed || (acc[u] != prev[u]);
             prev[u] = acc[u];
         }
+        if (threadIdx.x == 0 && iter - it0 <= 4) L.misc[8 + (iter - it0 - 1)] = (int)(clock64() - tj0);
         if (!__syncthreads_or(changed ? 1 : 0)) break;
     }
     if (threadIdx.x == 0) {
         L.misc[4] = (int)(iter - it0);
         L.misc[5] = (int)(clock64() - tj0);
+        L.misc[6] = (int)(ts1 - ts0);
+        L.misc[3] = 0;
+        L.misc[7] = (int)(tj0 - ts1);
     }
+    __syncthreads();
+    atomicMax(&L.misc[3], dbg_steps);
 #pragma unroll
     for (int u = 0; u < 2; u++)
         if (acc[u] >= 0) {
@@ -532,7 +542,7 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
     __shared__ uint32_t r_tab[2 * NF_MAX];                  \
     __shared__ uint32_t r_lists[LCAP];                      \
     __shared__ int r_scan[32];                              \
-    __shared__ int r_misc[8];                               \
+    __shared__ int r_misc[16];                              \
     ResolveLds L;                                           \
     L.flag = r_flag, L.tab0 = r_tab, L.tab1 = r_tab + NF_MAX, L.lists = r_lists, L.scan = r_scan, L.misc = r_misc;
 
@@ -569,6 +579,7 @@ __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int pa
     uint32_t iter = 0;
     int accepted = 0;  // block-uniform
     __syncthreads();
+    const long long tk1 = clock64();
     for (int b0 = 0; b0 < M;) {
         int acc[2];
         const uint8_t *lflag = S.fb[par].feat[0].flag;
@@ -631,9 +642,15 @@ __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int pa
             if (!pass2) {
                 ctl.dbg[18] = L.misc[4];
                 ctl.dbg[19] = L.misc[5];
+                ctl.dbg[28] = L.misc[3];
+                for (int k = 0; k < 4; k++) ctl.dbg[24 + k] = L.misc[8 + k];
+                ctl.dbg[29] = L.misc[6];
+                ctl.dbg[30] = L.misc[7];
+                ctl.dbg[31] = tk1 - tk0;
                 ctl.dbg[23] = clock64() - tk0;
                 ctl.n_pass1 = accepted;
                 ctl.do_pass2 = (accepted < N_MATCHES_TH) ? 1 : 0;  // lvt_local_map.cpp:173
+                L.misc[2] = ctl.do_pass2;
                 ctl.counts[C_SECOND_PASS] = ctl.do_pass2;
             } else
                 ctl.n_pass2 = accepted;
@@ -643,6 +660,7 @@ __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int pa
         if (tid == 0) {
             ctl.n_pairs = accepted;
             ctl.counts[C_N_ROW_MATCHES] = accepted;
+            L.misc[2] = accepted;
         }
     }
 }
@@ -733,8 +751,85 @@ __device__ __forceinline__ void cull_body(Seq &S, Ctl &ctl, int par, int *scan) 
     }
 }
 
+// bookkeeping + LOST decision + clean_untracked_points in ONE pass for maps of up to RES_THREADS points (the map of a
+// KITTI sequence holds ~800): every field of a point is loaded once (independent loads: one memory round trip), both
+// compactions (PnP input = matched points, surviving map = counter < untracked_th) come from one packed scan, and the
+// survivors go straight to the other map buffer.  Returns true when the frame is LOST (block-uniform).
+__device__ __forceinline__ bool bookkeep_cull_small(Seq &S, Ctl &ctl, int par, int *scan) {
+    const int tid = threadIdx.x;
+    const int cur = *S.map_cur, M = *S.map_n;
+    MapSoA &A = S.map[cur], &B = S.map[cur ^ 1];
+    const Feat &F = S.fb[par].feat[0];
+    const int th = S.prm.untracked_th;
+    const int i = tid;
+    int m = -2, cnt = 0, ag = 0;
+    double pos[3] = {0, 0, 0};
+    uint64_t dsc[4] = {0, 0, 0, 0};
+    if (i < M) {
+        m = S.match[i];
+        cnt = A.counter[i];
+        ag = A.age[i];
+        pos[0] = A.pos[3 * i], pos[1] = A.pos[3 * i + 1], pos[2] = A.pos[3 * i + 2];
+#pragma unroll
+        for (int k = 0; k < 4; k++) dsc[k] = A.desc[(size_t)i * 4 + k];
+        if (m == -1) cnt += 1;       // lvt_local_map.cpp:201-224
+        else if (m >= 0) ag += 1;
+    }
+    float ox = 0.f, oy = 0.f;
+    if (m >= 0) ox = F.x[m], oy = F.y[m];
+    const bool keep = (i < M) && (cnt < th);
+    int total;
+    const int ex = block_excl_scan((m >= 0 ? 1 : 0) | (keep ? 0x10000 : 0), scan, &total);
+    const int n_match = total & 0xFFFF, n_keep = total >> 16;
+    const int offm = ex & 0xFFFF, offk = ex >> 16;
+    if (m >= 0 && offm < NF_MAX) {
+        S.pnp_X[3 * offm] = pos[0];
+        S.pnp_X[3 * offm + 1] = pos[1];
+        S.pnp_X[3 * offm + 2] = pos[2];
+        S.pnp_obs[2 * offm] = ox;
+        S.pnp_obs[2 * offm + 1] = oy;
+        S.pnp_feat[offm] = m;
+        S.pnp_level[offm] = 0;
+    }
+    const bool lost = n_match < S.prm.min_matches;  // lvt_system.cpp:267-272, :199-204
+    if (tid == 0) {
+        ctl.n_matches = n_match;
+        ctl.counts[C_N_MATCHES] = n_match;
+        if (lost) {
+            ctl.lost_now = 1;
+            ctl.state = 3;
+            pose_to_Rt(ctl.last_pose, ctl.out_R, ctl.out_t);
+            ctl.out_status = 3;
+        } else {  // push_back / pop_front
+            ctl.last_matches[0] = ctl.last_matches[1];
+            ctl.last_matches[1] = ctl.last_matches[2];
+            ctl.last_matches[2] = n_match;
+        }
+    }
+    if (lost) {  // the map stays where it is, with the bookkeeping applied
+        if (i < M) A.match_idx[i] = m, A.counter[i] = cnt, A.age[i] = ag;
+        return true;
+    }
+    // clean_untracked_points (lvt_local_map.cpp:393-413): stable compaction into the other buffer
+    if (keep) {
+        B.pos[3 * offk] = pos[0], B.pos[3 * offk + 1] = pos[1], B.pos[3 * offk + 2] = pos[2];
+#pragma unroll
+        for (int k = 0; k < 4; k++) B.desc[(size_t)offk * 4 + k] = dsc[k];
+        B.counter[offk] = cnt;
+        B.age[offk] = ag;
+        B.match_idx[offk] = m;
+    } else if (i < M && m >= 0)
+        S.fb[par].feat[0].flag[m] = 0;  // :402-405
+    if (tid == 0) {
+        ctl.counts[C_N_CULLED] = M - n_keep;
+        *S.map_cur = cur ^ 1;
+        *S.map_n = n_keep;
+    }
+    return false;
+}
+
 // =================================================================================================
-// k_track_mid : [find_matches second pass, if pass 1 found < 50] + bookkeeping + LOST decision + cull
+// k_track_mid : find_matches pass 1 [+ second pass, if pass 1 found < 50] + bookkeeping + LOST decision + cull
 // =================================================================================================
 __global__ __launch_bounds__(RES_THREADS) void k_track_mid(Seq *seqs, int par) {
     Seq &S = seqs[blockIdx.z];
@@ -747,7 +842,9 @@ __global__ __launch_bounds__(RES_THREADS) void k_track_mid(Seq *seqs, int par) {
     }
     if (ctl.first_frame) return;
     RESOLVE_LDS_DECL
-    if (ctl.do_pass2) {  // rare (< 50 matches): doubled-radius candidate lists are built by this one block
+    resolve_body<MODE_MAP>(S, ctl, 0, par, L, r_tab);  // find_matches pass 1 (lists from k_candidates)
+    __syncthreads();
+    if (L.misc[2]) {  // rare (< 50 matches): doubled-radius candidate lists are built by this one block
         {
             CandLds C;  // carve the (not yet used) list area of the resolver
             C.lbuf = r_lists;                                      // 16 waves x KC words
@@ -759,6 +856,10 @@ __global__ __launch_bounds__(RES_THREADS) void k_track_mid(Seq *seqs, int par) {
         __syncthreads();
         resolve_body<MODE_MAP>(S, ctl, 1, par, L, r_tab);
         __syncthreads();
+    }
+    if (*S.map_n <= RES_THREADS) {
+        bookkeep_cull_small(S, ctl, par, L.scan);
+        return;
     }
     bookkeep_body(S, ctl, par, L.scan);
     __syncthreads();
@@ -1164,7 +1265,6 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
     for (int k = 0; k < 3; k++) result.p[k] = ct[k];
     if (dbg && tid == 0) {
         dbg[12] = t_sweep, dbg[13] = t_red, dbg[14] = t_solve, dbg[15] = t_dec, dbg[16] = clock64() - t_all, dbg[17] = calls;
-        for (int k = 0; k < 5; k++) dbg[18 + k] = bs[k];
     }
     __syncthreads();
 }
@@ -1456,6 +1556,13 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par) {
     const int tid = threadIdx.x;
     const bool run = ctl.active && !ctl.lost_now && ctl.need_tri;  // block-uniform
     if (run) {
+    int n_pairs = 0;
+    if (S.prm.sensor == 1) {  // row_match (lvt_image_features_handler.cpp:299-326): greedy resolution of the lists k_candidates<ROW> built
+        RESOLVE_LDS_DECL
+        resolve_body<MODE_ROW>(S, ctl, 0, par, L, r_tab);
+        __syncthreads();
+        n_pairs = L.misc[2];
+    }
     if (tid == 0) {
         if (ctl.first_frame) {
             cam.q[0] = 1, cam.q[1] = cam.q[2] = cam.q[3] = 0;
@@ -1471,7 +1578,7 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par) {
     __syncthreads();
     const Feat &FL = S.fb[par].feat[0], &FR = S.fb[par].feat[1];
     const bool rgbd = (S.prm.sensor == 2);
-    const int n_in = rgbd ? *FL.n : ctl.n_pairs;
+    const int n_in = rgbd ? *FL.n : n_pairs;
     // destination: lvt_local_map.cpp:345 (decided once, before anything is appended)
     const bool to_map = ctl.dont_stage || S.prm.staged_th == 0 || (*S.map_n < N_MAP_POINTS);
     MapSoA &D = to_map ? S.map[*S.map_cur] : S.staged[*S.staged_cur];

@@ -17,6 +17,7 @@
 #include "k_hamming.hip"
 
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -391,8 +392,8 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
 // ---- the per-frame launch chain -------------------------------------------------------------------
 static const char *kProfNames[Context::PROF_SLOTS] = {
     "k_feat_begin", "", "k_score", "k_cells(pass0)", "k_cells(retry)", "k_gather", "k_brief", "k_project(begin+map)",
-    "k_candidates(map)", "k_resolve(map)", "", "", "k_track_mid(pass2+bookkeep+cull)", "k_pnp(+project staged)", "",
-    "", "k_candidates(staged)", "k_staged", "k_candidates(row) [feature stream]", "k_resolve(row)", "k_triangulate(+finalize)", "",
+    "k_candidates(map)", "", "", "", "k_track_mid(resolve+pass2+bookkeep+cull)", "k_pnp(+project staged)", "",
+    "", "k_candidates(staged)", "k_staged", "k_candidates(row) [feature stream]", "", "k_triangulate(row resolve+triangulate+finalize)", "",
     "", ""};
 
 #define LAUNCH(slot, st, kern, grid, block, lds, ...)                              \
@@ -408,7 +409,17 @@ static const char *kProfNames[Context::PROF_SLOTS] = {
 static void collect_oldest(Context *c);
 
 // frame inputs must already be in h_fargs[slot] (and any upload enqueued on stream_f)
+static double g_enq_us = 0, g_wait_us = 0;
+static long g_enq_n = 0, g_wait_n = 0;
+struct HostTimer {
+    double *acc;
+    std::chrono::steady_clock::time_point t0;
+    explicit HostTimer(double *a) : acc(a), t0(std::chrono::steady_clock::now()) {}
+    ~HostTimer() { *acc += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
+};
 static void enqueue_frame(Context *c) {
+    HostTimer ht(&g_enq_us);
+    g_enq_n++;
     const int B = c->B;
     const Params &p = c->prm;
     Seq *S = c->d_seqs;
@@ -433,12 +444,10 @@ static void enqueue_frame(Context *c) {
     (void)hipStreamWaitEvent(st, c->ev_feat[par], 0);
     LAUNCH(7, st, k_project, dim3(32, 1, B), dim3(256), 0, S, par);
     LAUNCH(8, st, k_candidates<MODE_MAP>, dim3(256, 1, B), dim3(256), 0, S, 0, par);
-    LAUNCH(9, st, k_resolve<MODE_MAP>, dim3(1, 1, B), dim3(RES_THREADS), 0, S, 0, par);
     LAUNCH(12, st, k_track_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par);
     LAUNCH(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), PNP_DYN_BYTES, S, par);
     LAUNCH(16, st, k_candidates<MODE_STAGED>, dim3(64, 1, B), dim3(256), 0, S, 0, par);
     LAUNCH(17, st, k_staged, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par);
-    LAUNCH(19, st, k_resolve<MODE_ROW>, dim3(1, 1, B), dim3(RES_THREADS), 0, S, 0, par);
     LAUNCH(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, S, par);
     for (int s = 0; s < B; s++)
         (void)hipMemcpyAsync(&c->h_ctl[(size_t)slot * B + s], c->d_ctl[s], sizeof(Ctl), hipMemcpyDeviceToHost, st);
@@ -449,6 +458,8 @@ static void enqueue_frame(Context *c) {
 
 // wait for the oldest un-collected frame; its record becomes "last"
 static void collect_oldest(Context *c) {
+    HostTimer ht(&g_wait_us);
+    g_wait_n++;
     if (c->done >= c->enq) return;
     const int slot = (int)(c->done % RING);
     HIPCHK(c, hipEventSynchronize(c->ev_done[slot]));
@@ -535,6 +546,9 @@ LVT_API lvt_handle lvt_create(const char *config_file_name, int sensor_type) {
 }
 
 LVT_API void lvt_destroy(lvt_handle h) {
+    if (std::getenv("LVT_AMD_HOST_TIMING") && g_enq_n > 0)
+        std::fprintf(stderr, "lvt_amd host timing: %ld frames enqueued, %.1f us each; %ld collected, %.1f us each (blocking)\n", g_enq_n,
+                     g_enq_us / g_enq_n, g_wait_n, g_wait_us / std::max(g_wait_n, 1L));
     try {
         delete static_cast<Context *>(h);
     } catch (...) {

@@ -9,5 +9,5 @@ for i in range(4):
     L, R = w.render_stereo(i); vo.track(L, R)
     d = vo.debug_stamps()
     print("frame", i, "n_raw", d[20], "n_kp", d[21], "n_out", d[22], " cycles:", {names[k + 1]: int(d[k + 1] - d[k]) for k in range(11)}, "total", int(d[11] - d[0]))
-    print("   pnp cycles: err", d[12], "build", d[13], "solve", d[14], "decide", d[15], "all", d[16], "calls", d[17], "| block_sum: wait", d[18], "write", d[19], "segments", d[20], "final", d[21], "read", d[22])
-    print("   resolve(map): fixpoint iterations", d[18], "fixpoint cycles", d[19], "kernel cycles", d[23])
+    print("   pnp cycles: err", d[12], "build", d[13], "solve", d[14], "decide", d[15], "all", d[16], "calls", d[17], "| block_sum: wait", d[24], "write", d[25], "segments", d[26], "final", d[27], "read", 0)
+    print("   resolve(map): fixpoint iterations", d[18], "fixpoint cycles", d[19], "kernel cycles", d[23], "| init", d[31], "counts+scan", d[29], "pack", d[30], "max list len", d[28], "iteration ends", d[24], d[25], d[26], d[27])

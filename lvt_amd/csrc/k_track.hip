@@ -457,17 +457,24 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
             if (tid + u * RES_THREADS >= limit) n[u] = 0;
     }
     const long long ts1 = clock64();
-    // pack the lists into LDS (independent loads, 8 in flight per query)
+    // pack the lists into LDS: 16-byte loads, 32 entries (8 loads) in flight per query -- one memory round trip for
+    // the usual list of < 32 candidates (rows of `cand` are KC words apart, so every row start is 16-byte aligned)
 #pragma unroll
     for (int u = 0; u < 2; u++) {
-        const uint32_t *src = cand + (size_t)(b0 + tid + u * RES_THREADS) * KC;
-        for (int e0 = 0; e0 < n[u]; e0 += 8) {
-            uint32_t v[8];
+        const uint4 *src = reinterpret_cast<const uint4 *>(cand + (size_t)(b0 + tid + u * RES_THREADS) * KC);
+        for (int e0 = 0; e0 < n[u]; e0 += 32) {
+            uint4 v[8];
 #pragma unroll
-            for (int k = 0; k < 8; k++) v[k] = (e0 + k < n[u]) ? src[e0 + k] : 0u;
+            for (int k = 0; k < 8; k++) v[k] = (e0 + 4 * k < n[u]) ? src[(e0 >> 2) + k] : make_uint4(0, 0, 0, 0);
 #pragma unroll
-            for (int k = 0; k < 8; k++)
-                if (e0 + k < n[u]) L.lists[off[u] + e0 + k] = v[k];
+            for (int k = 0; k < 8; k++) {
+                const int e = e0 + 4 * k;
+                uint32_t *dst = L.lists + off[u] + e;
+                if (e < n[u]) dst[0] = v[k].x;
+                if (e + 1 < n[u]) dst[1] = v[k].y;
+                if (e + 2 < n[u]) dst[2] = v[k].z;
+                if (e + 3 < n[u]) dst[3] = v[k].w;
+            }
         }
     }
     __syncthreads();
@@ -612,10 +619,14 @@ __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int pa
         }
         // results, in query order (local query = tid + u * RES_THREADS)
         const int a0 = (tid < used && acc[0] >= 0) ? 1 : 0, a1 = (tid + RES_THREADS < used && acc[1] >= 0) ? 1 : 0;
-        int tot0, tot1 = 0;
-        const int ex0 = block_excl_scan(a0, L.scan, &tot0);
-        int ex1 = 0;
-        if (used > RES_THREADS) ex1 = block_excl_scan(a1, L.scan, &tot1);
+        int tot0, tot1 = 0, ex0 = 0, ex1 = 0;
+        if (MODE == MODE_MAP) {  // only the number of matches is needed
+            tot0 = __syncthreads_count(a0);
+            if (used > RES_THREADS) tot1 = __syncthreads_count(a1);
+        } else {
+            ex0 = block_excl_scan(a0, L.scan, &tot0);
+            if (used > RES_THREADS) ex1 = block_excl_scan(a1, L.scan, &tot1);
+        }
         const int tot = tot0 + tot1;
 #pragma unroll
         for (int u = 0; u < 2; u++) {

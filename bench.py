@@ -224,17 +224,32 @@ def main():
             out = torch.zeros((B, M, 4), dtype=torch.int32, device=dev)
             torch.cuda.synchronize()
             us = []
-            for _ in range(6):
-                us.append(lvt_amd.hamming_match_batched(qd, qxy.contiguous(), td, txy.contiguous(), tf, 625.0, 0, H, W, out))
+            for _ in range(6):  # 5 launches back to back per timing: the average excludes the ~5 us of launch latency
+                us.append(lvt_amd.hamming_match_batched(qd, qxy.contiguous(), td, txy.contiguous(), tf, 625.0, 0, H, W, out, launches=5))
             us = sorted(us[1:])
             med = us[len(us) // 2]
             byts = float(B) * bmatch(M, N)
             ach = byts / (med * 1e-6) / 1e9
-            hb = {"kernel": "lvt::k_hamming_batched<0> (masked 2-NN Hamming matcher, radius mode)", "bound": "hbm", "achieved": round(ach, 1),
-                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+            # HBM traffic of the same launch from the rocprofv3 PMC passes (tools/profile.sh; counters cannot be read from
+            # inside this process).  FETCH_SIZE counts the 16-B-per-lane loads of this kernel at one half on gfx950
+            # (MI355X_MICROARCH.md, HBM section): corrected bytes = 2 * FETCH_SIZE + WRITE_SIZE.
+            traffic, traffic_src = None, None
+            try:
+                pj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "hamming_pmc.json")
+                with open(pj) as f:
+                    pm = json.load(f)
+                if pm.get("launch") == {"B": B, "M": M, "N": N}:
+                    traffic = round(2.0 * pm["FETCH_SIZE_KB_per_launch"] * 1024.0 + pm["WRITE_SIZE_KB_per_launch"] * 1024.0, 1)
+                    traffic_src = "profiles/hamming_pmc.json (%s)" % pm.get("source", "rocprofv3 --pmc")
+            except Exception:  # noqa: BLE001
+                pass
+            hb = {"kernel": "lvt::k_hamming_batched<0,3,2,3> (masked 2-NN Hamming matcher, radius mode)", "bound": "hbm", "achieved": round(ach, 1),
+                  "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                   "avg_us": round(med, 2), "launch": {"B": B, "M": M, "N": N, "algorithmic_bytes": byts},
-                  "note": "B independent KITTI-nominal problems per launch; algorithmic bytes 40(M+N)+N+16M each (SURVEY 8d); timed with "
-                          "HIP events on the launch stream inside bench.py; PMC traffic in profiles/"}
+                  "traffic_source": traffic_src,
+                  "note": "B independent KITTI-nominal problems per launch; algorithmic bytes 40(M+N)+N+16M each (SURVEY 8d); average of 5 "
+                          "back-to-back launches between two HIP events on the launch stream, median of 5 such timings; traffic = "
+                          "2*FETCH_SIZE + WRITE_SIZE of the same launch from the committed rocprofv3 PMC passes"}
         except Exception as e:  # noqa: BLE001
             hb = {"error": str(e)}
         # ---- CPU baseline: the oracle (port of the reference path), 2 threads like the reference, same frames

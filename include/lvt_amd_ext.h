@@ -116,6 +116,12 @@ LVT_API float lvt_amd_hamming_match_batched(const void *q_desc, const void *q_xy
                                             const void *t_xy, const void *t_flag, int B, int M, int N,
                                             float r2, int mode, int img_rows, int img_cols, void *out,
                                             void *hip_stream);
+/* same, `launches` identical launches back to back between the two events; returns the AVERAGE per launch (a single
+ * launch's event pair also times ~5 us of launch latency -- this is the form bench.py's roofline uses) */
+LVT_API float lvt_amd_hamming_match_batched_n(const void *q_desc, const void *q_xy, const void *t_desc,
+                                              const void *t_xy, const void *t_flag, int B, int M, int N,
+                                              float r2, int mode, int img_rows, int img_cols, void *out,
+                                              void *hip_stream, int launches);
 
 #ifdef __cplusplus
 }

@@ -28,7 +28,7 @@ ABI_SYMBOLS = [
     "lvt_amd_set_stream", "lvt_amd_last_error", "lvt_amd_get_counts", "lvt_amd_get_features",
     "lvt_amd_get_matches", "lvt_amd_get_row_matches", "lvt_amd_get_map", "lvt_amd_get_staged",
     "lvt_amd_get_pose", "lvt_amd_get_predicted_pose", "lvt_amd_get_plane", "lvt_amd_pnp",
-    "lvt_amd_hamming_match_batched", "lvt_amd_profile_enable", "lvt_amd_profile_read", "lvt_amd_get_debug",
+    "lvt_amd_hamming_match_batched", "lvt_amd_hamming_match_batched_n", "lvt_amd_profile_enable", "lvt_amd_profile_read", "lvt_amd_get_debug",
     "lvt_amd_batch_create", "lvt_amd_batch_size", "lvt_amd_batch_track_device_async", "lvt_amd_batch_wait",
     "lvt_amd_batch_get_counts",
 ]
@@ -92,6 +92,8 @@ def load_library():
     L.lvt_amd_pnp.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]
     L.lvt_amd_hamming_match_batched.restype = C.c_float
     L.lvt_amd_hamming_match_batched.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.lvt_amd_hamming_match_batched_n.restype = C.c_float
+    L.lvt_amd_hamming_match_batched_n.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int]
     L.lvt_amd_profile_enable.argtypes = [vp, C.c_int]
     L.lvt_amd_batch_create.restype = vp
     L.lvt_amd_batch_create.argtypes = [vp, C.c_int, C.c_int]
@@ -334,15 +336,16 @@ def pnp(params: LvtParameters, q_in, p_in, pts, obs):
     return q, p, inl, calls.value
 
 
-def hamming_match_batched(q_desc, q_xy, t_desc, t_xy, t_flag, r2: float, mode: int, img_rows: int, img_cols: int, out, stream: int = 0):
+def hamming_match_batched(q_desc, q_xy, t_desc, t_xy, t_flag, r2: float, mode: int, img_rows: int, img_cols: int, out, stream: int = 0,
+                          launches: int = 1):
     """Batched masked 2-NN Hamming matcher on DEVICE tensors (torch): q_desc (B,M,32) u8, q_xy (B,M,2) f32,
     t_desc (B,N,32) u8, t_xy (B,N,2) f32, t_flag (B,N) u8, out (B,M,4) i32.  Returns kernel time in us."""
     L = load_library()
     B, M = q_desc.shape[0], q_desc.shape[1]
     N = t_desc.shape[1]
-    us = L.lvt_amd_hamming_match_batched(C.c_void_p(q_desc.data_ptr()), C.c_void_p(q_xy.data_ptr()), C.c_void_p(t_desc.data_ptr()),
-                                         C.c_void_p(t_xy.data_ptr()), C.c_void_p(t_flag.data_ptr()), B, M, N, float(r2), int(mode),
-                                         int(img_rows), int(img_cols), C.c_void_p(out.data_ptr()), C.c_void_p(stream))
+    us = L.lvt_amd_hamming_match_batched_n(C.c_void_p(q_desc.data_ptr()), C.c_void_p(q_xy.data_ptr()), C.c_void_p(t_desc.data_ptr()),
+                                           C.c_void_p(t_xy.data_ptr()), C.c_void_p(t_flag.data_ptr()), B, M, N, float(r2), int(mode),
+                                           int(img_rows), int(img_cols), C.c_void_p(out.data_ptr()), C.c_void_p(stream), int(launches))
     if us < 0:
         raise RuntimeError("lvt_amd_hamming_match_batched failed")
     return us

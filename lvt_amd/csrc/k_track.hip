@@ -1,15 +1,16 @@
 // k_track.hip -- map<->frame matching, motion-only BA, map maintenance, stereo triangulation (gfx950).
 //
-//   k_project    : is_point_visible + projection of map / staged points        (lvt_local_map.cpp:62-82,152)
+//   k_project    : frame prologue (motion model, state machine) + is_point_visible / projection of the map points
+//                                                                               (lvt_system.cpp:157-197, lvt_local_map.cpp:62-82,152)
 //   k_candidates : masked Hamming candidate lists, one wavefront per query      (lvt_image_features_struct.cpp:68-148)
-//   k_resolve    : the order-dependent accept/mark pass of find_matches and row_match
-//                                                                               (lvt_local_map.cpp:146-199, handler.cpp:302-323)
-//   k_bookkeep   : counters / ages / PnP input, LOST decision                   (lvt_local_map.cpp:201-224, lvt_system.cpp:267-274)
-//   k_pnp        : g2o Levenberg-Marquardt, 2 passes x optimize(5), on device   (lvt_pnp_solver.cpp:60-128)
-//   k_cull       : clean_untracked_points                                       (lvt_local_map.cpp:393-413)
+//   k_track_mid  : the order-dependent accept/mark pass of find_matches (pass 1, rare pass 2), counters / ages / PnP
+//                  input, LOST decision, clean_untracked_points
+//                                      (lvt_local_map.cpp:146-224,393-413, lvt_system.cpp:267-274)
+//   k_pnp        : g2o Levenberg-Marquardt, 2 passes x optimize(5), on device; projects the staged points with the result
+//                                                                               (lvt_pnp_solver.cpp:60-128)
 //   k_staged     : update_staged_map_points + triangulation policy              (lvt_local_map.cpp:355-391, lvt_system.cpp:308-334)
-//   k_triangulate: linear-LS triangulation + gates, append to map / staged      (lvt_local_map.cpp:231-353)
-//   k_finalize   : first-frame epilogue, result record                          (lvt_system.cpp:185-193)
+//   k_triangulate: row_match accept/mark pass, linear-LS triangulation + gates, append to map / staged, frame epilogue
+//                                      (handler.cpp:302-323, lvt_local_map.cpp:231-353, lvt_system.cpp:185-193)
 //
 // The Hamming distance evaluation is parallel (k_candidates); only the accept/mark scan is sequential,
 // and it walks pre-sorted candidate lists so it touches a few words per query.

@@ -962,9 +962,10 @@ LVT_API int lvt_amd_pnp(const lvt_amd_params *pin, const double q_in[4], const d
 
 
 // ---- stage entry: batched masked 2-NN Hamming matcher on device-resident problems --------------------
-LVT_API float lvt_amd_hamming_match_batched(const void *q_desc, const void *q_xy, const void *t_desc, const void *t_xy, const void *t_flag,
-                                            int B, int M, int N, float r2, int mode, int img_rows, int img_cols, void *out,
-                                            void *hip_stream) {
+LVT_API float lvt_amd_hamming_match_batched_n(const void *q_desc, const void *q_xy, const void *t_desc, const void *t_xy, const void *t_flag,
+                                              int B, int M, int N, float r2, int mode, int img_rows, int img_cols, void *out,
+                                              void *hip_stream, int launches) {
+    if (launches < 1) launches = 1;
     if (B <= 0 || M <= 0 || N <= 0 || N > HB_NMAX || M > HB_MMAX) {
         std::fprintf(stderr, "lvt_amd_hamming_match_batched: bad sizes B=%d M=%d N=%d (N <= %d, M <= %d)\n", B, M, N, HB_NMAX, HB_MMAX);
         return -1.0f;
@@ -1021,7 +1022,7 @@ LVT_API float lvt_amd_hamming_match_batched(const void *q_desc, const void *q_xy
     }
     const hipError_t ea = hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipEventRecord(e0, st);
-    hipLaunchKernelGGL(kern, dim3(B), dim3(HB_THREADS), lds, st, a);
+    for (int l = 0; l < launches; l++) hipLaunchKernelGGL(kern, dim3(B), dim3(HB_THREADS), lds, st, a);
     const hipError_t elaunch = hipGetLastError();
     (void)hipEventRecord(e1, st);
     const hipError_t es = hipEventSynchronize(e1);
@@ -1040,7 +1041,13 @@ LVT_API float lvt_amd_hamming_match_batched(const void *q_desc, const void *q_xy
                      hd[1] - hd[0], hd[2] - hd[1], hd[3] - hd[2], hd[4] - hd[3], hd[5] - hd[4], hd[7] - hd[5], hd[6] - hd[7], hd[6] - hd[0]);
         (void)hipFree(d_dbg);
     }
-    return (ee != hipSuccess || ms < 0) ? -1.0f : ms * 1000.0f;
+    return (ee != hipSuccess || ms < 0) ? -1.0f : ms * 1000.0f / (float)launches;
+}
+
+LVT_API float lvt_amd_hamming_match_batched(const void *q_desc, const void *q_xy, const void *t_desc, const void *t_xy, const void *t_flag,
+                                            int B, int M, int N, float r2, int mode, int img_rows, int img_cols, void *out,
+                                            void *hip_stream) {
+    return lvt_amd_hamming_match_batched_n(q_desc, q_xy, t_desc, t_xy, t_flag, B, M, N, r2, mode, img_rows, img_cols, out, hip_stream, 1);
 }
 
 }  // extern "C"

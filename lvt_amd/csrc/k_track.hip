@@ -177,12 +177,15 @@ struct CandLds {
     uint32_t *lbuf;          // [waves][KC]
     float *tx, *ty;          // [NF_MAX]
     uint32_t *tc;            // [NF_MAX] packed hash cell (cy << 16 | cx)
+    const double *w2c;       // PROJECT: world -> camera of the predicted pose (LDS)
 };
 
 // wave `wave0 + k * wave_stride` handles query wave0 + k * wave_stride; all `nthreads` threads of the block stage the
 // train data.  MODE_ROW lists are built for EVERY left feature (they depend on the two feature sets only, so the
 // kernel runs on the feature stream); the resolver skips the left features tracking has already matched.
-template <int MODE>
+// PROJECT (map mode, pass 1): the wavefront first projects its map point with the predicted pose (is_point_visible,
+// lvt_local_map.cpp:62-82,152-156) and records the projection for the rest of the chain.
+template <int MODE, bool PROJECT = false>
 __device__ __forceinline__ void candidates_body(Seq &S, int pass2, int par, CandLds &C, int wave0, int wave_stride, int nthreads) {
     uint32_t *s_tc = C.tc;
     float *s_tx = C.tx, *s_ty = C.ty;
@@ -221,7 +224,27 @@ __device__ __forceinline__ void candidates_body(Seq &S, int pass2, int par, Cand
     uint32_t *buf = C.lbuf + wv * KC;
     for (int i = wave0; i < M; i += wave_stride) {
         Query q;
-        if (MODE == MODE_MAP) {
+        if (MODE == MODE_MAP && PROJECT) {
+            MapSoA &P = S.map[*S.map_cur];
+            const double X[3] = {P.pos[3 * i], P.pos[3 * i + 1], P.pos[3 * i + 2]};
+            double u, v;
+            const bool visible = is_point_visible(X, C.w2c, S.prm, u, v);  // wave-uniform
+            if (lane == 0) {
+                if (visible) {
+                    S.proj[2 * i] = (float)u;
+                    S.proj[2 * i + 1] = (float)v;
+                    S.vis[i] = 1;
+                    S.match[i] = -1;
+                } else {
+                    S.vis[i] = 0;
+                    P.counter[i] += 1;  // lvt_local_map.cpp:154
+                    S.match[i] = -2;
+                    ncand[i] = 0;
+                }
+            }
+            if (!visible) continue;
+            make_query_track(S.prm, (float)u, (float)v, radius, q);
+        } else if (MODE == MODE_MAP) {
             if (!S.vis[i]) {
                 if (lane == 0) ncand[i] = 0;
                 continue;
@@ -299,6 +322,37 @@ __global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2, int pa
     CandLds C;
     C.lbuf = lbuf, C.tx = s_tx, C.ty = s_ty, C.tc = s_tc;
     candidates_body<MODE>(S, pass2, par, C, blockIdx.x * 4 + wave_id(), gridDim.x * 4, 256);
+}
+
+// k_match_map : frame prologue + projection of the map points + their candidate lists (find_matches pass 1).  Every block
+// derives the per-frame facts it needs (active / first frame / predicted pose) from the PERSISTENT part of Ctl, which
+// nobody writes during this kernel; block 0 additionally publishes them for the rest of the chain.
+__global__ __launch_bounds__(256) void k_match_map(Seq *seqs, int par) {
+    Seq &S = seqs[blockIdx.z];
+    Ctl &ctl = *S.ctl;
+    const int state = ctl.state;  // persistent; not written by this kernel
+    const bool active = (state != 3), first = (state == 1);
+    __shared__ double w2c[12];
+    if (threadIdx.x == 0) {
+        Pose predicted;
+        double mmn[14];
+        if (active && !first) {
+            motion_predict(ctl, ctl.last_pose, predicted, mmn);
+            world_to_camera(predicted, w2c);
+        }
+        if (blockIdx.x == 0) {
+            frame_prologue(S, ctl, par, predicted, mmn, active, first);
+            if (active && !first) ctl.counts[C_MAP_SIZE_AT_MATCH] = *S.map_n;
+        }
+    }
+    if (!active || first) return;
+    __syncthreads();
+    __shared__ uint32_t lbuf[4 * KC];
+    __shared__ float s_tx[NF_MAX], s_ty[NF_MAX];
+    __shared__ uint32_t s_tc[NF_MAX];
+    CandLds C;
+    C.lbuf = lbuf, C.tx = s_tx, C.ty = s_ty, C.tc = s_tc, C.w2c = w2c;
+    candidates_body<MODE_MAP, true>(S, 0, par, C, blockIdx.x * 4 + wave_id(), gridDim.x * 4, 256);
 }
 
 // =================================================================================================

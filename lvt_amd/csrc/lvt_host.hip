@@ -391,8 +391,8 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
 
 // ---- the per-frame launch chain -------------------------------------------------------------------
 static const char *kProfNames[Context::PROF_SLOTS] = {
-    "k_feat_begin", "", "k_score", "k_cells(pass0)", "k_cells(retry)", "k_gather", "k_brief", "k_project(begin+map)",
-    "k_candidates(map)", "", "", "", "k_track_mid(resolve+pass2+bookkeep+cull)", "k_pnp(+project staged)", "",
+    "k_feat_begin", "", "k_score", "k_cells(pass0)", "k_cells(retry)", "k_gather", "k_brief", "",
+    "k_match_map(begin+project+candidates)", "", "", "", "k_track_mid(resolve+pass2+bookkeep+cull)", "k_pnp(+project staged)", "",
     "", "k_candidates(staged)", "k_staged", "k_candidates(row) [feature stream]", "", "k_triangulate(row resolve+triangulate+finalize)", "",
     "", ""};
 
@@ -442,8 +442,7 @@ static void enqueue_frame(Context *c) {
     (void)hipEventRecord(c->ev_feat[par], sf);
     // ---- tracking chain (stream): strictly ordered frame after frame
     (void)hipStreamWaitEvent(st, c->ev_feat[par], 0);
-    LAUNCH(7, st, k_project, dim3(32, 1, B), dim3(256), 0, S, par);
-    LAUNCH(8, st, k_candidates<MODE_MAP>, dim3(256, 1, B), dim3(256), 0, S, 0, par);
+    LAUNCH(8, st, k_match_map, dim3(256, 1, B), dim3(256), 0, S, par);
     LAUNCH(12, st, k_track_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par);
     LAUNCH(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), PNP_DYN_BYTES, S, par);
     LAUNCH(16, st, k_candidates<MODE_STAGED>, dim3(64, 1, B), dim3(256), 0, S, 0, par);

@@ -346,7 +346,11 @@ struct CellGeom {
 // raster-order compaction of the cell's raw corners into keys[0..cap); returns the true count.
 // Every thread owns a CONTIGUOUS run of 16-pixel chunks (so one block scan orders the whole cell); the chunks
 // are read twice (count, then emit) -- the second read hits L2.
-__device__ __forceinline__ int cell_compact(const CellGeom &g, uint32_t *keys, int cap, int *scan) {
+// Thresholds up to 128 (every shipped configuration: 25 / 12) take the byte-parallel path: the four scores of a word are
+// compared at once (s >= th  <=>  bit 7 of (s & 0x7F) + (0x80 - th), or bit 7 of s itself), so a 16-pixel chunk costs ~25
+// instructions to count and a find-first-set walk over its corners to emit, instead of ~100 + ~160 for the scalar loops
+// -- one CU runs all 16 wavefronts of the cell, so this phase is VALU-bound.
+__device__ __forceinline__ int cell_compact(const CellGeom &g, uint32_t *keys, int cap, int *scan, long long *dbg = nullptr) {
     const int tid = threadIdx.x;
     const int xa = g.X0 + 3, xb = g.X0 + g.cw - 4;  // inclusive pixel range
     const int c0 = xa >> 4, c1 = xb >> 4;
@@ -355,9 +359,26 @@ __device__ __forceinline__ int cell_compact(const CellGeom &g, uint32_t *keys, i
     const int items = nrows * nchunk;
     const int per = (items + 1023) / 1024;
     const int it0 = tid * per, it1 = min(items, it0 + per);
+    const bool swar = g.threshold >= 1 && g.threshold <= 128;
+    const uint32_t addk = (uint32_t)(0x80 - g.threshold) * 0x01010101u;
+    // bit 7 of byte b of the result <=> pixel gx0 + 4 * word + b is a corner of this cell at this threshold
+    auto mask4 = [&](uint32_t w, int gx) -> uint32_t {
+        uint32_t m = ((((w & 0x7F7F7F7Fu) + addk) | w) & 0x80808080u);
+        if (gx < xa || gx + 3 > xb) {  // the cell's first / last chunk only
+#pragma unroll
+            for (int b = 0; b < 4; b++)
+                if (gx + b < xa || gx + b > xb) m &= ~(0x80u << (8 * b));
+        }
+        return m;
+    };
     auto count16 = [&](const uint4 &v, int gx0) -> int {
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         int cnt = 0;
+        if (swar) {
+#pragma unroll
+            for (int k = 0; k < 4; k++) cnt += __popc(mask4(w[k], gx0 + 4 * k));
+            return cnt;
+        }
 #pragma unroll
         for (int b = 0; b < 16; b++) {
             const int s = (w[b >> 2] >> (8 * (b & 3))) & 255;
@@ -366,29 +387,70 @@ __device__ __forceinline__ int cell_compact(const CellGeom &g, uint32_t *keys, i
         }
         return cnt;
     };
+    // up to 4 chunks per thread stay in registers between the counting and the emitting pass (KITTI: 4, EuRoC: 2)
+    constexpr int KEEP = 4;
+    uint4 kv[KEEP];
     int cnt = 0;
+    if (per <= KEEP) {
+#pragma unroll
+        for (int u = 0; u < KEEP; u++) {
+            const int it = min(it0 + u, items - 1);
+            const int ly = 3 + it / nchunk, gx0 = (c0 + it % nchunk) << 4;
+            kv[u] = *reinterpret_cast<const uint4 *>(g.score + (size_t)(g.Y0 + ly) * g.pp + gx0);
+        }
+#pragma unroll
+        for (int u = 0; u < KEEP; u++) {
+            const int it = it0 + u;
+            if (it < it1) cnt += count16(kv[u], (c0 + it % nchunk) << 4);
+        }
+    } else {
 #pragma unroll 4
-    for (int it = it0; it < it1; it++) {
-        const int ly = 3 + it / nchunk, gx0 = (c0 + it % nchunk) << 4;
-        const uint4 v = *reinterpret_cast<const uint4 *>(g.score + (size_t)(g.Y0 + ly) * g.pp + gx0);
-        cnt += count16(v, gx0);
-    }
-    int total;
-    int off = block_excl_scan(cnt, scan, &total);
-    if (cnt) {
         for (int it = it0; it < it1; it++) {
             const int ly = 3 + it / nchunk, gx0 = (c0 + it % nchunk) << 4;
             const uint4 v = *reinterpret_cast<const uint4 *>(g.score + (size_t)(g.Y0 + ly) * g.pp + gx0);
-            const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-            if ((w[0] | w[1] | w[2] | w[3]) == 0) continue;
+            cnt += count16(v, gx0);
+        }
+    }
+    int total;
+    int off = block_excl_scan(cnt, scan, &total);
+    auto emit16 = [&](const uint4 &v, int ly, int gx0) {
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        if ((w[0] | w[1] | w[2] | w[3]) == 0) return;
+        if (swar) {
 #pragma unroll
-            for (int b = 0; b < 16; b++) {
-                const int s = (w[b >> 2] >> (8 * (b & 3))) & 255;
-                const int gx = gx0 + b;
-                if (s >= g.threshold && gx >= xa && gx <= xb) {
-                    if (off < cap) keys[off] = mk_key(ly, gx - g.X0, s);
+            for (int k = 0; k < 4; k++) {
+                uint32_t m = mask4(w[k], gx0 + 4 * k);
+                while (m) {  // ascending x: lowest set byte first
+                    const int b = (__ffs((int)m) - 1) >> 3;
+                    m &= m - 1;
+                    const int s = (w[k] >> (8 * b)) & 255;
+                    if (off < cap) keys[off] = mk_key(ly, gx0 + 4 * k + b - g.X0, s);
                     off++;
                 }
+            }
+            return;
+        }
+#pragma unroll
+        for (int b = 0; b < 16; b++) {
+            const int s = (w[b >> 2] >> (8 * (b & 3))) & 255;
+            const int gx = gx0 + b;
+            if (s >= g.threshold && gx >= xa && gx <= xb) {
+                if (off < cap) keys[off] = mk_key(ly, gx - g.X0, s);
+                off++;
+            }
+        }
+    };
+    if (cnt) {
+        if (per <= KEEP) {
+#pragma unroll
+            for (int u = 0; u < KEEP; u++) {
+                const int it = it0 + u;
+                if (it < it1) emit16(kv[u], 3 + it / nchunk, (c0 + it % nchunk) << 4);
+            }
+        } else {
+            for (int it = it0; it < it1; it++) {
+                const int ly = 3 + it / nchunk, gx0 = (c0 + it % nchunk) << 4;
+                emit16(*reinterpret_cast<const uint4 *>(g.score + (size_t)(g.Y0 + ly) * g.pp + gx0), ly, gx0);
             }
         }
     }
@@ -869,7 +931,7 @@ __global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass, int par) {
     if (g.cw > 1024 || g.ch > 1024) {
         if (tid == 0) atomicOr(&ctl.overflow, OVF_CELL_DIM);
     } else if (g.cw >= 7 && g.ch >= 7) {
-        int n_raw = cell_compact(g, keys, RAW_CAP, scan);
+        int n_raw = cell_compact(g, keys, RAW_CAP, scan, dbg);
         if (dbg && tid == 0) dbg[1] = clock64();
         if (n_raw <= RAW_CAP) {
             n_out = cell_nms_anms<uint16_t>(S, g, keys, uf, root16, abv16, nms16, tie8, n_raw, RAW_CAP, row_first, row_end, scan, stack, misc, out, dbg);

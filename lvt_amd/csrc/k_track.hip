@@ -958,18 +958,30 @@ __device__ __forceinline__ void cam_refresh(CamRegs &c, const double r[4], const
         c.w2i[8 + j] = c.w2n[8 + j];
     }
 }
+// 1 / sqrt(s) for s > 0 in the normal range: hardware seed (v_rsq_f64, ~26 bits) + two Newton steps in fma form.
+// One dependency chain of ~10 instructions where sqrt followed by a division costs ~45 -- thread 0 runs the pose solve
+// alone, so these chains ARE its time.  The result is within 1 ulp of the correctly rounded value.
+__device__ __forceinline__ double rsqrt_nr(double s) {
+    double y = __builtin_amdgcn_rsq(s);
+#pragma unroll
+    for (int it = 0; it < 2; it++) {
+        const double e = __builtin_fma(-(s * y), y, 1.0);  // 1 - s y^2
+        y = __builtin_fma(0.5 * y, e, y);
+    }
+    return y;
+}
+
 __device__ bool solve6_spd(const double *H /*6x6*/, const double *b, double *x) {
-    // Cholesky (Eigen LLT as used by g2o's dense linear solver).  One thread runs this, so the chain of fp64 divisions
-    // is the cost: each column's 1 / L_jj is formed once and reused by the column scaling and both substitutions
-    // (6 divisions instead of 27; the quotients differ from v / L_jj by at most one rounding).
+    // Cholesky (Eigen LLT as used by g2o's dense linear solver) in the form that never needs L_jj itself: every use of the
+    // pivot is a division by it, so the column keeps inv_j = 1 / sqrt(s_j) (column scaling and both substitutions multiply
+    // by it).  Each quotient differs from the divide-by-sqrt form by at most a rounding or two; see DESIGN.md section 5.
     double L[36], inv[6];
     for (int i = 0; i < 36; i++) L[i] = 0;
     for (int j = 0; j < 6; j++) {
         double s = H[6 * j + j];
         for (int k = 0; k < j; k++) s -= L[6 * j + k] * L[6 * j + k];
         if (!(s > 0) || !isfinite(s)) return false;
-        L[6 * j + j] = sqrt(s);
-        inv[j] = 1.0 / L[6 * j + j];
+        inv[j] = rsqrt_nr(s);
         for (int i = j + 1; i < 6; i++) {
             double v = H[6 * i + j];
             for (int k = 0; k < j; k++) v -= L[6 * i + k] * L[6 * j + k];
@@ -1248,7 +1260,13 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
                     qr[1] = dx[3], qr[2] = dx[4], qr[3] = dx[5];
                     qr[0] = sqrt(1.0 - (dx[3] * dx[3] + dx[4] * dx[4] + dx[5] * dx[5]));
                     q_mul(cr, qr, nr);
-                    q_normalize(nr);
+                    {  // normalize(): one reciprocal square root instead of sqrt + four divisions
+                        const double z = nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2] + nr[3] * nr[3];
+                        if (z > 0) {
+                            const double rn = rsqrt_nr(z);
+                            nr[0] *= rn, nr[1] *= rn, nr[2] *= rn, nr[3] *= rn;
+                        }
+                    }
                     for (int k2 = 0; k2 < 4; k2++) sh.r[k2] = nr[k2];
                     for (int k2 = 0; k2 < 3; k2++) sh.t[k2] = nt[k2];
                 }

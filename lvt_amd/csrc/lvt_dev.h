@@ -160,34 +160,42 @@ __device__ __forceinline__ int hamming256(const uint64_t a[4], const uint64_t b[
     return __popcll(a[0] ^ b[0]) + __popcll(a[1] ^ b[1]) + __popcll(a[2] ^ b[2]) + __popcll(a[3] ^ b[3]);
 }
 
-// inclusive wave scan (64 lanes)
+// inclusive wave scan (64 lanes), all lanes active.  DPP row shifts inside each row of 16 lanes, then the two row
+// broadcasts (row_bcast:15 into rows 1 and 3, row_bcast:31 into rows 2 and 3): six VALU instructions, no LDS crossbar
+// (the __shfl_up form costs six ds_bpermute round trips of ~120 cycles each -- with the barriers around it a block scan
+// took 2-5k cycles, and the per-cell / per-map kernels run dozens of them back to back on one CU).
 __device__ __forceinline__ int wave_incl_scan(int v) {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        int t = __shfl_up(v, d, 64);
-        if (lane_id() >= d) v += t;
-    }
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);  // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);  // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);  // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);  // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);  // row_bcast:15 -> rows 1, 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+// inclusive scan inside each row of 16 lanes only
+__device__ __forceinline__ int row16_incl_scan(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
     return v;
 }
 
-// exclusive block scan over blockDim.x (<= 1024) threads; `scratch` >= 17 ints of LDS; returns
-// exclusive prefix, *total receives the block sum.  Contains __syncthreads().
+// exclusive block scan over blockDim.x (<= 1024) threads, called by every thread; `scratch` >= 16 ints of LDS; returns the
+// exclusive prefix, *total receives the block sum.  Two barriers: every wave reads the <= 16 wave totals itself and scans
+// them inside one DPP row, so there is no third "wave 0 publishes the prefixes" round.
 __device__ __forceinline__ int block_excl_scan(int v, int *scratch, int *total) {
     const int incl = wave_incl_scan(v);
-    const int w = wave_id(), l = lane_id();
+    const int w = __builtin_amdgcn_readfirstlane(wave_id()), l = lane_id();
     const int nw = (blockDim.x + 63) >> 6;
-    __syncthreads();
+    __syncthreads();  // readers of the previous call are done with scratch
     if (l == 63) scratch[w] = incl;
     __syncthreads();
-    if (w == 0) {
-        int s = (l < nw) ? scratch[l] : 0;
-        int si = wave_incl_scan(s);
-        if (l < nw) scratch[l] = si - s;
-        if (l == nw - 1) scratch[16] = si;
-    }
-    __syncthreads();
-    const int base = scratch[w];
-    *total = scratch[16];
+    const int part = (l < nw) ? scratch[l] : 0;
+    const int pin = row16_incl_scan(part);  // lanes 0..15: inclusive prefix of the wave totals
+    const int base = __builtin_amdgcn_readlane(pin, w) - __builtin_amdgcn_readlane(part, w);
+    *total = __builtin_amdgcn_readlane(pin, 15);
     return base + incl - v;
 }
 

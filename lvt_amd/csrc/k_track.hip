@@ -1021,7 +1021,7 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red, double *
         // transposed partials part[k][tid], then thread (k, j) adds the 32 entries j, j + 8, j + 16, ... of row k (one
         // address register, immediate offsets, no predicates), then thread k adds the 8 segment sums.  No cross-lane
         // traffic, three barriers.  Row stride 264 doubles: rows k and k + 4 share banks, nothing else does.
-        constexpr int SEG = PNP_THREADS / 32, SLEN = PNP_THREADS / SEG;
+        constexpr int SEG = 8, SLEN = PNP_THREADS / SEG;  // SEG = 8: one DPP row holds two rows' segment sums
         constexpr int STRIDE = PNP_THREADS + 8;
         static_assert(NV * SEG <= PNP_THREADS && PNP_THREADS % SEG == 0, "block_sum layout");
         double *part = red + 384;  // [NV][STRIDE]
@@ -1043,18 +1043,22 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red, double *
                 s2 += p[SEG * (u + 2)];
                 s3 += p[SEG * (u + 3)];
             }
-            seg[tid] = (s0 + s1) + (s2 + s3);
+            // the 8 segment sums of row k sit in 8 consecutive lanes: three DPP row shifts add them up in lane 8k + 7
+            double s = (s0 + s1) + (s2 + s3);
+#define LVT_DPP_ADD_F64(CTRL)                                                                          \
+    {                                                                                                  \
+        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(s), CTRL, 0xf, 0xf, false);      \
+        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(s), CTRL, 0xf, 0xf, false);      \
+        s += __hiloint2double(hi_, lo_);                                                               \
+    }
+            LVT_DPP_ADD_F64(0x111)  // row_shr:1 (lanes without a source read 0)
+            LVT_DPP_ADD_F64(0x112)  // row_shr:2
+            LVT_DPP_ADD_F64(0x114)  // row_shr:4
+#undef LVT_DPP_ADD_F64
+            if ((tid & (SEG - 1)) == SEG - 1) dst[tid / SEG] = s;
         }
         __syncthreads();
-        long long b3 = clock64();
-        if (tid < NV) {
-            double s = 0.0;
-#pragma unroll
-            for (int j = 0; j < SEG; j++) s += seg[tid * SEG + j];
-            dst[tid] = s;
-        }
-        __syncthreads();
-        long long b4 = clock64();  // the NV sums are in dst[0..NV-1]; v[] is NOT updated (only thread 0 wants them)
+        long long b3 = clock64(), b4 = b3;  // the NV sums are in dst[0..NV-1]; v[] is NOT updated (only thread 0 wants them)
         if (bs) {
             long long b5 = clock64();
             bs[0] += b1 - b0, bs[1] += b2 - b1, bs[2] += b3 - b2, bs[3] += b4 - b3, bs[4] += b5 - b4;

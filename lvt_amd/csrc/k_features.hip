@@ -49,6 +49,13 @@ __device__ __forceinline__ int oast9_score(int p, const int r[16]) {
     return best - 1;
 }
 
+// raw-corner key: (ly << 18) | (lx << 8) | score    (cell-local coords < 1024, score <= 254)
+__device__ __forceinline__ uint32_t mk_key(int ly, int lx, int s) { return ((uint32_t)ly << 18) | ((uint32_t)lx << 8) | (uint32_t)s; }
+__device__ __forceinline__ int key_y(uint32_t k) { return (int)(k >> 18); }
+__device__ __forceinline__ int key_x(uint32_t k) { return (int)((k >> 8) & 1023); }
+__device__ __forceinline__ int key_r(uint32_t k) { return (int)(k & 255); }
+__device__ __forceinline__ uint32_t key_pos(uint32_t k) { return k >> 8; }
+
 __global__ __launch_bounds__(256) void k_score(Seq *seqs, int par) {
     const int seq = blockIdx.z >> 1, eye = blockIdx.z & 1;
     Seq &S = seqs[seq];
@@ -99,6 +106,13 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs, int par) {
     const int cs = S.prm.cell_size;
     const int t_low = S.prm.agast_th_low;
     uint32_t packed = 0;
+    // raw corners of pass 0 (score >= agast_th), as cell-local keys: k_cells gathers them per (row, tile) segment instead of
+    // re-reading the score map with one CU per cell
+    const int t_hi = S.prm.agast_th;
+    const int cell_x0 = x0 / cs;  // cell of the tile's first pixel; at most one cell boundary inside a tile when cs >= 64
+    uint32_t ckey[4] = {0, 0, 0, 0};
+    uint32_t cvalid = 0;  // bit k: pixel k of this thread is a pass-0 corner
+    int ncl = 0;
     if (gy < H) {
         const int cy = gy / cs, ly = gy - cy * cs, ch = min(cs, H - cy * cs);
         const bool vy = (ly >= 3) && (ly <= ch - 4);
@@ -137,10 +151,28 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs, int par) {
                         r[15] = tile[r0 + 1][c0 - 3];
                         const int s = oast9_score(p, r);
                         sc = (s >= t_low) ? s : 0;
+                        if (s >= t_hi) {
+                            ckey[k] = mk_key(ly, lx, s);
+                            cvalid |= 1u << k;
+                            ncl += (cx == cell_x0) ? 1 : 0;
+                        }
                     }
                 }
             }
             packed |= (uint32_t)sc << (8 * k);
+        }
+    }
+    {  // the 16 lanes of one DPP row hold one tile row, x-ascending: a row scan of the counts places the keys
+        const int nc = __popc(cvalid);
+        const int incl = row16_incl_scan(nc | (ncl << 8));
+        const int excl = (incl & 0xFF) - nc;
+        if (gy < H) {
+            const size_t seg = (size_t)gy * gridDim.x + blockIdx.x;
+            uint32_t *dst = FB.seg_keys[eye] + seg * TS_W + excl;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if ((cvalid >> k) & 1u) dst[__popc(cvalid & ((1u << k) - 1u))] = ckey[k];
+            if (tx == 15) FB.seg_cnt[eye][seg] = (uint16_t)incl;  // count | left-of-boundary count << 8
         }
     }
     __syncthreads();  // hs complete
@@ -165,13 +197,6 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs, int par) {
 // =================================================================================================
 // k_cells : one 1024-thread workgroup per (cell, eye, sequence)
 // =================================================================================================
-// raw-corner key: (ly << 18) | (lx << 8) | score    (cell-local coords < 1024, score <= 254)
-__device__ __forceinline__ uint32_t mk_key(int ly, int lx, int s) { return ((uint32_t)ly << 18) | ((uint32_t)lx << 8) | (uint32_t)s; }
-__device__ __forceinline__ int key_y(uint32_t k) { return (int)(k >> 18); }
-__device__ __forceinline__ int key_x(uint32_t k) { return (int)((k >> 8) & 1023); }
-__device__ __forceinline__ int key_r(uint32_t k) { return (int)(k & 255); }
-__device__ __forceinline__ uint32_t key_pos(uint32_t k) { return k >> 8; }
-
 // index traits: 16-bit indices while a cell's corners fit in LDS, 32-bit in the global-memory path
 template <typename I> struct IdxT;
 template <> struct IdxT<uint16_t> {
@@ -452,6 +477,50 @@ __device__ __forceinline__ int cell_compact(const CellGeom &g, uint32_t *keys, i
                 const int ly = 3 + it / nchunk, gx0 = (c0 + it % nchunk) << 4;
                 emit16(*reinterpret_cast<const uint4 *>(g.score + (size_t)(g.Y0 + ly) * g.pp + gx0), ly, gx0);
             }
+        }
+    }
+    __syncthreads();
+    return total;
+}
+
+// Pass 0: the raw corners were already extracted by k_score (all CUs) as one x-ascending list per (image row, 64-px tile);
+// the cell's raster-ordered list is the concatenation of its (row, tile) segments: one scan over the segment counts and a
+// copy.  Returns the number of raw corners; copies nothing when they do not fit `cap` (caller: global-memory path).
+__device__ __forceinline__ int cell_gather_segments(const FrameBuf &FB, int eye, const CellGeom &g, int cs, int cell_x, int tiles_x, uint32_t *keys,
+                                                    int cap, int *scan) {
+    const int tid = threadIdx.x;
+    const int t0 = g.X0 / TS_W, t1 = (g.X0 + g.cw - 1) / TS_W, nt = t1 - t0 + 1;
+    const int nrows = g.ch - 6;
+    const int items = nrows * nt;
+    const int per = (items + 1023) / 1024;
+    const int it0 = min(tid * per, items), it1 = min(items, it0 + per);
+    const uint16_t *cnt = FB.seg_cnt[eye];
+    const uint32_t *sk = FB.seg_keys[eye];
+    auto range_of = [&](int it, int &start, int &n) -> size_t {
+        const int r = it / nt, t = t0 + (it - r * nt);
+        const size_t seg = (size_t)(g.Y0 + 3 + r) * tiles_x + t;
+        const int c = cnt[seg], total = c & 0xFF, left = c >> 8;
+        const int cl = (t * TS_W) / cs, cr = (t * TS_W + TS_W - 1) / cs;  // cells of the tile's first / last pixel
+        if (cl == cr) start = 0, n = (cl == cell_x) ? total : 0;
+        else if (cl == cell_x) start = 0, n = left;
+        else start = left, n = (cr == cell_x) ? total - left : 0;
+        return seg;
+    };
+    int sum = 0;
+    for (int it = it0; it < it1; it++) {
+        int st, n;
+        range_of(it, st, n);
+        sum += n;
+    }
+    int total;
+    int off = block_excl_scan(sum, scan, &total);
+    if (total <= cap) {
+        for (int it = it0; it < it1; it++) {
+            int st, n;
+            const size_t seg = range_of(it, st, n);
+            const uint32_t *src = sk + seg * TS_W + st;
+            for (int k = 0; k < n; k++) keys[off + k] = src[k];
+            off += n;
         }
     }
     __syncthreads();
@@ -931,7 +1000,10 @@ __global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass, int par) {
     if (g.cw > 1024 || g.ch > 1024) {
         if (tid == 0) atomicOr(&ctl.overflow, OVF_CELL_DIM);
     } else if (g.cw >= 7 && g.ch >= 7) {
-        int n_raw = cell_compact(g, keys, RAW_CAP, scan, dbg);
+        // pass 0 with cells of at least one tile width: gather k_score's segments; otherwise compact the score map here
+        const bool segs = (pass == 0) && (cs >= TS_W);
+        int n_raw = segs ? cell_gather_segments(FB, eye, g, cs, cxi, (S.prm.W + TS_W - 1) / TS_W, keys, RAW_CAP, scan)
+                         : cell_compact(g, keys, RAW_CAP, scan, dbg);
         if (dbg && tid == 0) dbg[1] = clock64();
         if (n_raw <= RAW_CAP) {
             n_out = cell_nms_anms<uint16_t>(S, g, keys, uf, root16, abv16, nms16, tie8, n_raw, RAW_CAP, row_first, row_end, scan, stack, misc, out, dbg);

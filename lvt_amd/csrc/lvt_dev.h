@@ -119,6 +119,8 @@ struct FrameBuf {
     int img_pitch, depth_pitch; // bytes / elements
     uint8_t *score[2];          // OAST-9/16 score map (0 = below the lowered threshold / dead band)
     uint16_t *boxsum[2];        // 9x9 box sums
+    uint32_t *seg_keys[2];      // [H][tiles_x][64] raw-corner keys (score >= agast_th) of one 64-px tile row, x-ascending
+    uint16_t *seg_cnt[2];       // [H][tiles_x]  count | (count left of the cell boundary inside the tile) << 8
     float *cell_kp[2];          // [CELLS_MAX][CELL_OUT_CAP][3] (x, y, response)
     int *cell_n[2];             // [CELLS_MAX]
     const float *ext_xy[2];     // external corners (n_ext x 2, f32) for track_with_external_corners

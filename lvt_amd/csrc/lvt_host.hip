@@ -336,6 +336,11 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
                 for (int e = 0; e < 2; e++) {
                     FB.score[e] = c->dalloc<uint8_t>(plane + 64);
                     FB.boxsum[e] = c->dalloc<uint16_t>(plane + 64);
+                    {
+                        const size_t tiles_x = (size_t)(prm.W + TS_W - 1) / TS_W;
+                        FB.seg_keys[e] = c->dalloc<uint32_t>((size_t)prm.H * tiles_x * TS_W);
+                        FB.seg_cnt[e] = c->dalloc<uint16_t>((size_t)prm.H * tiles_x);
+                    }
                     FB.cell_kp[e] = c->dalloc<float>((size_t)CELLS_MAX * CELL_OUT_CAP * 3);
                     FB.cell_n[e] = c->dalloc<int>(CELLS_MAX);
                     alloc_feat(c, FB.feat[e]);

@@ -1440,6 +1440,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_staged(Seq *seqs, int par) {
         const int scur = *S.staged_cur, SM = *S.staged_n;
         MapSoA &A = S.staged[scur], &B = S.staged[scur ^ 1];
         MapSoA &MP = S.map[*S.map_cur];
+        if (SM > 0) {  // nothing staged (most frames): nothing to match, promote or compact
         for (int j = tid; j < NF_MAX; j += RES_THREADS) {
             const uint8_t f = (j < N) ? T.flag[j] : 0;
             if (j < N) L.flag[j] = f;
@@ -1544,6 +1545,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_staged(Seq *seqs, int par) {
             *S.staged_cur = scur ^ 1;
             *S.staged_n = n_out;
         }
+        }  // SM > 0
     }
     __syncthreads();
     if (tid == 0) {

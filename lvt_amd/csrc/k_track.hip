@@ -493,16 +493,19 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
 #pragma unroll
     for (int u = 0; u < 2; u++)
         if (tid + u * RES_THREADS >= limit) n[u] = 0;
+    // every list starts on a 16-byte boundary of L.lists (lengths rounded up to 4 entries): the walk reads 4 candidates
+    // with one ds_read_b128
+    const int n4[2] = {(n[0] + 3) & ~3, (n[1] + 3) & ~3};
     int t0, t1;
-    off[0] = block_excl_scan(n[0], L.scan, &t0);
+    off[0] = block_excl_scan(n4[0], L.scan, &t0);
     if (limit > RES_THREADS) {
-        off[1] = t0 + block_excl_scan(n[1], L.scan, &t1);
+        off[1] = t0 + block_excl_scan(n4[1], L.scan, &t1);
     } else {
         off[1] = t0;
         t1 = 0;
     }
     if (t0 + t1 > LCAP) {  // keep the longest prefix of queries whose lists fit
-        int f0 = (tid < limit && off[0] + n[0] <= LCAP) ? 1 : 0, f1 = (tid + RES_THREADS < limit && off[1] + n[1] <= LCAP) ? 1 : 0;
+        int f0 = (tid < limit && off[0] + n4[0] <= LCAP) ? 1 : 0, f1 = (tid + RES_THREADS < limit && off[1] + n4[1] <= LCAP) ? 1 : 0;
         int c0, c1;
         block_excl_scan(f0, L.scan, &c0);
         block_excl_scan(f1, L.scan, &c1);
@@ -554,10 +557,12 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
             // overlap; evaluation stays in list order
             for (int e = 0; e < n[u] && cnt < 2; e += 4) {
                 uint32_t c[4], v[4];
+                {
+                    const uint4 c4 = *reinterpret_cast<const uint4 *>(list + e);  // entries past n[u] are padding (never evaluated)
+                    c[0] = c4.x, c[1] = c4.y, c[2] = c4.z, c[3] = c4.w;
+                }
 #pragma unroll
-                for (int k = 0; k < 4; k++) c[k] = list[min(e + k, n[u] - 1)];
-#pragma unroll
-                for (int k = 0; k < 4; k++) v[k] = rd[c[k] & 0xFFFFu];
+                for (int k = 0; k < 4; k++) v[k] = rd[c[k] & (uint32_t)(NF_MAX - 1)];  // valid indices are < NF_MAX; padding stays in range
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     // unavailable: marked (PERM), or accepted in iteration iter-1 by an earlier query
@@ -602,7 +607,7 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
 #define RESOLVE_LDS_DECL                                    \
     __shared__ uint8_t r_flag[NF_MAX];                      \
     __shared__ uint32_t r_tab[2 * NF_MAX];                  \
-    __shared__ uint32_t r_lists[LCAP];                      \
+    __shared__ __attribute__((aligned(16))) uint32_t r_lists[LCAP]; \
     __shared__ int r_scan[32];                              \
     __shared__ int r_misc[16];                              \
     ResolveLds L;                                           \

@@ -56,16 +56,45 @@ __device__ __forceinline__ int key_x(uint32_t k) { return (int)((k >> 8) & 1023)
 __device__ __forceinline__ int key_r(uint32_t k) { return (int)(k & 255); }
 __device__ __forceinline__ uint32_t key_pos(uint32_t k) { return k >> 8; }
 
-__global__ __launch_bounds__(256) void k_score(Seq *seqs, int par) {
+// per-frame, per-sequence inputs (pinned host memory read by k_feat_begin for batches; a kernel argument of k_score for
+// a single sequence, which then needs no separate "begin" launch)
+struct FrameArgs {
+    const uint8_t *img[2];
+    const float *depth;
+    int img_pitch, depth_pitch;
+    int ext_corners, n_ext[2];
+};
+
+// publish this frame's inputs, clear the feature stage's control block
+__device__ __forceinline__ void feat_begin(Seq &S, const FrameArgs &f, int par) {
+    FrameBuf &FB = S.fb[par];
+    FB.img[0] = f.img[0];
+    FB.img[1] = f.img[1];
+    FB.depth_img = f.depth;
+    FB.img_pitch = f.img_pitch;
+    FB.depth_pitch = f.depth_pitch;
+    FeatCtl &c = *FB.fc;
+    c.ext_corners = f.ext_corners;
+    c.n_ext[0] = f.n_ext[0];
+    c.n_ext[1] = f.n_ext[1];
+    c.n_detected[0] = c.n_detected[1] = 0;
+    c.retry[0] = c.retry[1] = 0;
+    c.overflow = 0;
+}
+
+// BEGIN = single sequence: `fa` carries the frame's inputs, block (0, 0, 0) publishes them for the later kernels
+template <bool BEGIN>
+__global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par) {
     const int seq = blockIdx.z >> 1, eye = blockIdx.z & 1;
     Seq &S = seqs[seq];
     FrameBuf &FB = S.fb[par];
+    if (BEGIN && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) feat_begin(S, fa, par);
     if (eye == 1 && S.prm.sensor == 2) return;
     const int W = S.prm.W, H = S.prm.H;
     const int x0 = blockIdx.x * TS_W, y0 = blockIdx.y * TS_H;
     if (x0 >= W || y0 >= H) return;
-    const uint8_t *img = FB.img[eye];
-    const int pitch = FB.img_pitch;
+    const uint8_t *img = BEGIN ? fa.img[eye] : FB.img[eye];
+    const int pitch = BEGIN ? fa.img_pitch : FB.img_pitch;
 
     __shared__ __attribute__((aligned(16))) uint8_t tile[TILE_H][TILE_W];
     __shared__ uint16_t hs[TILE_H][TS_W];

@@ -38,31 +38,11 @@ namespace lvt {
 constexpr int EXT_MAX = 16384;
 constexpr int RING = 8;  // frames that may be in flight / un-collected
 
-struct FrameArgs {  // per-frame, per-sequence inputs (pinned host memory read by k_feat_begin)
-    const uint8_t *img[2];
-    const float *depth;
-    int img_pitch, depth_pitch;
-    int ext_corners, n_ext[2];
-};
-
-// first kernel of the feature stage: publish this frame's inputs, clear the stage's control block
+// first kernel of the feature stage of a BATCH: publish every sequence's inputs (a single sequence gets them as a kernel
+// argument of k_score)
 __global__ void k_feat_begin(Seq *seqs, const FrameArgs *fa, int par) {
     if (threadIdx.x != 0) return;
-    Seq &S = seqs[blockIdx.x];
-    const FrameArgs &f = fa[blockIdx.x];
-    FrameBuf &FB = S.fb[par];
-    FB.img[0] = f.img[0];
-    FB.img[1] = f.img[1];
-    FB.depth_img = f.depth;
-    FB.img_pitch = f.img_pitch;
-    FB.depth_pitch = f.depth_pitch;
-    FeatCtl &c = *FB.fc;
-    c.ext_corners = f.ext_corners;
-    c.n_ext[0] = f.n_ext[0];
-    c.n_ext[1] = f.n_ext[1];
-    c.n_detected[0] = c.n_detected[1] = 0;
-    c.retry[0] = c.retry[1] = 0;
-    c.overflow = 0;
+    feat_begin(seqs[blockIdx.x], fa[blockIdx.x], par);
 }
 
 // tightly packed host-layout image (stride == cols) -> pitched device image
@@ -435,8 +415,12 @@ static void enqueue_frame(Context *c) {
     for (int i = 0; i < Context::PROF_SLOTS; i++) c->ev_used[i] = false;
     // ---- feature stage (stream_f): may start as soon as the tracking chain of frame enq-2 released this parity
     if (c->enq >= 2) (void)hipStreamWaitEvent(sf, c->ev_track[par], 0);
-    LAUNCH(0, sf, k_feat_begin, dim3(B), dim3(64), 0, S, fa, par);
-    LAUNCH(2, sf, k_score, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2 * B), dim3(256), 0, S, par);
+    if (B == 1) {  // the frame's inputs travel as a kernel argument: no separate "begin" launch, no device read of pinned host memory
+        LAUNCH(2, sf, k_score<true>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2), dim3(256), 0, S, c->h_fargs[slot], par);
+    } else {
+        LAUNCH(0, sf, k_feat_begin, dim3(B), dim3(64), 0, S, fa, par);
+        LAUNCH(2, sf, k_score<false>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2 * B), dim3(256), 0, S, FrameArgs{}, par);
+    }
     if (!ext) {
         LAUNCH(3, sf, k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, S, 0, par);
         LAUNCH(4, sf, k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, S, 1, par);

@@ -254,7 +254,7 @@ def main():
             hb = {"error": str(e)}
         # ---- CPU baseline: the oracle (port of the reference path), 2 threads like the reference, same frames
         cpu = None
-        if not args.no_cpu:
+        if not args.no_cpu and world_size == 1:  # reported at N = 1 only (rank 0's host cores)
             from oracle import pyoracle as O
             nf = min(n_frames, args.cpu_frames)
             host = frames[:nf, :, :, :W].contiguous().cpu().numpy()

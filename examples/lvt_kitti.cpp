@@ -1,0 +1,262 @@
+// lvt_kitti -- KITTI-odometry command line harness over the lvt_c C-ABI.
+//
+// Same argv, inputs and outputs as the reference's example binary (examples/kitti/kitti_example.cpp:49-152 there):
+//     lvt_kitti <sequences_dir> <seq_number> [--config vo_config.yaml] [--calib calib/NN.yml] [--max-frames N] [--out NN.txt]
+// reads <sequences_dir>/NN/image_0/%06d.{png,pgm} and image_1/..., the OpenCV-YAML calibration (camera_matrix, baseline)
+// and vo_config.yaml, tracks every frame until the sequence ends or the tracker is LOST, writes NN.txt in the KITTI
+// 3x4 row format with the reference's precision (fixed, 9 digits) and prints the mean per-frame track() time.
+// No OpenCV: the PNG reader below handles what KITTI ships (8-bit gray / RGB / RGBA / gray+alpha, non-interlaced), colour
+// is reduced to gray with cv::cvtColor's fixed-point weights, and PGM (P5) is accepted for pre-converted data.
+#include "../include/lvt_amd_ext.h"
+#include "../include/lvt_c.h"
+
+#include <zlib.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <iostream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+namespace {
+
+struct Gray {
+    int w = 0, h = 0;
+    std::vector<unsigned char> px;
+};
+
+bool read_file(const std::string &path, std::vector<unsigned char> &out) {
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return false;
+    f.seekg(0, std::ios::end);
+    const std::streamoff n = f.tellg();
+    f.seekg(0);
+    out.resize((size_t)n);
+    f.read(reinterpret_cast<char *>(out.data()), n);
+    return (bool)f;
+}
+
+uint32_t be32(const unsigned char *p) { return ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3]; }
+
+// cv::cvtColor(BGR2GRAY) on 8-bit data: (R*4899 + G*9617 + B*1868 + 8192) >> 14
+unsigned char to_gray(int r, int g, int b) { return (unsigned char)((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14); }
+
+bool decode_png(const std::vector<unsigned char> &buf, Gray &img, std::string &err) {
+    static const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0D, 0x0A, 0x1A, 0x0A};
+    if (buf.size() < 33 || std::memcmp(buf.data(), sig, 8) != 0) return err = "not a PNG", false;
+    size_t off = 8;
+    int w = 0, h = 0, depth = 0, ctype = 0, interlace = 0;
+    std::vector<unsigned char> idat;
+    while (off + 12 <= buf.size()) {
+        const uint32_t len = be32(&buf[off]);
+        const char *type = reinterpret_cast<const char *>(&buf[off + 4]);
+        if (off + 12 + len > buf.size()) return err = "truncated chunk", false;
+        const unsigned char *data = &buf[off + 8];
+        if (!std::memcmp(type, "IHDR", 4)) {
+            w = (int)be32(data), h = (int)be32(data + 4);
+            depth = data[8], ctype = data[9], interlace = data[12];
+        } else if (!std::memcmp(type, "IDAT", 4)) {
+            idat.insert(idat.end(), data, data + len);
+        } else if (!std::memcmp(type, "IEND", 4))
+            break;
+        off += 12 + len;
+    }
+    int ch = 0;
+    switch (ctype) {
+        case 0: ch = 1; break;
+        case 2: ch = 3; break;
+        case 4: ch = 2; break;
+        case 6: ch = 4; break;
+        default: return err = "palette PNGs are not supported", false;
+    }
+    if (w <= 0 || h <= 0 || (depth != 8 && depth != 16) || interlace) return err = "unsupported PNG layout (need 8/16-bit, non-interlaced)", false;
+    const int bps = depth / 8, bpp = ch * bps;
+    const size_t stride = (size_t)w * bpp;
+    std::vector<unsigned char> raw((stride + 1) * (size_t)h);
+    uLongf raw_len = (uLongf)raw.size();
+    if (uncompress(raw.data(), &raw_len, idat.data(), (uLong)idat.size()) != Z_OK || raw_len != raw.size()) return err = "zlib inflate failed", false;
+    std::vector<unsigned char> cur(stride), prev(stride, 0);
+    img.w = w, img.h = h;
+    img.px.resize((size_t)w * h);
+    for (int y = 0; y < h; y++) {
+        const unsigned char *line = &raw[(stride + 1) * (size_t)y];
+        const int ft = line[0];
+        for (size_t i = 0; i < stride; i++) {
+            const int a = (i >= (size_t)bpp) ? cur[i - bpp] : 0, b = prev[i], c = (i >= (size_t)bpp) ? prev[i - bpp] : 0;
+            int pred = 0;
+            switch (ft) {
+                case 0: pred = 0; break;
+                case 1: pred = a; break;
+                case 2: pred = b; break;
+                case 3: pred = (a + b) >> 1; break;
+                case 4: {
+                    const int p = a + b - c, pa = std::abs(p - a), pb = std::abs(p - b), pc = std::abs(p - c);
+                    pred = (pa <= pb && pa <= pc) ? a : (pb <= pc ? b : c);
+                    break;
+                }
+                default: return err = "bad PNG filter", false;
+            }
+            cur[i] = (unsigned char)(line[1 + i] + pred);
+        }
+        for (int x = 0; x < w; x++) {
+            const unsigned char *p = &cur[(size_t)x * bpp];
+            // 16-bit samples: the most significant byte (what an 8-bit imread returns)
+            if (ch <= 2) img.px[(size_t)y * w + x] = p[0];
+            else img.px[(size_t)y * w + x] = to_gray(p[0], p[bps], p[2 * bps]);
+        }
+        std::swap(cur, prev);
+    }
+    return true;
+}
+
+bool decode_pgm(const std::vector<unsigned char> &buf, Gray &img, std::string &err) {
+    size_t pos = 0;
+    auto token = [&]() -> std::string {
+        for (;;) {
+            while (pos < buf.size() && std::isspace(buf[pos])) pos++;
+            if (pos < buf.size() && buf[pos] == '#') {
+                while (pos < buf.size() && buf[pos] != '\n') pos++;
+                continue;
+            }
+            break;
+        }
+        std::string t;
+        while (pos < buf.size() && !std::isspace(buf[pos])) t.push_back((char)buf[pos++]);
+        return t;
+    };
+    if (token() != "P5") return err = "not a binary PGM", false;
+    const int w = std::atoi(token().c_str()), h = std::atoi(token().c_str()), mx = std::atoi(token().c_str());
+    pos++;  // single whitespace after maxval
+    if (w <= 0 || h <= 0 || mx <= 0 || mx > 255 || pos + (size_t)w * h > buf.size()) return err = "unsupported PGM", false;
+    img.w = w, img.h = h;
+    img.px.assign(buf.begin() + (long)pos, buf.begin() + (long)(pos + (size_t)w * h));
+    return true;
+}
+
+bool load_gray(const std::string &stem, Gray &img, std::string &err) {
+    std::vector<unsigned char> buf;
+    if (read_file(stem + ".png", buf)) return decode_png(buf, img, err);
+    if (read_file(stem + ".pgm", buf)) return decode_pgm(buf, img, err);
+    err = "no such file";
+    return false;
+}
+
+// the two entries the reference reads from calib/NN.yml (OpenCV FileStorage YAML): camera_matrix.data and baseline
+bool read_calib(const std::string &path, double K[9], double &baseline) {
+    std::ifstream f(path);
+    if (!f) return false;
+    std::stringstream ss;
+    ss << f.rdbuf();
+    const std::string s = ss.str();
+    const size_t cm = s.find("camera_matrix");
+    const size_t d0 = (cm == std::string::npos) ? cm : s.find("data:", cm);
+    const size_t b0 = s.find("baseline:");
+    if (d0 == std::string::npos || b0 == std::string::npos) return false;
+    const size_t lb = s.find('[', d0), rb = s.find(']', d0);
+    if (lb == std::string::npos || rb == std::string::npos) return false;
+    std::string list = s.substr(lb + 1, rb - lb - 1);
+    for (char &c : list)
+        if (c == ',') c = ' ';
+    std::stringstream ls(list);
+    for (int i = 0; i < 9; i++)
+        if (!(ls >> K[i])) return false;
+    baseline = std::atof(s.c_str() + b0 + 9);
+    return true;
+}
+
+}  // namespace
+
+int main(int argc, char **argv) {
+    if (argc < 3) {
+        std::cout << "Usage ./lvt_kitti sequences_dir seq_number [--config vo_config.yaml] [--calib calib/NN.yml] [--max-frames N] [--out NN.txt]" << std::endl;
+        return -1;
+    }
+    char seq_cstr[16];
+    std::snprintf(seq_cstr, sizeof seq_cstr, "%02d", std::atoi(argv[2]));
+    const std::string seq_str(seq_cstr), dir_prefix = std::string(argv[1]) + "/" + seq_str;
+    std::string config = "vo_config.yaml", calib = "calib/" + seq_str + ".yml", out_name = seq_str + ".txt";
+    long max_frames = -1;
+    for (int i = 3; i + 1 < argc; i += 2) {
+        const std::string k = argv[i];
+        if (k == "--config") config = argv[i + 1];
+        else if (k == "--calib") calib = argv[i + 1];
+        else if (k == "--out") out_name = argv[i + 1];
+        else if (k == "--max-frames") max_frames = std::atol(argv[i + 1]);
+    }
+    double K[9], baseline = 0;
+    if (!read_calib(calib, K, baseline)) {
+        std::cout << "failed to open camera matrix yml file" << std::endl;
+        return -1;
+    }
+    lvt_amd_params params;
+    if (!lvt_amd_params_from_file(config.c_str(), &params)) {
+        std::cout << "failed to initialize from vo_config.yml file." << std::endl;
+        return -1;
+    }
+    auto stem = [&](int cam, long i) {
+        char name[32];
+        std::snprintf(name, sizeof name, "/image_%d/%06ld", cam, i);
+        return dir_prefix + name;
+    };
+    Gray left, right;
+    std::string err;
+    if (!load_gray(stem(0, 0), left, err) || !load_gray(stem(1, 0), right, err)) {
+        std::cout << "failed to get image sequences (" << err << ")" << std::endl;
+        return -1;
+    }
+    params.fx = (float)K[0], params.fy = (float)K[4], params.cx = (float)K[2], params.cy = (float)K[5];
+    params.baseline = (float)baseline;
+    params.img_width = left.w, params.img_height = left.h;
+    lvt_handle vo = lvt_amd_create(&params, 1 /* STEREO */);
+    if (!vo) {
+        std::cout << "failed to create the tracker: " << lvt_amd_last_error(nullptr) << std::endl;
+        return -1;
+    }
+    // like the reference, the trajectory has one row per frame of the sequence; frames after a LOST keep the default pose
+    long frame_count = 0;
+    for (;; frame_count++) {
+        std::ifstream pl(stem(0, frame_count) + ".png"), gl(stem(0, frame_count) + ".pgm");
+        if (!pl && !gl) break;
+        if (max_frames >= 0 && frame_count >= max_frames) break;
+    }
+    std::vector<double> rows;  // 12 per processed frame
+    double total_time = 0.0;
+    long n = 0;
+    for (long i = 0; i < frame_count; i++) {
+        if (i > 0 && (!load_gray(stem(0, i), left, err) || !load_gray(stem(1, i), right, err))) break;  // unreadable frame
+        if (left.w != params.img_width || left.h != params.img_height || right.w != left.w || right.h != left.h) {
+            std::cout << "frame " << i << ": image size changed" << std::endl;
+            break;
+        }
+        std::cout << "Frame number: " << i << "\r" << std::flush;
+        double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, t[3] = {0, 0, 0};
+        const auto t0 = std::chrono::steady_clock::now();
+        lvt_track(vo, left.px.data(), right.px.data(), left.h, left.w, R, t);
+        total_time += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        for (int r = 0; r < 3; r++) {
+            rows.push_back(R[r][0]), rows.push_back(R[r][1]), rows.push_back(R[r][2]);
+            rows.push_back(t[r]);
+        }
+        n++;
+        if (lvt_get_status(vo) == 3) break;  // LOST
+    }
+    std::ofstream file(out_name.c_str());
+    file << std::fixed;
+    static const double identity[12] = {1, 0, 0, 0, 0, 1, 0, 0, 0, 0, 1, 0};
+    for (long i = 0; i < frame_count; i++) {
+        const double *row = (i < n) ? &rows[(size_t)i * 12] : identity;
+        for (int k = 0; k < 12; k++) file << std::setprecision(9) << row[k] << (k == 11 ? "" : " ");
+        file << std::endl;
+    }
+    file.close();
+    lvt_destroy(vo);
+    std::cout << std::endl << "Frames: " << n << "/" << frame_count << "  Average frame processing time: " << (frame_count ? total_time / (double)frame_count : 0.0) << std::endl;
+    return 0;
+}

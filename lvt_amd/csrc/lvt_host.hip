@@ -561,7 +561,10 @@ LVT_API void lvt_amd_set_stream(lvt_handle h, void *hip_stream) {
     }
 }
 
-LVT_API const char *lvt_amd_last_error(lvt_handle h) { return static_cast<Context *>(h)->err.c_str(); }
+LVT_API const char *lvt_amd_last_error(lvt_handle h) {
+    if (!h) return "no handle (creation failed: bad parameters, or no HIP device -- there is no CPU fallback)";
+    return static_cast<Context *>(h)->err.c_str();
+}
 
 LVT_API void lvt_amd_profile_enable(lvt_handle h, int enable) {
     Context *c = static_cast<Context *>(h);

@@ -1,0 +1,84 @@
+"""examples/lvt_kitti (the dataset command line harness over the C-ABI) on a synthetic KITTI-layout
+directory: PNG / PGM decoding, calibration + config parsing and the trajectory file, against the Python binding."""
+import os
+import struct
+import subprocess
+import zlib
+
+import numpy as np
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(HERE)
+EXE = os.path.join(ROOT, "examples", "lvt_kitti")
+
+
+def _png(path, img, color=False, filt=0):
+    h, w = img.shape[:2]
+    raw = bytearray()
+    data = img if not color else np.repeat(img[:, :, None], 3, axis=2)
+    bpp = 3 if color else 1
+    prev = np.zeros(w * bpp, np.int32)
+    for y in range(h):
+        cur = data[y].reshape(-1).astype(np.int32)
+        if filt == 0:
+            out = cur
+        elif filt == 1:   # Sub
+            out = (cur - np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])) & 255
+        elif filt == 2:   # Up
+            out = (cur - prev) & 255
+        else:             # Paeth
+            a = np.concatenate([np.zeros(bpp, np.int32), cur[:-bpp]])
+            c = np.concatenate([np.zeros(bpp, np.int32), prev[:-bpp]])
+            p = a + prev - c
+            pa, pb, pc = np.abs(p - a), np.abs(p - prev), np.abs(p - c)
+            pred = np.where((pa <= pb) & (pa <= pc), a, np.where(pb <= pc, prev, c))
+            out = (cur - pred) & 255
+        raw.append(filt if filt < 3 else 4)
+        raw += out.astype(np.uint8).tobytes()
+        prev = cur
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    ihdr = struct.pack(">IIBBBBB", w, h, 8, 2 if color else 0, 0, 0, 0)
+    comp = zlib.compress(bytes(raw), 6)
+    with open(path, "wb") as f:  # two IDAT chunks: the reader must concatenate them
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", ihdr) + chunk(b"IDAT", comp[:len(comp) // 2]) + chunk(b"IDAT", comp[len(comp) // 2:]) + chunk(b"IEND", b""))
+
+
+@pytest.mark.gpu
+def test_kitti_cli_matches_the_binding(tmp_path):
+    import lvt_amd
+    from lvt_amd.synth import make_world
+    if not os.path.exists(EXE):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s"])
+    world = make_world("kitti", seed=3, scale=0.5)
+    prm = lvt_amd.kitti_params(width=world.W, height=world.H, fx=world.fx, fy=world.fy, cx=world.cx, cy=world.cy, baseline=world.baseline)
+    seq = tmp_path / "sequences" / "07"
+    (seq / "image_0").mkdir(parents=True)
+    (seq / "image_1").mkdir(parents=True)
+    (tmp_path / "calib").mkdir()
+    n = 6
+    frames = [world.render_stereo(i) for i in range(n)]
+    for i, (L, R) in enumerate(frames):
+        _png(str(seq / "image_0" / f"{i:06d}.png"), L, color=(i % 2 == 1), filt=i % 4)   # gray and RGB files, every filter type
+        if i < 3:
+            _png(str(seq / "image_1" / f"{i:06d}.png"), R, filt=(i + 1) % 4)
+        else:
+            with open(seq / "image_1" / f"{i:06d}.pgm", "wb") as f:
+                f.write(b"P5\n# synthetic\n%d %d\n255\n" % (R.shape[1], R.shape[0]) + R.tobytes())
+    with open(tmp_path / "calib" / "07.yml", "w") as f:
+        f.write("%%YAML:1.0\n\ncamera_matrix: !!opencv-matrix\n  rows: 3\n  cols: 3\n  dt: d\n  data: [ %.12e, 0, %.12e, 0, %.12e, %.12e, 0, 0, 1 ]\n\nbaseline: %.10e\n"
+                % (prm.fx, prm.cx, prm.fy, prm.cy, prm.baseline))
+    prm.write_yaml(str(tmp_path / "vo_config.yaml"))
+    out = subprocess.run([EXE, str(tmp_path / "sequences"), "7"], cwd=tmp_path, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    traj = np.loadtxt(tmp_path / "07.txt").reshape(-1, 3, 4)
+    assert traj.shape[0] == n
+
+    # the binding, with the parameters exactly as the harness builds them (YAML floats, calibration narrowed to float)
+    ref = lvt_amd.LvtSystem.create_from_file(str(tmp_path / "vo_config.yaml"), lvt_amd.eSensor_STEREO)
+    for i, (L, R) in enumerate(frames):
+        Rm, t = ref.track(L, R)
+        assert ref.get_state() == 2
+        assert np.allclose(traj[i, :, :3], Rm, atol=2e-9) and np.allclose(traj[i, :, 3], t, atol=2e-9), f"frame {i}"

@@ -1,13 +1,24 @@
-import sys, os
+#!/usr/bin/env python3
+"""clock64 phase stamps of the single-workgroup kernels (Ctl::dbg, bring-up profiling): k_cells of cell 0 / left eye,
+k_pnp and the map resolver inside k_track_mid.  Run on the GPU box:  python tools/cells_phases.py"""
+import os
+import sys
+
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
-import numpy as np, lvt_amd
+import lvt_amd
 from lvt_amd.synth import make_world
-w = make_world("kitti", seed=0); prm = lvt_amd.kitti_params()
+
+w = make_world("kitti", seed=0)
+prm = lvt_amd.kitti_params()
 vo = lvt_amd.LvtSystem.create(prm, 1)
-names = ["start", "compact", "links", "replay", "survivors", "anms-sort", "rank", "radii", "decision", "emit", "done", "end"]
+# stamp k .. k+1 of k_cells (k_features.hip STAMP(k)); dbg[1] is taken right after the corner gather
+phases = ["gather segments", "(links start)", "links + union-find + component maxima", "replay of tied components", "survivors",
+          "std::sort emulation", "rank", "radii", "decision radius", "emit", "done"]
 for i in range(4):
-    L, R = w.render_stereo(i); vo.track(L, R)
+    L, R = w.render_stereo(i)
+    vo.track(L, R)
     d = vo.debug_stamps()
-    print("frame", i, "n_raw", d[20], "n_kp", d[21], "n_out", d[22], " cycles:", {names[k + 1]: int(d[k + 1] - d[k]) for k in range(11)}, "total", int(d[11] - d[0]))
-    print("   pnp cycles: err", d[12], "build", d[13], "solve", d[14], "decide", d[15], "all", d[16], "calls", d[17], "| block_sum: wait", d[24], "write", d[25], "segments", d[26], "final", d[27], "read", 0)
-    print("   resolve(map): fixpoint iterations", d[18], "fixpoint cycles", d[19], "kernel cycles", d[23], "| init", d[31], "counts+scan", d[29], "pack", d[30], "max list len", d[28], "iteration ends", d[24], d[25], d[26], d[27])
+    print("frame", i, "k_cells cell 0 cycles:", {phases[k]: int(d[k + 1] - d[k]) for k in range(11)}, "total", int(d[11] - d[0]))
+    print("   k_pnp cycles: sweeps (incl. reductions)", d[12], "reductions", d[13], "solve", d[14], "decide", d[15], "all", d[16], "solve() calls", d[17])
+    print("   map resolver: fixpoint iterations", d[18], "fixpoint cycles", d[19], "kernel cycles", d[23], "| init", d[31], "counts+scan", d[29],
+          "pack", d[30], "longest list", d[28], "end of iterations 1-4", d[24], d[25], d[26], d[27])

@@ -96,6 +96,70 @@ def test_hamming_match_batched(hip_lib, oracle_lib, mode, variant):
     assert np.array_equal(got, ref), f"first mismatch {np.argwhere(got != ref)[:3]}"
 
 
+def _hamming_ref_np(qd, qxy, td, txy, tf, r2, mode, rows):
+    """vectorised restatement of the same semantics (masked top-2, ties -> lowest index) for sizes the scalar oracle loop
+    would take minutes on; checked against the oracle on the small cases above by construction of the same masks"""
+    B, M = qd.shape[:2]
+    N = td.shape[1]
+    out = np.zeros((B, M, 4), np.int32)
+    pop = np.array([bin(i).count("1") for i in range(256)], np.int32)
+    for b in range(B):
+        d = pop[qd[b][:, None, :] ^ td[b][None, :, :]].sum(axis=2).astype(np.int64)      # (M, N)
+        if mode == 0:
+            dx = (txy[b][None, :, 0] - qxy[b][:, None, 0]).astype(np.float32)
+            dy = (txy[b][None, :, 1] - qxy[b][:, None, 1]).astype(np.float32)
+            mask = ((dx * dx).astype(np.float32) + (dy * dy).astype(np.float32)).astype(np.float32) < np.float32(r2)
+        else:
+            y = qxy[b][:, 1]
+            s = np.maximum(y.astype(np.int64) - 2, 0)[:, None]
+            e = np.minimum(y.astype(np.int64) + 2, rows)[:, None]
+            ty = txy[b][None, :, 1]
+            mask = (ty >= s) & (ty <= e)
+        mask &= (tf[b] == 0)[None, :]
+        key = np.where(mask, d * 65536 + np.arange(N)[None, :], np.int64(1) << 40)
+        order = np.argsort(key, axis=1, kind="stable")[:, :2]
+        k1 = np.take_along_axis(key, order[:, :1], 1)[:, 0]
+        k2 = np.take_along_axis(key, order[:, 1:2], 1)[:, 0]
+        big = np.int64(1) << 40
+        out[b, :, 0] = np.where(k1 < big, k1 % 65536, -1)
+        out[b, :, 1] = np.where(k1 < big, k1 // 65536, 0x7FFFFFFF)
+        out[b, :, 2] = np.where(k2 < big, k2 % 65536, -1)
+        out[b, :, 3] = np.where(k2 < big, k2 // 65536, 0x7FFFFFFF)
+    return out
+
+
+@pytest.mark.parametrize("mode,r2,M,N", [(0, 625.0, 1100, 1700), (0, 2500.0, 700, 1200), (0, 40000.0, 300, 900), (1, 0.0, 1100, 1700),
+                                         (0, 625.0, 2048, 2048), (0, 625.0, 513, 1025)])
+def test_hamming_match_batched_large(hip_lib, mode, r2, M, N):
+    """every template variant of k_hamming_batched (queries / train features per thread 1..4; 3-, 5- and any-range windows;
+    row mode) at sizes where all lanes and both query stages are busy; flags, clustered points (windows > 64 candidates)"""
+    import torch
+    rng = np.random.default_rng(7 + M + N)
+    B, rows, cols = 3, 376, 1241
+    td = rng.integers(0, 256, (B, N, 32), dtype=np.uint8)
+    qd = rng.integers(0, 256, (B, M, 32), dtype=np.uint8)
+    txy = np.floor(rng.uniform(0, 1, (B, N, 2)) * [cols - 1, rows - 1]).astype(np.float32)
+    qxy = (rng.uniform(0, 1, (B, M, 2)) * [cols - 1, rows - 1]).astype(np.float32)
+    # problem 1: a dense cluster, so that many windows hold more than 64 candidates (one-stage fallback inside stage A)
+    txy[1, : N // 2] = np.floor(rng.uniform(0, 1, (N // 2, 2)) * [120, 90] + [300, 100]).astype(np.float32)
+    qxy[1, : M // 2] = (rng.uniform(0, 1, (M // 2, 2)) * [120, 90] + [300, 100]).astype(np.float32)
+    # problem 2: descriptor ties (8 prototypes) and queries outside the image
+    proto = rng.integers(0, 256, (8, 32), dtype=np.uint8)
+    td[2] = proto[rng.integers(0, 8, N)]
+    qd[2] = proto[rng.integers(0, 8, M)]
+    qxy[2, :20] = (rng.uniform(-60, 0, (20, 2))).astype(np.float32)
+    qxy[2, 20:40] += np.float32(1300)
+    tf = (rng.uniform(0, 1, (B, N)) < 0.15).astype(np.uint8)
+    ref = _hamming_ref_np(qd, qxy, td, txy, tf, r2, mode, rows)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    out = torch.zeros((B, M, 4), dtype=torch.int32, device="cuda")
+    us = hip_lib.hamming_match_batched(t(qd), t(qxy), t(td), t(txy), t(tf), r2, mode, rows, cols, out)
+    assert us > 0
+    got = out.cpu().numpy()
+    bad = np.argwhere((got != ref).any(axis=2))
+    assert bad.size == 0, f"{len(bad)} queries differ, first {bad[:3]}: got {got[tuple(bad[0])]} ref {ref[tuple(bad[0])]}"
+
+
 def test_pnp_standalone(hip_lib, oracle_lib):
     """k_pnp vs the oracle's g2o-LM restatement on synthetic 2D-3D sets incl. outliers (chi2 gate exercised)"""
     import lvt_amd

@@ -268,3 +268,27 @@ def test_parameters_defaults_and_yaml(tmp_path):
     q = LvtParameters.from_file(str(y))
     assert q.img_width == 1241 and abs(q.fx - 718.856) < 1e-9 and q.agast_threshold == 25
     assert q.img_height == 0 and q.tracking_radius == 0 and q.far_plane_distance == 0.0     # missing keys read as 0
+
+
+def test_vectorised_matcher_reference_equals_the_oracle():
+    """tests/test_gpu_primitives.py checks the large matcher launches against a numpy restatement (the scalar oracle loop
+    would take minutes there); this pins that restatement to the oracle's hamming_top2 on a small case, both mask kinds."""
+    from oracle import pyoracle as O
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("gpu_prims", os.path.join(os.path.dirname(__file__), "test_gpu_primitives.py"))
+    gp = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gp)
+    rng = np.random.default_rng(5)
+    B, M, N, rows, cols = 2, 60, 150, 120, 200
+    proto = rng.integers(0, 256, (5, 32), dtype=np.uint8)
+    td = proto[rng.integers(0, 5, (B, N))]          # ties everywhere
+    qd = proto[rng.integers(0, 5, (B, M))]
+    td[0] = rng.integers(0, 256, (N, 32), dtype=np.uint8)
+    txy = np.floor(rng.uniform(0, 1, (B, N, 2)) * [cols - 1, rows - 1]).astype(np.float32)
+    qxy = (rng.uniform(0, 1, (B, M, 2)) * [cols - 1, rows - 1]).astype(np.float32)
+    tf = (rng.uniform(0, 1, (B, N)) < 0.2).astype(np.uint8)
+    for mode, r2 in ((0, 625.0), (0, 2500.0), (1, 0.0)):
+        a = gp._hamming_ref(O, qd, qxy, td, txy, tf, r2, mode, rows, cols)
+        b = gp._hamming_ref_np(qd, qxy, td, txy, tf, r2, mode, rows)
+        assert np.array_equal(a, b), (mode, r2)

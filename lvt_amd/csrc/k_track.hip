@@ -214,10 +214,25 @@ __device__ __forceinline__ void candidates_body(Seq &S, int pass2, int par, Cand
         ncand = S.rncand + par * NF_MAX;
     }
     if (wave0 - wv >= M) return;  // no query for this block (block-uniform: wave0 - wv is the block's first query)
-    for (int j = threadIdx.x; j < N; j += nthreads) {
-        s_tx[j] = T.x[j];
-        s_ty[j] = T.y[j];
-        if (MODE != MODE_ROW) s_tc[j] = ((uint32_t)(uint16_t)T.hcy[j] << 16) | (uint32_t)(uint16_t)T.hcx[j];
+    // the first query's descriptor (and map point) are requested before the train data is staged: one memory round trip less
+    uint64_t qd0[4] = {0, 0, 0, 0};
+    double X0[3] = {0, 0, 0};
+    if (wave0 < M) {
+#pragma unroll
+        for (int k = 0; k < 4; k++) qd0[k] = qdesc[(size_t)wave0 * 4 + k];
+        if (MODE == MODE_MAP && PROJECT) {
+            const MapSoA &P0 = S.map[*S.map_cur];
+            X0[0] = P0.pos[3 * wave0], X0[1] = P0.pos[3 * wave0 + 1], X0[2] = P0.pos[3 * wave0 + 2];
+        }
+    }
+    {   // PROJECT: wavefront 0 arrives late (its thread 0 ran the frame prologue), the other waves stage the train data meanwhile
+        const int t0 = PROJECT ? (int)threadIdx.x - 64 : (int)threadIdx.x, tn = PROJECT ? nthreads - 64 : nthreads;
+        if (t0 >= 0)
+            for (int j = t0; j < N; j += tn) {
+                s_tx[j] = T.x[j];
+                s_ty[j] = T.y[j];
+                if (MODE != MODE_ROW) s_tc[j] = ((uint32_t)(uint16_t)T.hcy[j] << 16) | (uint32_t)(uint16_t)T.hcx[j];
+            }
     }
     __syncthreads();
     const int radius = S.prm.tracking_radius * ((MODE == MODE_MAP && pass2) ? 2 : 1);
@@ -226,7 +241,8 @@ __device__ __forceinline__ void candidates_body(Seq &S, int pass2, int par, Cand
         Query q;
         if (MODE == MODE_MAP && PROJECT) {
             MapSoA &P = S.map[*S.map_cur];
-            const double X[3] = {P.pos[3 * i], P.pos[3 * i + 1], P.pos[3 * i + 2]};
+            double X[3] = {X0[0], X0[1], X0[2]};
+            if (i != wave0) X[0] = P.pos[3 * i], X[1] = P.pos[3 * i + 1], X[2] = P.pos[3 * i + 2];
             double u, v;
             const bool visible = is_point_visible(X, C.w2c, S.prm, u, v);  // wave-uniform
             if (lane == 0) {
@@ -260,7 +276,7 @@ __device__ __forceinline__ void candidates_body(Seq &S, int pass2, int par, Cand
             make_query_row(S.prm, S.fb[par].feat[0].x[i], S.fb[par].feat[0].y[i], q);
         }
 #pragma unroll
-        for (int k = 0; k < 4; k++) q.d[k] = qdesc[(size_t)i * 4 + k];
+        for (int k = 0; k < 4; k++) q.d[k] = (i == wave0) ? qd0[k] : qdesc[(size_t)i * 4 + k];
         int cnt = 0;
         for (int base = 0; base < N; base += 64) {
             const int j = base + lane;
@@ -346,7 +362,7 @@ __global__ __launch_bounds__(256) void k_match_map(Seq *seqs, int par) {
         }
     }
     if (!active || first) return;
-    __syncthreads();
+    // no barrier here: the one after the train staging inside candidates_body also publishes w2c
     __shared__ uint32_t lbuf[4 * KC];
     __shared__ float s_tx[NF_MAX], s_ty[NF_MAX];
     __shared__ uint32_t s_tc[NF_MAX];

@@ -635,11 +635,12 @@ __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int pa
     const long long tk0 = clock64();
     const Feat &T = (MODE == MODE_ROW) ? S.fb[par].feat[1] : S.fb[par].feat[0];
     const int N = *T.n;
-    // find_matches pass 2 starts from cleared marks (lvt_local_map.cpp:176)
+    // Both users start from cleared marks: find_matches works on the marks of a fresh frame (k_gather zeroes them; pass 2
+    // clears them again, lvt_local_map.cpp:176) and row_match on those of the right image, which nothing else marks --
+    // so the tables are initialised without reading the global flags (one memory round trip less at kernel start).
     for (int j = tid; j < NF_MAX; j += RES_THREADS) {
-        const uint8_t f = (j < N && !(MODE == MODE_MAP && pass2)) ? T.flag[j] : 0;
-        if (j < N) L.flag[j] = f;
-        r_tab[j] = r_tab[NF_MAX + j] = f ? PERM : 0u;
+        L.flag[j] = 0;
+        r_tab[j] = r_tab[NF_MAX + j] = 0u;
     }
     int M;
     const uint64_t *qdesc;

@@ -243,7 +243,7 @@ def main():
                     traffic_src = "profiles/hamming_pmc.json (%s)" % pm.get("source", "rocprofv3 --pmc")
             except Exception:  # noqa: BLE001
                 pass
-            hb = {"kernel": "lvt::k_hamming_batched<0,3,2,3> (masked 2-NN Hamming matcher, radius mode)", "bound": "hbm", "achieved": round(ach, 1),
+            hb = {"kernel": "lvt::k_hamming_batched<0,3,1,2> (masked 2-NN Hamming matcher, radius mode)", "bound": "hbm", "achieved": round(ach, 1),
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                   "avg_us": round(med, 2), "launch": {"B": B, "M": M, "N": N, "algorithmic_bytes": byts},
                   "traffic_source": traffic_src,

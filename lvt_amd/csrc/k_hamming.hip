@@ -1,8 +1,9 @@
 // k_hamming.hip -- batched masked 2-NN Hamming matcher (the matcher of lvt_image_features_struct.cpp:68-148
 // + cv::BFMatcher::knnMatch(k=2, mask)) as ONE launch over B independent problems.
 //
-// One 512-thread workgroup per problem, two workgroups per CU (78 KB of LDS each at N = 1500, M = 1000), so the
-// HBM phase of one problem overlaps the LDS/VALU phase of the other.
+// One 1024-thread workgroup per problem, two workgroups per CU (76 KB of LDS each at N = 1500, M = 1000; <= 64 VGPRs, so
+// the CU holds its maximum of 8 waves per SIMD): the HBM / barrier phases of one problem overlap the LDS / VALU phases of
+// the other, and 512 -> 768 -> 1024 threads per workgroup measured 80 -> 77 -> 73 us for the KITTI-nominal launch.
 //   1. every thread fetches "its" train features (coordinates, flag, 32-B descriptor) and its query coordinates into
 //      registers -- all global loads of the problem are in flight at once;
 //   2. the unflagged train features are counting-sorted into the reference's 25-px hash cells (tracking mode) or
@@ -35,10 +36,10 @@ struct HammingArgs {
     long long *dbg;          // optional: phase cycle stamps of one workgroup
 };
 
-constexpr int HB_THREADS = 512;
+constexpr int HB_THREADS = 1024;
 constexpr int HB_WAVES = HB_THREADS / 64;
-constexpr int HB_TPT = 4;          // train features per thread  => N <= 2048
-constexpr int HB_QPT = 4;          // queries per thread         => M <= 2048
+constexpr int HB_TPT = 4;          // train features per thread  => N <= 4096 (LDS permitting)
+constexpr int HB_QPT = 4;          // queries per thread         => M <= 4096 (LDS permitting)
 constexpr int HB_NMAX = HB_THREADS * HB_TPT;
 constexpr int HB_MMAX = HB_THREADS * HB_QPT;
 constexpr int HB_HIST = 64;        // query classes by candidate count (>= 63 candidates share the first class)
@@ -56,7 +57,7 @@ __device__ __forceinline__ float div_cell(float y) {
 // NSP = number of candidate ranges a query keeps in registers: 1 (row mode), 3 (csr 1), 5 (csr 2); 0 = any csr, the
 // ranges are walked one after the other (no flattening)
 template <int MODE, int NSP, int QPT, int TPT>  // QPT = ceil(M / 512) rounds of queries, TPT = ceil(N / 512) train features per thread
-__global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_hamming_batched(HammingArgs a) {
+__global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_hamming_batched(HammingArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int N = a.N, M = a.M;
     const int nbins = a.nbx * a.nby;
@@ -210,6 +211,9 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         if (q < M) {
             qkey[k] = HB_HIST - 1 - min(count_of(qp[k]), HB_HIST - 1);
             qrank[k] = atomicAdd(&s_hist[qkey[k]], 1);
+            // stage 4a visits the queries in sorted order: it finds the coordinates in the query's (still unused) mask slot
+            // instead of going back to HBM for them
+            if (MODE == 0 && NSP > 0) s_mask[q] = make_uint2(__float_as_uint(qp[k].x), __float_as_uint(qp[k].y));
         }
     }
     __syncthreads();
@@ -318,14 +322,14 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
         int aq[QPT], akey[QPT], arank[QPT];
         {
             int q = slot_query(0, M);
-            float2 p = qxy[max(q, 0)];
 #pragma unroll
             for (int j = 0; j < QPT; j++) {
                 aq[j] = -1, akey[j] = 0, arank[j] = 0;
                 {
                     const int qn = slot_query(j + 1, M);
-                    const float2 np = qxy[max(qn, 0)];
                     if (q >= 0) {
+                        const uint2 pw = s_mask[q];  // coordinates stashed by the pre-pass; the slot receives the mask below
+                        const float2 p = make_float2(__uint_as_float(pw.x), __uint_as_float(pw.y));
                         const Ranges R = ranges(p);
                         const int c1 = R.l0, c2 = c1 + R.l1, c3 = c2 + R.l2, c4 = c3 + R.l3, total = c4 + R.l4;
                         const int o0 = R.s0, o1 = R.s1 - c1, o2 = R.s2 - c2, o3 = R.s3 - c3, o4 = R.s4 - c4;
@@ -354,7 +358,7 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(4, 4
                             akey[j] = HB_HIST - 1 - min(__popc(lo) + __popc(hi), HB_HIST - 1);
                         }
                     }
-                    q = qn, p = np;
+                    q = qn;
                 }
             }
         }

@@ -82,3 +82,59 @@ def test_kitti_cli_matches_the_binding(tmp_path):
         Rm, t = ref.track(L, R)
         assert ref.get_state() == 2
         assert np.allclose(traj[i, :, :3], Rm, atol=2e-9) and np.allclose(traj[i, :, 3], t, atol=2e-9), f"frame {i}"
+
+
+def _png16(path, img16):
+    h, w = img16.shape
+    raw = bytearray()
+    be = img16.astype(">u2")
+    for y in range(h):
+        raw.append(0)
+        raw += be[y].tobytes()
+
+    def chunk(t, d):
+        return struct.pack(">I", len(d)) + t + d + struct.pack(">I", zlib.crc32(t + d) & 0xFFFFFFFF)
+    with open(path, "wb") as f:
+        f.write(b"\x89PNG\r\n\x1a\n" + chunk(b"IHDR", struct.pack(">IIBBBBB", w, h, 16, 0, 0, 0, 0)) + chunk(b"IDAT", zlib.compress(bytes(raw), 6)) + chunk(b"IEND", b""))
+
+
+@pytest.mark.gpu
+def test_tum_cli_matches_the_binding(tmp_path):
+    import lvt_amd
+    from lvt_amd.synth import make_world
+    exe = os.path.join(ROOT, "examples", "lvt_tum")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s"])
+    world = make_world("tum", seed=2, scale=0.5)
+    prm = lvt_amd.tum_params(width=world.W, height=world.H, fx=world.fx, fy=world.fy, cx=world.cx, cy=world.cy)
+    ds = tmp_path / "root" / "fr1_synth"
+    (ds / "rgb").mkdir(parents=True)
+    (ds / "depth").mkdir(parents=True)
+    (tmp_path / "assoc").mkdir()
+    n = 5
+    frames = []
+    with open(tmp_path / "assoc" / "fr1_synth.txt", "w") as af:
+        for i in range(n):
+            gray, depth = world.render_rgbd(i)
+            d16 = np.clip(np.rint(depth.astype(np.float64) * 5000.0), 0, 65535).astype(np.uint16)
+            _png(str(ds / "rgb" / f"{i:04d}.png"), gray, color=True, filt=(i % 4))
+            _png16(str(ds / "depth" / f"{i:04d}.png"), d16)
+            af.write(f"{1305031102.175304 + 0.033 * i:.6f} rgb/{i:04d}.png {1305031102.160407 + 0.033 * i:.6f} depth/{i:04d}.png\n")
+            frames.append((gray, d16.astype(np.float32) * np.float32(1.0 / 5000.0)))
+    prm.write_yaml(str(tmp_path / "config.yaml"))
+    out = subprocess.run([exe, str(tmp_path / "root"), str(tmp_path / "assoc"), "fr1_synth", str(tmp_path / "config.yaml")], cwd=tmp_path, capture_output=True, text=True,
+                         timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    traj = np.loadtxt(tmp_path / "fr1_synth.txt").reshape(-1, 8)
+    assert traj.shape[0] == n
+
+    import ctypes as C
+    L = lvt_amd.load_library()
+    pod = lvt_amd.ParamsPOD()
+    assert L.lvt_amd_params_from_file(str(tmp_path / "config.yaml").encode(), C.byref(pod)) == 1
+    ref = lvt_amd.LvtSystem(L.lvt_amd_create(C.byref(pod), 2), 2)
+    for i, (gray, depth) in enumerate(frames):
+        ref.track(gray, depth)
+        assert ref.get_state() == 2
+        q, p = ref.pose()
+        assert np.allclose(traj[i, 1:4], p, atol=2e-7) and np.allclose(traj[i, 4:8], [q[1], q[2], q[3], q[0]], atol=2e-7), f"frame {i}"

@@ -61,11 +61,12 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const int N = a.N, M = a.M;
     const int nbins = a.nbx * a.nby;
-    // carve: desc [N][2] uint4 | xy [N] float2 | mask [M] uint2 | start [nbins + 1] | idx [N] u16 | order [M] u16
+    // carve: desc [N][2] uint4 | xy [N] float2 | per-query slot [M] 12 B | start [nbins + 1] | idx [N] u16 | order [M] u16
     uint4 *s_desc = reinterpret_cast<uint4 *>(smem);
     float2 *s_xy = reinterpret_cast<float2 *>(s_desc + (size_t)N * 2);
     uint2 *s_mask = reinterpret_cast<uint2 *>(s_xy + N);
-    int *s_start = reinterpret_cast<int *>(s_mask + M);
+    uint32_t *s_q = reinterpret_cast<uint32_t *>(s_mask);  // 12 B per query: packed ranges + candidate mask (see stage 4)
+    int *s_start = reinterpret_cast<int *>(s_q + 3 * (size_t)M);
     uint16_t *s_idx = reinterpret_cast<uint16_t *>(s_start + nbins + 1);
     uint16_t *s_order = s_idx + ((N + 1) & ~1);
     __shared__ int s_scan[32];
@@ -209,11 +210,21 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         const int q = tid + k * HB_THREADS;
         qkey[k] = 0, qrank[k] = 0;
         if (q < M) {
-            qkey[k] = HB_HIST - 1 - min(count_of(qp[k]), HB_HIST - 1);
+            if (MODE == 0 && NSP == 3) {
+                // the three candidate ranges travel with the query through both stages, packed into two words (11-bit
+                // starts, 6-bit lengths): neither stage recomputes hash cells, window clamps or bin lookups
+                const Ranges R = ranges(qp[k]);
+                qkey[k] = HB_HIST - 1 - min(R.l0 + R.l1 + R.l2, HB_HIST - 1);
+                const bool fits = (N <= 2048) && (R.l0 < 64) && (R.l1 < 64) && (R.l2 < 64);
+                s_q[3 * q] = fits ? ((uint32_t)R.s0 | ((uint32_t)R.s1 << 11) | ((uint32_t)R.l0 << 22)) : 0xFFFFFFFFu;
+                s_q[3 * q + 1] = (uint32_t)R.s2 | ((uint32_t)R.l1 << 11) | ((uint32_t)R.l2 << 17);
+            } else {
+                qkey[k] = HB_HIST - 1 - min(count_of(qp[k]), HB_HIST - 1);
+                // stage 4a visits the queries in sorted order: it finds the coordinates in the query's (still unused) mask
+                // slot instead of going back to HBM for them
+                if (MODE == 0 && NSP > 0) s_mask[q] = make_uint2(__float_as_uint(qp[k].x), __float_as_uint(qp[k].y));
+            }
             qrank[k] = atomicAdd(&s_hist[qkey[k]], 1);
-            // stage 4a visits the queries in sorted order: it finds the coordinates in the query's (still unused) mask slot
-            // instead of going back to HBM for them
-            if (MODE == 0 && NSP > 0) s_mask[q] = make_uint2(__float_as_uint(qp[k].x), __float_as_uint(qp[k].y));
         }
     }
     __syncthreads();
@@ -303,7 +314,136 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     };
 
     constexpr bool TWO_STAGE = (MODE == 0 && NSP > 0);
-    if (!TWO_STAGE) {
+    constexpr bool PACKED = (MODE == 0 && NSP == 3);
+    if (PACKED) {
+        // ---- 4a (packed ranges). radius test over every window candidate -> one bit per candidate of the flattened index space
+        constexpr int MASK_BITS = 41;  // 32 in word 2, 9 in the free top of word 1
+        if (tid < HB_HIST) s_hist[tid] = 0;
+        int aq[QPT], akey[QPT], arank[QPT];
+        {
+            int q = slot_query(0, M);
+            float2 p = qxy[max(q, 0)];
+#pragma unroll
+            for (int j = 0; j < QPT; j++) {
+                aq[j] = -1, akey[j] = 0, arank[j] = 0;
+                const int qn = slot_query(j + 1, M);
+                const float2 np = qxy[max(qn, 0)];
+                if (q >= 0) {
+                    const uint32_t W0 = s_q[3 * q], W1 = s_q[3 * q + 1];
+                    Ranges R;
+                    R.s3 = R.l3 = R.s4 = R.l4 = 0;
+                    R.y0 = R.y1 = R.x0 = R.x1 = 0;
+                    R.s0 = (int)(W0 & 2047u), R.s1 = (int)((W0 >> 11) & 2047u), R.l0 = (int)(W0 >> 22);
+                    R.s2 = (int)(W1 & 2047u), R.l1 = (int)((W1 >> 11) & 63u), R.l2 = (int)((W1 >> 17) & 63u);
+                    const bool packed = W0 != 0xFFFFFFFFu;
+                    const int c1 = R.l0, c2 = c1 + R.l1, total = c2 + R.l2;
+                    const int o0 = R.s0, o1 = R.s1 - c1, o2 = R.s2 - c2;
+                    const int c3 = 0, c4 = 0, o3 = 0, o4 = 0;
+                    (void)c3, (void)c4, (void)o3, (void)o4;
+                    if (!packed || total > MASK_BITS) {  // ranges or mask do not fit their slot: matched here and now (rare)
+                        match_all(q, p, qd[2 * q], qd[2 * q + 1], packed ? R : ranges(p));
+                    } else {
+                        uint32_t lo = 0, hi = 0;
+                        const int t0 = min(total, 32);
+#pragma unroll 4
+                        for (int v = 0; v < t0; v++) {
+                            int it;
+                            LVT_POS_OF(it, v)
+                            const float2 r = s_xy[it];
+                            const float dx = r.x - p.x, dy = r.y - p.y;
+                            lo |= ((dx * dx + dy * dy) < a.r2) ? (1u << v) : 0u;
+                        }
+                        for (int v = 32; v < total; v++) {
+                            int it;
+                            LVT_POS_OF(it, v)
+                            const float2 r = s_xy[it];
+                            const float dx = r.x - p.x, dy = r.y - p.y;
+                            hi |= ((dx * dx + dy * dy) < a.r2) ? (1u << (v - 32)) : 0u;
+                        }
+                        s_q[3 * q + 2] = lo;
+                        s_q[3 * q + 1] = (W1 & 0x7FFFFFu) | (hi << 23);
+                        aq[j] = q;
+                        akey[j] = HB_HIST - 1 - min(__popc(lo) + __popc(hi), HB_HIST - 1);
+                    }
+                }
+                q = qn, p = np;
+            }
+        }
+        // ---- 4b. the queries again, sorted by the number of candidates inside the circle; only descriptors are fetched
+        __syncthreads();  // s_hist zeroed, every stage-4a read of s_order done
+#pragma unroll
+        for (int j = 0; j < QPT; j++)
+            if (aq[j] >= 0) arank[j] = atomicAdd(&s_hist[akey[j]], 1);
+        __syncthreads();
+        if (wv == 0) {
+            const int v = s_hist[lane];
+            const int incl = wave_incl_scan(v);
+            s_hist[lane] = incl - v;
+            if (lane == 63) s_scan[0] = incl;
+        }
+        __syncthreads();
+        const int M2 = s_scan[0];
+#pragma unroll
+        for (int j = 0; j < QPT; j++)
+            if (aq[j] >= 0) s_order[s_hist[akey[j]] + arank[j]] = (uint16_t)aq[j];
+        __syncthreads();
+        if (dbg) dbg[7] = clock64();
+
+        int q = slot_query(0, M2);
+        uint4 w0 = qd[2 * max(q, 0)], w1 = qd[2 * max(q, 0) + 1];
+        for (int j = 0; j < rounds; j++) {
+            const int qn = slot_query(j + 1, M2);
+            const uint4 nw0 = qd[2 * max(qn, 0)], nw1 = qd[2 * max(qn, 0) + 1];
+            if (q >= 0) {
+                const uint64_t d0 = ((uint64_t)w0.y << 32) | w0.x, d1 = ((uint64_t)w0.w << 32) | w0.z;
+                const uint64_t d2 = ((uint64_t)w1.y << 32) | w1.x, d3 = ((uint64_t)w1.w << 32) | w1.z;
+                uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+                const uint32_t W0 = s_q[3 * q], W1 = s_q[3 * q + 1], W2 = s_q[3 * q + 2];
+                const int c1 = (int)(W0 >> 22), c2 = c1 + (int)((W1 >> 11) & 63u);
+                const int o0 = (int)(W0 & 2047u), o1 = (int)((W0 >> 11) & 2047u) - c1, o2 = (int)(W1 & 2047u) - c2;
+                const int c3 = 0, c4 = 0, o3 = 0, o4 = 0;
+                (void)c3, (void)c4, (void)o3, (void)o4;
+                auto walk_bits = [&](uint32_t m, int base) {  // set bits of m, software-pipelined by one candidate
+                    if (m == 0) return;
+                    int it;
+                    {
+                        const int v = base + __ffs((int)m) - 1;
+                        LVT_POS_OF(it, v)
+                    }
+                    m &= m - 1;
+                    uint4 a0 = s_desc[2 * it], a1 = s_desc[2 * it + 1];
+                    uint32_t id = s_idx[it];
+                    for (;;) {
+                        const bool more = m != 0;
+                        int itn;
+                        {
+                            const int v = base + ((__ffs((int)m) - 1) & 31);
+                            LVT_POS_OF(itn, v)
+                        }
+                        m &= m - 1;
+                        const uint4 b0 = s_desc[2 * itn], b1 = s_desc[2 * itn + 1];
+                        const uint32_t idn = s_idx[itn];
+                        const int d = __popcll(d0 ^ (((uint64_t)a0.y << 32) | a0.x)) + __popcll(d1 ^ (((uint64_t)a0.w << 32) | a0.z)) +
+                                      __popcll(d2 ^ (((uint64_t)a1.y << 32) | a1.x)) + __popcll(d3 ^ (((uint64_t)a1.w << 32) | a1.z));
+                        const uint32_t key = ((uint32_t)d << 16) | id;
+                        k2 = min(k2, max(k1, key));
+                        k1 = min(k1, key);
+                        if (!more) break;
+                        a0 = b0, a1 = b1, id = idn;
+                    }
+                };
+                walk_bits(W2, 0);
+                walk_bits(W1 >> 23, 32);
+                int4 o;
+                o.x = (k1 == 0xFFFFFFFFu) ? -1 : (int)(k1 & 0xFFFFu);
+                o.y = (k1 == 0xFFFFFFFFu) ? 0x7FFFFFFF : (int)(k1 >> 16);
+                o.z = (k2 == 0xFFFFFFFFu) ? -1 : (int)(k2 & 0xFFFFu);
+                o.w = (k2 == 0xFFFFFFFFu) ? 0x7FFFFFFF : (int)(k2 >> 16);
+                out[q] = o;
+            }
+            q = qn, w0 = nw0, w1 = nw1;
+        }
+    } else if (!TWO_STAGE) {
         int q = slot_query(0, M);
         uint4 w0 = qd[2 * max(q, 0)], w1 = qd[2 * max(q, 0) + 1];
         float2 p = qxy[max(q, 0)];
@@ -443,7 +583,7 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
 }
 
 static inline size_t hamming_lds_bytes(int N, int M, int nbins) {
-    return (size_t)N * 32 + (size_t)N * 8 + (size_t)M * 8 + (size_t)(nbins + 1) * 4 + (size_t)((N + 1) & ~1) * 2 + (size_t)((M + 1) & ~1) * 2 + 16;
+    return (size_t)N * 32 + (size_t)N * 8 + (size_t)M * 12 + (size_t)(nbins + 1) * 4 + (size_t)((N + 1) & ~1) * 2 + (size_t)((M + 1) & ~1) * 2 + 16;
 }
 
 }  // namespace lvt

@@ -88,7 +88,7 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=600, help="upper bound of frames timed on the CPU oracle")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--depth", type=int, default=4, help="poses outstanding in the async pipeline (1 = synchronous)")
-    ap.add_argument("--hamming-batch", type=int, default=2048)
+    ap.add_argument("--hamming-batch", type=int, default=8192, help="problems per matcher launch (SURVEY 8d: the roofline fraction is reported on the largest batch)")
     ap.add_argument("--seqs-per-gpu", type=int, default=1, help="independent sequences advanced in lock-step on each GPU")
     args = ap.parse_args()
 

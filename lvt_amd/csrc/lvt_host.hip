@@ -55,6 +55,8 @@ __global__ __launch_bounds__(256) void k_repitch(const uint8_t *src, uint8_t *ds
 }
 
 struct Context {
+    double host_enq_us = 0, host_wait_us = 0;  // host time spent enqueueing / blocking (LVT_AMD_HOST_TIMING=1 prints it at destroy)
+    long host_enq_n = 0, host_wait_n = 0;
     int B = 1;                 // sequences advanced in lock-step by one launch chain
     int sensor = 1;
     Params prm{};
@@ -394,8 +396,6 @@ static const char *kProfNames[Context::PROF_SLOTS] = {
 static void collect_oldest(Context *c);
 
 // frame inputs must already be in h_fargs[slot] (and any upload enqueued on stream_f)
-static double g_enq_us = 0, g_wait_us = 0;
-static long g_enq_n = 0, g_wait_n = 0;
 struct HostTimer {
     double *acc;
     std::chrono::steady_clock::time_point t0;
@@ -403,8 +403,8 @@ struct HostTimer {
     ~HostTimer() { *acc += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(); }
 };
 static void enqueue_frame(Context *c) {
-    HostTimer ht(&g_enq_us);
-    g_enq_n++;
+    HostTimer ht(&c->host_enq_us);
+    c->host_enq_n++;
     const int B = c->B;
     const Params &p = c->prm;
     Seq *S = c->d_seqs;
@@ -446,8 +446,8 @@ static void enqueue_frame(Context *c) {
 
 // wait for the oldest un-collected frame; its record becomes "last"
 static void collect_oldest(Context *c) {
-    HostTimer ht(&g_wait_us);
-    g_wait_n++;
+    HostTimer ht(&c->host_wait_us);
+    c->host_wait_n++;
     if (c->done >= c->enq) return;
     const int slot = (int)(c->done % RING);
     HIPCHK(c, hipEventSynchronize(c->ev_done[slot]));
@@ -534,9 +534,12 @@ LVT_API lvt_handle lvt_create(const char *config_file_name, int sensor_type) {
 }
 
 LVT_API void lvt_destroy(lvt_handle h) {
-    if (std::getenv("LVT_AMD_HOST_TIMING") && g_enq_n > 0)
-        std::fprintf(stderr, "lvt_amd host timing: %ld frames enqueued, %.1f us each; %ld collected, %.1f us each (blocking)\n", g_enq_n,
-                     g_enq_us / g_enq_n, g_wait_n, g_wait_us / std::max(g_wait_n, 1L));
+    if (h && std::getenv("LVT_AMD_HOST_TIMING")) {
+        const Context *c = static_cast<Context *>(h);
+        if (c->host_enq_n > 0)
+            std::fprintf(stderr, "lvt_amd host timing: %ld frames enqueued, %.1f us each; %ld collected, %.1f us each (blocking)\n", c->host_enq_n,
+                         c->host_enq_us / c->host_enq_n, c->host_wait_n, c->host_wait_us / std::max(c->host_wait_n, 1L));
+    }
     try {
         delete static_cast<Context *>(h);
     } catch (...) {

@@ -123,6 +123,19 @@ LVT_API float lvt_amd_hamming_match_batched_n(const void *q_desc, const void *q_
                                               float r2, int mode, int img_rows, int img_cols, void *out,
                                               void *hip_stream, int launches);
 
+/* ---- EuRoC pre-step: stereo rectification (reference examples/euroc/euroc_example.cpp:95-107,142-143 = cv::initUndistortRectifyMap
+ * with CV_32FC1 maps + cv::remap INTER_LINEAR, BORDER_CONSTANT 0).  K, R, Pnew row-major 3x3, D = k1 k2 p1 p2 k3.
+ * The maps are built once on the device; lvt_amd_rectify_device rectifies one 8-bit image already in HBM (dst_pitch % 4 == 0,
+ * returns 0 on success), lvt_amd_rectify does the same for tightly packed host buffers. ---- */
+typedef void *lvt_amd_rectifier;
+LVT_API lvt_amd_rectifier lvt_amd_rectifier_create(const double K[9], const double D[5], const double R[9],
+                                                   const double Pnew[9], int width, int height);
+LVT_API void lvt_amd_rectifier_destroy(lvt_amd_rectifier r);
+LVT_API int lvt_amd_rectify_device(lvt_amd_rectifier r, const void *d_src, int src_pitch, void *d_dst, int dst_pitch,
+                                   void *hip_stream);
+LVT_API int lvt_amd_rectify(lvt_amd_rectifier r, const unsigned char *src, unsigned char *dst);
+LVT_API int lvt_amd_rectifier_get_maps(lvt_amd_rectifier r, float *map1, float *map2);
+
 #ifdef __cplusplus
 }
 #endif

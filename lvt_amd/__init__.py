@@ -28,7 +28,8 @@ ABI_SYMBOLS = [
     "lvt_amd_set_stream", "lvt_amd_last_error", "lvt_amd_get_counts", "lvt_amd_get_features",
     "lvt_amd_get_matches", "lvt_amd_get_row_matches", "lvt_amd_get_map", "lvt_amd_get_staged",
     "lvt_amd_get_pose", "lvt_amd_get_predicted_pose", "lvt_amd_get_plane", "lvt_amd_pnp",
-    "lvt_amd_hamming_match_batched", "lvt_amd_hamming_match_batched_n", "lvt_amd_profile_enable", "lvt_amd_profile_read", "lvt_amd_get_debug",
+    "lvt_amd_hamming_match_batched", "lvt_amd_hamming_match_batched_n", "lvt_amd_rectifier_create", "lvt_amd_rectifier_destroy",
+    "lvt_amd_rectify_device", "lvt_amd_rectify", "lvt_amd_rectifier_get_maps", "lvt_amd_profile_enable", "lvt_amd_profile_read", "lvt_amd_get_debug",
     "lvt_amd_batch_create", "lvt_amd_batch_size", "lvt_amd_batch_track_device_async", "lvt_amd_batch_wait",
     "lvt_amd_batch_get_counts",
 ]
@@ -92,6 +93,12 @@ def load_library():
     L.lvt_amd_pnp.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]
     L.lvt_amd_hamming_match_batched.restype = C.c_float
     L.lvt_amd_hamming_match_batched.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp]
+    L.lvt_amd_rectifier_create.restype = vp
+    L.lvt_amd_rectifier_create.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int]
+    L.lvt_amd_rectifier_destroy.argtypes = [vp]
+    L.lvt_amd_rectify_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
+    L.lvt_amd_rectify.argtypes = [vp, vp, vp]
+    L.lvt_amd_rectifier_get_maps.argtypes = [vp, vp, vp]
     L.lvt_amd_hamming_match_batched_n.restype = C.c_float
     L.lvt_amd_hamming_match_batched_n.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int]
     L.lvt_amd_profile_enable.argtypes = [vp, C.c_int]
@@ -349,3 +356,40 @@ def hamming_match_batched(q_desc, q_xy, t_desc, t_xy, t_flag, r2: float, mode: i
     if us < 0:
         raise RuntimeError("lvt_amd_hamming_match_batched failed")
     return us
+
+
+class Rectifier:
+    """cv::initUndistortRectifyMap + cv::remap(INTER_LINEAR) on the GPU (the EuRoC example's pre-step, SURVEY 8(f) row 2)."""
+
+    def __init__(self, K, D, R, P, width: int, height: int):
+        L = load_library()
+        a = [np.ascontiguousarray(x, dtype=np.float64).reshape(-1) for x in (K, D, R, P)]
+        self._keep = a
+        self.w, self.h = width, height
+        self._h = L.lvt_amd_rectifier_create(_p(a[0]), _p(a[1]), _p(a[2]), _p(a[3]), width, height)
+        if not self._h:
+            raise RuntimeError("lvt_amd_rectifier_create returned NULL")
+
+    def maps(self):
+        m1 = np.zeros((self.h, self.w), np.float32); m2 = np.zeros((self.h, self.w), np.float32)
+        if load_library().lvt_amd_rectifier_get_maps(self._h, _p(m1), _p(m2)) != 0:
+            raise RuntimeError("lvt_amd_rectifier_get_maps failed")
+        return m1, m2
+
+    def rectify(self, img):
+        a = _u8(img)
+        out = np.zeros((self.h, self.w), np.uint8)
+        if load_library().lvt_amd_rectify(self._h, _p(a), _p(out)) != 0:
+            raise RuntimeError("lvt_amd_rectify failed")
+        return out
+
+    def close(self):
+        if self._h:
+            load_library().lvt_amd_rectifier_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass

@@ -1047,7 +1047,6 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double *red, double *
         constexpr int STRIDE = PNP_THREADS + 8;
         static_assert(NV * SEG <= PNP_THREADS && PNP_THREADS % SEG == 0, "block_sum layout");
         double *part = red + 384;  // [NV][STRIDE]
-        double *seg = red + 128;   // [NV][SEG]
         long long b0 = clock64();
         __syncthreads();
         long long b1 = clock64();

@@ -15,6 +15,7 @@
 #include "k_features.hip"
 #include "k_track.hip"
 #include "k_hamming.hip"
+#include "k_rectify.hip"
 
 #include <cmath>
 #include <chrono>
@@ -1042,6 +1043,90 @@ LVT_API float lvt_amd_hamming_match_batched(const void *q_desc, const void *q_xy
                                             int B, int M, int N, float r2, int mode, int img_rows, int img_cols, void *out,
                                             void *hip_stream) {
     return lvt_amd_hamming_match_batched_n(q_desc, q_xy, t_desc, t_xy, t_flag, B, M, N, r2, mode, img_rows, img_cols, out, hip_stream, 1);
+}
+
+
+// ---- EuRoC pre-step: rectification -------------------------------------------------------------------------------------
+struct Rectifier {
+    int w = 0, h = 0, pitch = 0;
+    float *d_map1 = nullptr, *d_map2 = nullptr;
+    uint8_t *d_src = nullptr, *d_dst = nullptr;  // staging for the host-buffer entry point
+};
+
+LVT_API lvt_amd_rectifier lvt_amd_rectifier_create(const double K[9], const double D[5], const double R[9], const double Pnew[9], int width,
+                                                   int height) {
+    if (!K || !D || !R || !Pnew || width <= 0 || height <= 0) return nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return nullptr;  // no CPU fallback
+    Rectifier *r = new (std::nothrow) Rectifier;
+    if (!r) return nullptr;
+    r->w = width, r->h = height, r->pitch = ((width + 63) / 64) * 64;
+    const size_t n = (size_t)width * height;
+    if (hipMalloc((void **)&r->d_map1, n * 4) != hipSuccess || hipMalloc((void **)&r->d_map2, n * 4) != hipSuccess ||
+        hipMalloc((void **)&r->d_src, n) != hipSuccess || hipMalloc((void **)&r->d_dst, (size_t)r->pitch * height) != hipSuccess) {
+        lvt_amd_rectifier_destroy(r);
+        return nullptr;
+    }
+    RectifyArgs a;
+    {   // iR = (Pnew * R)^-1: 3x3 product in k-ascending order, closed-form inverse (cv::gemm / cv::invert for 3x3 doubles)
+        double AR[9];
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double s = 0;
+                for (int k = 0; k < 3; k++) s += Pnew[3 * i + k] * R[3 * k + j];
+                AR[3 * i + j] = s;
+            }
+        const double *S = AR;
+        double ir[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+        double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);
+        if (d != 0.) {
+            d = 1. / d;
+            ir[0] = (S[4] * S[8] - S[5] * S[7]) * d, ir[1] = (S[2] * S[7] - S[1] * S[8]) * d, ir[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+            ir[3] = (S[5] * S[6] - S[3] * S[8]) * d, ir[4] = (S[0] * S[8] - S[2] * S[6]) * d, ir[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+            ir[6] = (S[3] * S[7] - S[4] * S[6]) * d, ir[7] = (S[1] * S[6] - S[0] * S[7]) * d, ir[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+        }
+        for (int k = 0; k < 9; k++) a.ir[k] = ir[k];
+    }
+    a.fx = K[0], a.fy = K[4], a.u0 = K[2], a.v0 = K[5];
+    a.k1 = D[0], a.k2 = D[1], a.p1 = D[2], a.p2 = D[3], a.k3 = D[4];
+    a.w = width, a.h = height;
+    hipLaunchKernelGGL(k_rectify_map, dim3((height + 63) / 64), dim3(64), 0, 0, a, r->d_map1, r->d_map2);
+    if (hipDeviceSynchronize() != hipSuccess) {
+        lvt_amd_rectifier_destroy(r);
+        return nullptr;
+    }
+    return r;
+}
+
+LVT_API void lvt_amd_rectifier_destroy(lvt_amd_rectifier h) {
+    Rectifier *r = static_cast<Rectifier *>(h);
+    if (!r) return;
+    (void)hipFree(r->d_map1), (void)hipFree(r->d_map2), (void)hipFree(r->d_src), (void)hipFree(r->d_dst);
+    delete r;
+}
+
+LVT_API int lvt_amd_rectify_device(lvt_amd_rectifier h, const void *d_src, int src_pitch, void *d_dst, int dst_pitch, void *hip_stream) {
+    Rectifier *r = static_cast<Rectifier *>(h);
+    if (!r || !d_src || !d_dst || src_pitch < r->w || dst_pitch < r->w || (dst_pitch & 3)) return -1;
+    hipLaunchKernelGGL(k_rectify, dim3((dst_pitch / 4 + 255) / 256, r->h), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                       static_cast<const uint8_t *>(d_src), r->w, r->h, src_pitch, r->d_map1, r->d_map2, r->w, r->h, static_cast<uint8_t *>(d_dst), dst_pitch);
+    return hipGetLastError() == hipSuccess ? 0 : -1;
+}
+
+LVT_API int lvt_amd_rectify(lvt_amd_rectifier h, const unsigned char *src, unsigned char *dst) {
+    Rectifier *r = static_cast<Rectifier *>(h);
+    if (!r || !src || !dst) return -1;
+    const size_t n = (size_t)r->w * r->h;
+    if (hipMemcpy(r->d_src, src, n, hipMemcpyHostToDevice) != hipSuccess) return -1;
+    if (lvt_amd_rectify_device(r, r->d_src, r->w, r->d_dst, r->pitch, nullptr) != 0) return -1;
+    return hipMemcpy2D(dst, (size_t)r->w, r->d_dst, (size_t)r->pitch, (size_t)r->w, (size_t)r->h, hipMemcpyDeviceToHost) == hipSuccess ? 0 : -1;
+}
+
+LVT_API int lvt_amd_rectifier_get_maps(lvt_amd_rectifier h, float *map1, float *map2) {
+    Rectifier *r = static_cast<Rectifier *>(h);
+    if (!r || !map1 || !map2) return -1;
+    const size_t n = (size_t)r->w * r->h * 4;
+    return (hipMemcpy(map1, r->d_map1, n, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(map2, r->d_map2, n, hipMemcpyDeviceToHost) == hipSuccess) ? 0 : -1;
 }
 
 }  // extern "C"

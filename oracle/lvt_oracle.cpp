@@ -1558,4 +1558,85 @@ void lvto_motion_predict(double st[14], const double q[4], const double p[3], do
     p_out[0] = o.p.x, p_out[1] = o.p.y, p_out[2] = o.p.z;
 }
 
+
+// ---- EuRoC pre-step: stereo rectification as the reference's example runs it through OpenCV ------------------------
+// cv::initUndistortRectifyMap, scalar path of OpenCV 3.x imgproc/src/undistort.cpp: iR = (Pnew * R)^-1 (closed-form 3x3
+// inverse of cv::invert), per row the homogeneous coordinate is ACCUMULATED column by column (_x += ir[0] ...), then the
+// Brown-Conrady model with k4..k6 = s1..s4 = tau = 0, result narrowed to float.
+void lvto_init_undistort_rectify_map(const double K[9], const double D[5], const double R[9], const double P[9], int w, int h, float *map1,
+                                     float *map2) {
+    double AR[9];
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += P[3 * i + k] * R[3 * k + j];
+            AR[3 * i + j] = s;
+        }
+    double ir[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
+    {
+        const double *S = AR;
+        double d = S[0] * (S[4] * S[8] - S[5] * S[7]) - S[1] * (S[3] * S[8] - S[5] * S[6]) + S[2] * (S[3] * S[7] - S[4] * S[6]);
+        if (d != 0.) {
+            d = 1. / d;
+            ir[0] = (S[4] * S[8] - S[5] * S[7]) * d;
+            ir[1] = (S[2] * S[7] - S[1] * S[8]) * d;
+            ir[2] = (S[1] * S[5] - S[2] * S[4]) * d;
+            ir[3] = (S[5] * S[6] - S[3] * S[8]) * d;
+            ir[4] = (S[0] * S[8] - S[2] * S[6]) * d;
+            ir[5] = (S[2] * S[3] - S[0] * S[5]) * d;
+            ir[6] = (S[3] * S[7] - S[4] * S[6]) * d;
+            ir[7] = (S[1] * S[6] - S[0] * S[7]) * d;
+            ir[8] = (S[0] * S[4] - S[1] * S[3]) * d;
+        }
+    }
+    const double u0 = K[2], v0 = K[5], fx = K[0], fy = K[4];
+    const double k1 = D[0], k2 = D[1], p1 = D[2], p2 = D[3], k3 = D[4];
+    for (int i = 0; i < h; i++) {
+        double _x = i * ir[1] + ir[2], _y = i * ir[4] + ir[5], _w = i * ir[7] + ir[8];
+        for (int j = 0; j < w; j++, _x += ir[0], _y += ir[3], _w += ir[6]) {
+            const double iw = 1. / _w, x = _x * iw, y = _y * iw;
+            const double x2 = x * x, y2 = y * y;
+            const double r2 = x2 + y2, _2xy = 2 * x * y;
+            const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((0 * r2 + 0) * r2 + 0) * r2);
+            const double xd = (x * kr + p1 * _2xy + p2 * (r2 + 2 * x2) + 0 * r2 + 0 * r2 * r2);
+            const double yd = (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy + 0 * r2 + 0 * r2 * r2);
+            const double u = fx * 1. * xd + u0;  // invProj = 1 (no tilt)
+            const double v = fy * 1. * yd + v0;
+            map1[(size_t)i * w + j] = (float)u;
+            map2[(size_t)i * w + j] = (float)v;
+        }
+    }
+}
+
+// cv::remap, 8UC1, INTER_LINEAR, BORDER_CONSTANT(0): coordinates rounded to 1/32 px (cvRound = round-half-even of x*32),
+// weights from initInterTab2D: (32-fx)(32-fy)*32 ... as shorts, except the all-integer entry, whose 32768 saturates to
+// 32767 and is repaired by +1 on the LAST weight (the table's sum fix-up scans from index ksize/2 = 1).
+void lvto_remap_bilinear(const uint8_t *src, int sw, int sh, int sstep, const float *map1, const float *map2, int dw, int dh, uint8_t *dst) {
+    for (int y = 0; y < dh; y++)
+        for (int x = 0; x < dw; x++) {
+            const int sxf = (int)lrintf(map1[(size_t)y * dw + x] * 32.f), syf = (int)lrintf(map2[(size_t)y * dw + x] * 32.f);
+            auto sat16 = [](int v) { return v < -32768 ? -32768 : (v > 32767 ? 32767 : v); };
+            const int sx = sat16(sxf >> 5), sy = sat16(syf >> 5), ax = sxf & 31, ay = syf & 31;
+            int w0 = (32 - ax) * (32 - ay) * 32, w1 = ax * (32 - ay) * 32, w2 = (32 - ax) * ay * 32, w3 = ax * ay * 32;
+            if (ax == 0 && ay == 0) w0 = 32767, w3 = 1;
+            int v0, v1, v2, v3;
+            if ((unsigned)sx < (unsigned)std::max(sw - 1, 0) && (unsigned)sy < (unsigned)std::max(sh - 1, 0)) {
+                const uint8_t *S = src + (size_t)sy * sstep + sx;
+                v0 = S[0], v1 = S[1], v2 = S[sstep], v3 = S[sstep + 1];
+            } else if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) {
+                dst[(size_t)y * dw + x] = 0;
+                continue;
+            } else {
+                const uint8_t *S0 = src + (size_t)sy * sstep, *S1 = src + (size_t)(sy + 1) * sstep;
+                v0 = (sx >= 0 && sy >= 0) ? S0[sx] : 0;
+                v1 = (sx + 1 < sw && sy >= 0) ? S0[sx + 1] : 0;
+                v2 = (sx >= 0 && sy + 1 < sh) ? S1[sx] : 0;
+                v3 = (sx + 1 < sw && sy + 1 < sh) ? S1[sx + 1] : 0;
+            }
+            const int acc = v0 * w0 + v1 * w1 + v2 * w2 + v3 * w3;
+            const int r = (acc + (1 << 14)) >> 15;
+            dst[(size_t)y * dw + x] = (uint8_t)(r < 0 ? 0 : (r > 255 ? 255 : r));
+        }
+}
+
 }  // extern "C"

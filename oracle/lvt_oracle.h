@@ -131,6 +131,13 @@ void lvto_motion_predict(double state[14], const double q[4], const double p[3],
                          double p_out[3]);
 /* std::sort by response desc exactly as handler.cpp:38-41 (libstdc++ introsort order) */
 void lvto_sort_by_response(float *xyr, int n);
+/* EuRoC pre-step (euroc_example.cpp:95-107,142-143 of the reference; upstream semantics restated, unverifiable offline):
+ * cv::initUndistortRectifyMap(K, D(k1 k2 p1 p2 k3), R, Pnew(3x3), size, CV_32FC1) -> map1 (x), map2 (y), w*h floats each */
+void lvto_init_undistort_rectify_map(const double K[9], const double D[5], const double R[9], const double P[9], int w,
+                                     int h, float *map1, float *map2);
+/* cv::remap(src 8UC1, dst, map1, map2, INTER_LINEAR, BORDER_CONSTANT 0): 5-bit fixed-point coordinates, 15-bit weights */
+void lvto_remap_bilinear(const uint8_t *src, int src_w, int src_h, int src_step, const float *map1, const float *map2,
+                         int dst_w, int dst_h, uint8_t *dst);
 
 #ifdef __cplusplus
 }

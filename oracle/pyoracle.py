@@ -53,6 +53,8 @@ def lib():
         L.lvto_agast_detect.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, vp, C.c_int]
         L.lvto_anms.argtypes = [vp, C.c_int, C.c_int, C.c_float, C.c_float]
         L.lvto_sort_by_response.argtypes = [vp, C.c_int]
+        L.lvto_init_undistort_rectify_map.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int, vp, vp]
+        L.lvto_remap_bilinear.argtypes = [vp, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int, C.c_int, vp]
         L.lvto_detect_grid.argtypes = [vp, C.c_int, C.c_int, vp, vp, C.c_int, vp]
         L.lvto_brief.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp]
         L.lvto_compute_features.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp]
@@ -185,6 +187,22 @@ def sort_by_response(xyr):
     a = np.ascontiguousarray(xyr, dtype=np.float32).copy()
     lib().lvto_sort_by_response(_p(a), len(a))
     return a
+
+
+def init_undistort_rectify_map(K, D, R, P, w, h):
+    """cv::initUndistortRectifyMap(K, D[5], R, P[:3,:3], (w, h), CV_32FC1) -> (map1, map2)"""
+    K, D, R, P = (np.ascontiguousarray(a, dtype=np.float64).reshape(-1) for a in (K, D, R, P))
+    m1 = np.zeros((h, w), np.float32); m2 = np.zeros((h, w), np.float32)
+    lib().lvto_init_undistort_rectify_map(_p(K), _p(D), _p(R), _p(P), w, h, _p(m1), _p(m2))
+    return m1, m2
+
+
+def remap_bilinear(img, map1, map2):
+    """cv::remap(img 8UC1, map1, map2, INTER_LINEAR, BORDER_CONSTANT 0)"""
+    a = _u8(img); m1 = np.ascontiguousarray(map1, np.float32); m2 = np.ascontiguousarray(map2, np.float32)
+    out = np.zeros(m1.shape, np.uint8)
+    lib().lvto_remap_bilinear(_p(a), a.shape[1], a.shape[0], a.shape[1], _p(m1), _p(m2), m1.shape[1], m1.shape[0], _p(out))
+    return out
 
 
 def detect_grid(img, params, cap=65536):

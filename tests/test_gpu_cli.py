@@ -138,3 +138,70 @@ def test_tum_cli_matches_the_binding(tmp_path):
         assert ref.get_state() == 2
         q, p = ref.pose()
         assert np.allclose(traj[i, 1:4], p, atol=2e-7) and np.allclose(traj[i, 4:8], [q[1], q[2], q[3], q[0]], atol=2e-7), f"frame {i}"
+
+
+@pytest.mark.gpu
+def test_euroc_cli_matches_the_binding(tmp_path):
+    """lvt_euroc = PNG read + GPU rectification (both cameras) + track + body-frame TUM trajectory, against the same steps
+    done through the Python binding (Rectifier.rectify, LvtSystem.track) and numpy for T_BS / the quaternion"""
+    import lvt_amd
+    from lvt_amd.synth import make_world
+    from test_oracle_primitives import EUROC_L
+    exe = os.path.join(ROOT, "examples", "lvt_euroc")
+    if not os.path.exists(exe):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "examples"), "-s"])
+    world = make_world("euroc", seed=1)
+    assert (world.W, world.H) == (752, 480)
+    ds = tmp_path / "root" / "MH_synth" / "mav0"
+    (ds / "cam0" / "data").mkdir(parents=True)
+    (ds / "cam1" / "data").mkdir(parents=True)
+    (tmp_path / "stamps").mkdir()
+    n = 4
+    frames = []
+    with open(tmp_path / "stamps" / "MH_synth.txt", "w") as f:
+        for i in range(n):
+            L, R = world.render_stereo(i)
+            stamp = 1403636579763555584 + 50000000 * i
+            _png(str(ds / "cam0" / "data" / f"{stamp}.png"), L, filt=i % 4)
+            _png(str(ds / "cam1" / "data" / f"{stamp}.png"), R, filt=(i + 2) % 4)
+            f.write(f"{stamp}\n")
+            frames.append((stamp, L, R))
+    prm = lvt_amd.euroc_params()
+    prm.write_yaml(str(tmp_path / "config.yaml"))
+    out = subprocess.run([exe, str(tmp_path / "root"), str(tmp_path / "stamps"), "MH_synth", str(tmp_path / "config.yaml")], cwd=tmp_path, capture_output=True,
+                         text=True, timeout=300)
+    assert out.returncode == 0, out.stdout + out.stderr
+    traj = np.loadtxt(tmp_path / "MH_synth.txt").reshape(-1, 8)
+    assert traj.shape[0] == n
+
+    cam1 = dict(K=[457.587, 0.0, 379.999, 0.0, 456.134, 255.238, 0.0, 0.0, 1.0], D=[-0.28368365, 0.07451284, -0.00010473, -3.555907e-05, 0.0],
+                R=[0.9999633526194376, -0.003625811871560086, 0.007755443660172947, 0.003680398547259526, 0.9999684752771629, -0.007035845251224894,
+                   -0.007729688520722713, 0.007064130529506649, 0.999945173484644], P=EUROC_L["P"])
+    rl = lvt_amd.Rectifier(EUROC_L["K"], EUROC_L["D"], EUROC_L["R"], EUROC_L["P"], 752, 480)
+    rr = lvt_amd.Rectifier(cam1["K"], cam1["D"], cam1["R"], cam1["P"], 752, 480)
+    import ctypes as C
+    Lib = lvt_amd.load_library()
+    pod = lvt_amd.ParamsPOD()
+    assert Lib.lvt_amd_params_from_file(str(tmp_path / "config.yaml").encode(), C.byref(pod)) == 1
+    pod.fx = pod.fy = 435.2046959714599
+    pod.cx, pod.cy, pod.baseline = 367.4517211914062, 252.2008514404297, 0.110077842
+    pod.img_width, pod.img_height = 752, 480
+    ref = lvt_amd.LvtSystem(Lib.lvt_amd_create(C.byref(pod), 1), 1)
+    Tbs = np.array([[0.0148655429818, -0.999880929698, 0.00414029679422, -0.0216401454975], [0.999557249008, 0.0149672133247, 0.025715529948, -0.064676986768],
+                    [-0.0257744366974, 0.00375618835797, 0.999660727178, 0.00981073058949], [0, 0, 0, 1.0]])
+    lost = False
+    for i, (stamp, Lm, Rm) in enumerate(frames):
+        if lost:
+            assert np.allclose(traj[i, 1:], [0, 0, 0, 0, 0, 0, 1])   # default pose after a LOST, as in the reference
+            continue
+        Rc, tc = ref.track(rl.rectify(Lm), rr.rectify(Rm))
+        T = np.eye(4); T[:3, :3] = Rc; T[:3, 3] = tc
+        Bm = Tbs @ T
+        m = Bm[:3, :3]
+        tr = np.trace(m)
+        assert tr > 0
+        w = 0.5 * np.sqrt(tr + 1.0); s4 = 0.5 / np.sqrt(tr + 1.0)
+        q = [(m[2, 1] - m[1, 2]) * s4, (m[0, 2] - m[2, 0]) * s4, (m[1, 0] - m[0, 1]) * s4, w]
+        assert abs(traj[i, 0] - stamp / 1e9) < 1e-5
+        assert np.allclose(traj[i, 1:4], Bm[:3, 3], atol=2e-7) and np.allclose(traj[i, 4:8], q, atol=2e-7), f"frame {i}"
+        lost = ref.get_state() == 3

@@ -185,3 +185,28 @@ def test_pnp_standalone(hip_lib, oracle_lib):
         assert inl == int(marks.sum()) and calls == 10 or calls > 0
         assert np.allclose(ph, po, rtol=0, atol=1e-7) and np.allclose(qh, qo, atol=1e-9), (trial, ph, po)
         assert np.linalg.norm(ph - p_true) < 0.05
+
+
+def test_rectify_matches_the_oracle(hip_lib):
+    """k_rectify_map / k_rectify vs the oracle's restatement of cv::initUndistortRectifyMap + cv::remap with the EuRoC cam0 /
+    cam1 calibration of the reference's example: maps bit-identical (same fp64 recurrence), rectified images identical"""
+    from oracle import pyoracle as O
+    from test_oracle_primitives import EUROC_L
+    cams = [EUROC_L, dict(K=[457.587, 0.0, 379.999, 0.0, 456.134, 255.238, 0.0, 0.0, 1.0],
+                          D=[-0.28368365, 0.07451284, -0.00010473, -3.555907e-05, 0.0],
+                          R=[0.9999633526194376, -0.003625811871560086, 0.007755443660172947, 0.003680398547259526, 0.9999684752771629,
+                             -0.007035845251224894, -0.007729688520722713, 0.007064130529506649, 0.999945173484644],
+                          P=EUROC_L["P"])]
+    rng = np.random.default_rng(4)
+    for c in cams:
+        r = hip_lib.Rectifier(c["K"], c["D"], c["R"], c["P"], 752, 480)
+        m1, m2 = r.maps()
+        o1, o2 = O.init_undistort_rectify_map(c["K"], c["D"], c["R"], c["P"], 752, 480)
+        assert np.array_equal(m1, o1) and np.array_equal(m2, o2)
+        for kind in ("noise", "smooth"):
+            img = rng.integers(0, 256, (480, 752), dtype=np.uint8)
+            if kind == "smooth":
+                yy, xx = np.mgrid[0:480, 0:752]
+                img = ((np.sin(xx / 17.0) + np.cos(yy / 11.0)) * 60 + 128).astype(np.uint8)
+            assert np.array_equal(r.rectify(img), O.remap_bilinear(img, o1, o2)), kind
+        r.close()

@@ -292,3 +292,53 @@ def test_vectorised_matcher_reference_equals_the_oracle():
         a = gp._hamming_ref(O, qd, qxy, td, txy, tf, r2, mode, rows, cols)
         b = gp._hamming_ref_np(qd, qxy, td, txy, tf, r2, mode, rows)
         assert np.array_equal(a, b), (mode, r2)
+
+
+EUROC_L = dict(K=[458.654, 0.0, 367.215, 0.0, 457.296, 248.375, 0.0, 0.0, 1.0],
+               D=[-0.28340811, 0.07395907, 0.00019359, 1.76187114e-05, 0.0],
+               R=[0.999966347530033, -0.001422739138722922, 0.008079580483432283, 0.001365741834644127, 0.9999741760894847,
+                  0.007055629199258132, -0.008089410156878961, -0.007044357138835809, 0.9999424675829176],
+               P=[435.2046959714599, 0, 367.4517211914062, 0, 435.2046959714599, 252.2008514404297, 0, 0, 1])
+
+
+def test_rectify_map_known_answers():
+    """initUndistortRectifyMap restatement: identity camera -> identity map; no distortion + same K -> identity; EuRoC cam0
+    against an independent float64 numpy evaluation of the closed form (no accumulation along the row)."""
+    from oracle import pyoracle as O
+    I3 = np.eye(3).reshape(-1)
+    K = [400.0, 0, 160.0, 0, 400.0, 120.0, 0, 0, 1]
+    m1, m2 = O.init_undistort_rectify_map(K, [0, 0, 0, 0, 0], I3, K, 320, 240)
+    xs, ys = np.meshgrid(np.arange(320, dtype=np.float32), np.arange(240, dtype=np.float32))
+    assert np.abs(m1 - xs).max() < 1e-3 and np.abs(m2 - ys).max() < 1e-3
+    c = EUROC_L
+    m1, m2 = O.init_undistort_rectify_map(c["K"], c["D"], c["R"], c["P"], 752, 480)
+    Kd, D = np.array(c["K"]).reshape(3, 3), np.array(c["D"])
+    iR = np.linalg.inv(np.array(c["P"]).reshape(3, 3) @ np.array(c["R"]).reshape(3, 3))
+    u, v = np.meshgrid(np.arange(752.0), np.arange(480.0))
+    X = iR @ np.stack([u.ravel(), v.ravel(), np.ones(u.size)])
+    x, y = X[0] / X[2], X[1] / X[2]
+    r2 = x * x + y * y
+    kr = 1 + ((D[4] * r2 + D[1]) * r2 + D[0]) * r2
+    xd = x * kr + D[2] * 2 * x * y + D[3] * (r2 + 2 * x * x)
+    yd = y * kr + D[2] * (r2 + 2 * y * y) + D[3] * 2 * x * y
+    assert np.abs(m1.ravel() - (Kd[0, 0] * xd + Kd[0, 2])).max() < 2e-3   # float narrowing + row accumulation
+    assert np.abs(m2.ravel() - (Kd[1, 1] * yd + Kd[1, 2])).max() < 2e-3
+
+
+def test_remap_known_answers():
+    """remap restatement: identity map copies; integer shift shifts with zero border; half-pixel map = rounded mean of two
+    neighbours; far-outside coordinates give the border constant"""
+    from oracle import pyoracle as O
+    rng = np.random.default_rng(0)
+    img = rng.integers(0, 256, (40, 60), dtype=np.uint8)
+    xs, ys = np.meshgrid(np.arange(60, dtype=np.float32), np.arange(40, dtype=np.float32))
+    assert np.array_equal(O.remap_bilinear(img, xs, ys), img)
+    sh = O.remap_bilinear(img, xs + 3, ys - 2)
+    ref = np.zeros_like(img)
+    ref[2:, :57] = img[:38, 3:]
+    assert np.array_equal(sh, ref)
+    half = O.remap_bilinear(img, xs + 0.5, ys)
+    a, b = img[:, :-1].astype(np.int64), img[:, 1:].astype(np.int64)
+    assert np.array_equal(half[:, :-1], ((a * 16384 + b * 16384 + 16384) >> 15).astype(np.uint8))
+    assert np.array_equal(half[:, -1], ((img[:, -1].astype(np.int64) * 16384 + 16384) >> 15).astype(np.uint8))  # right tap = border 0
+    assert not O.remap_bilinear(img, xs + 1000, ys).any()

@@ -1041,7 +1041,7 @@ __global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass, int par) {
             const size_t cap = (size_t)g.cw * g.ch;
             uint32_t *gk = S.cell_scratch[eye] + S.cell_scratch_off[cell];
             uint32_t *guf = gk + cap, *groot = guf + cap, *gabv = groot + cap, *gnms = gabv + cap;
-            n_raw = cell_compact(g, gk, (int)cap, scan);
+            n_raw = segs ? cell_gather_segments(FB, eye, g, cs, cxi, (S.prm.W + TS_W - 1) / TS_W, gk, (int)cap, scan) : cell_compact(g, gk, (int)cap, scan);
             n_out = cell_nms_anms<uint32_t>(S, g, gk, guf, groot, gabv, gnms, reinterpret_cast<uint8_t *>(gnms + cap), n_raw, (int)cap, row_first, row_end, scan, stack, misc, out, dbg);
         }
     }

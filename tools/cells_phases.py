@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""clock64 phase stamps of the single-workgroup kernels (Ctl::dbg, bring-up profiling): k_cells of cell 0 / left eye,
+"""usage: python tools/cells_phases.py [kitti|euroc|tum]
+clock64 phase stamps of the single-workgroup kernels (Ctl::dbg, bring-up profiling): k_cells of cell 0 / left eye,
 k_pnp and the map resolver inside k_track_mid.  Run on the GPU box:  python tools/cells_phases.py"""
 import os
 import sys
@@ -8,14 +9,16 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import lvt_amd
 from lvt_amd.synth import make_world
 
-w = make_world("kitti", seed=0)
-prm = lvt_amd.kitti_params()
-vo = lvt_amd.LvtSystem.create(prm, 1)
+kind = sys.argv[1] if len(sys.argv) > 1 else "kitti"
+w = make_world(kind, seed=0)
+prm = {"kitti": lvt_amd.kitti_params, "euroc": lvt_amd.euroc_params, "tum": lvt_amd.tum_params}[kind]()
+sensor = 2 if kind == "tum" else 1
+vo = lvt_amd.LvtSystem.create(prm, sensor)
 # stamp k .. k+1 of k_cells (k_features.hip STAMP(k)); dbg[1] is taken right after the corner gather
 phases = ["gather segments", "(links start)", "links + union-find + component maxima", "replay of tied components", "survivors",
           "std::sort emulation", "rank", "radii", "decision radius", "emit", "done"]
 for i in range(4):
-    L, R = w.render_stereo(i)
+    L, R = w.render_rgbd(i) if sensor == 2 else w.render_stereo(i)
     vo.track(L, R)
     d = vo.debug_stamps()
     print("frame", i, "k_cells cell 0 cycles:", {phases[k]: int(d[k + 1] - d[k]) for k in range(11)}, "total", int(d[11] - d[0]))

@@ -186,7 +186,8 @@ struct CandLds {
 // PROJECT (map mode, pass 1): the wavefront first projects its map point with the predicted pose (is_point_visible,
 // lvt_local_map.cpp:62-82,152-156) and records the projection for the rest of the chain.
 template <int MODE, bool PROJECT = false>
-__device__ __forceinline__ void candidates_body(Seq &S, int pass2, int par, CandLds &C, int wave0, int wave_stride, int nthreads) {
+__device__ __forceinline__ void candidates_body(Seq &S, int pass2, int par, CandLds &C, int wave0, int wave_stride, int nthreads, int q_begin = 0,
+                                                int q_end = -1) {
     uint32_t *s_tc = C.tc;
     float *s_tx = C.tx, *s_ty = C.ty;
     const int lane = lane_id(), wv = wave_id();
@@ -213,6 +214,8 @@ __device__ __forceinline__ void candidates_body(Seq &S, int pass2, int par, Cand
         cand = S.rcand + (size_t)par * NF_MAX * KC;
         ncand = S.rncand + par * NF_MAX;
     }
+    if (q_end >= 0) M = min(M, q_end);  // only queries [q_begin, q_end): the split of find_matches across two launches
+    wave0 += q_begin;
     if (wave0 - wv >= M) return;  // no query for this block (block-uniform: wave0 - wv is the block's first query)
     // the first query's descriptor (and map point) are requested before the train data is staged: one memory round trip less
     uint64_t qd0[4] = {0, 0, 0, 0};
@@ -343,7 +346,7 @@ __global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2, int pa
 // k_match_map : frame prologue + projection of the map points + their candidate lists (find_matches pass 1).  Every block
 // derives the per-frame facts it needs (active / first frame / predicted pose) from the PERSISTENT part of Ctl, which
 // nobody writes during this kernel; block 0 additionally publishes them for the rest of the chain.
-__global__ __launch_bounds__(256) void k_match_map(Seq *seqs, int par) {
+__global__ __launch_bounds__(256) void k_match_map(Seq *seqs, int par, unsigned seq) {
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     const int state = ctl.state;  // persistent; not written by this kernel
@@ -368,7 +371,52 @@ __global__ __launch_bounds__(256) void k_match_map(Seq *seqs, int par) {
     __shared__ uint32_t s_tc[NF_MAX];
     CandLds C;
     C.lbuf = lbuf, C.tx = s_tx, C.ty = s_ty, C.tc = s_tc, C.w2c = w2c;
-    candidates_body<MODE_MAP, true>(S, 0, par, C, blockIdx.x * 4 + wave_id(), gridDim.x * 4, 256);
+    // the points [0, early_done) were projected and listed by k_early_map while the previous frame finished
+    candidates_body<MODE_MAP, true>(S, 0, par, C, blockIdx.x * 4 + wave_id(), gridDim.x * 4, 256, (ctl.early_ran_seq == seq) ? max(ctl.early_done, 0) : 0, -1);
+}
+
+// k_early_map : projection + candidate lists of the map points that survived the PREVIOUS frame's clean-up, launched on its own
+// stream as soon as that frame's pose is known (after its k_pnp) -- k_staged / k_triangulate of that frame only append points
+// behind early_done.  Nothing of the per-frame state is published here (k_match_map does that when the previous frame is
+// complete); the prediction is recomputed from the same persistent inputs, so both kernels see the same pose.
+// k_gate : one wavefront per sequence at the head of the early stream; returns when the previous frame's k_pnp has published
+// its sequence number (or after 20 ms of wall clock: then the early kernels stand down and the late ones do all the work)
+__global__ __launch_bounds__(64) void k_gate(Seq *seqs, unsigned want, unsigned seq) {
+    Ctl &ctl = *seqs[blockIdx.z].ctl;
+    if (threadIdx.x != 0) return;
+    bool ok = true;
+    if (want != 0) {
+        const unsigned long long t0 = wall_clock64();  // 100 MHz
+        while (__hip_atomic_load(&ctl.pnp_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(64);
+            if (wall_clock64() - t0 > 2000000ull) {
+                ok = false;
+                break;
+            }
+        }
+    }
+    if (!ok) atomicAdd(&ctl.gate_timeouts, 1);
+    ctl.gate_ok = ok ? seq : 0u;
+}
+
+__global__ __launch_bounds__(256) void k_early_map(Seq *seqs, int par, unsigned seq) {
+    Seq &S = seqs[blockIdx.z];
+    Ctl &ctl = *S.ctl;
+    const int n_early = (ctl.gate_ok == seq) ? ctl.early_done : 0;
+    if (n_early <= 0) return;  // first frame, LOST, the previous frame did not reach its pose refinement, or the gate timed out
+    __shared__ double w2c[12];
+    if (threadIdx.x == 0) {
+        Pose predicted;
+        double mmn[14];
+        motion_predict(ctl, ctl.last_pose, predicted, mmn);
+        world_to_camera(predicted, w2c);
+    }
+    __shared__ uint32_t lbuf[4 * KC];
+    __shared__ float s_tx[NF_MAX], s_ty[NF_MAX];
+    __shared__ uint32_t s_tc[NF_MAX];
+    CandLds C;
+    C.lbuf = lbuf, C.tx = s_tx, C.ty = s_ty, C.tc = s_tc, C.w2c = w2c;
+    candidates_body<MODE_MAP, true>(S, 0, par, C, blockIdx.x * 4 + wave_id(), gridDim.x * 4, 256, 0, n_early);
 }
 
 // =================================================================================================
@@ -630,7 +678,9 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
     L.flag = r_flag, L.tab0 = r_tab, L.tab1 = r_tab + NF_MAX, L.lists = r_lists, L.scan = r_scan, L.misc = r_misc;
 
 template <int MODE>
-__device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int par, ResolveLds &L, uint32_t *r_tab) {
+// phase 0: all queries; phase 1 (map mode, "early"): queries [0, q_split) only, no per-frame bookkeeping; phase 2 ("late"): queries
+// [q_split, M), continuing from the marks and the match count phase 1 left behind
+__device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int par, ResolveLds &L, uint32_t *r_tab, int phase = 0, int q_split = 0) {
     const int tid = threadIdx.x;
     const long long tk0 = clock64();
     const Feat &T = (MODE == MODE_ROW) ? S.fb[par].feat[1] : S.fb[par].feat[0];
@@ -639,8 +689,9 @@ __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int pa
     // clears them again, lvt_local_map.cpp:176) and row_match on those of the right image, which nothing else marks --
     // so the tables are initialised without reading the global flags (one memory round trip less at kernel start).
     for (int j = tid; j < NF_MAX; j += RES_THREADS) {
-        L.flag[j] = 0;
-        r_tab[j] = r_tab[NF_MAX + j] = 0u;
+        const uint8_t f = (phase == 2 && j < N) ? T.flag[j] : 0;  // late part: the marks the early part wrote back
+        L.flag[j] = f;
+        r_tab[j] = r_tab[NF_MAX + j] = f ? PERM : 0u;
     }
     int M;
     const uint64_t *qdesc;
@@ -661,10 +712,11 @@ __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int pa
     const float desc_th = S.prm.desc_th;
     const int radius = S.prm.tracking_radius * ((MODE == MODE_MAP && pass2) ? 2 : 1);
     uint32_t iter = 0;
-    int accepted = 0;  // block-uniform
+    int accepted = (phase == 2) ? ctl.early_accepted : 0;  // block-uniform
+    if (phase == 1) M = min(M, q_split);
     __syncthreads();
     const long long tk1 = clock64();
-    for (int b0 = 0; b0 < M;) {
+    for (int b0 = (phase == 2) ? q_split : 0; b0 < M;) {
         int acc[2];
         const uint8_t *lflag = S.fb[par].feat[0].flag;
         const int used = resolve_super(b0, M, [&](int q) { return (MODE == MODE_ROW && lflag[q]) ? 0 : ncand[q]; }, cand, L, iter, ratio, desc_th, acc);
@@ -726,7 +778,8 @@ __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int pa
     if (MODE == MODE_MAP) {
         // a failed pass 1 (< 50) is discarded: pass 2 rebuilds the marks from scratch
         for (int j = tid; j < N; j += RES_THREADS) S.fb[par].feat[0].flag[j] = L.flag[j];
-        if (tid == 0) {
+        if (tid == 0 && phase == 1) ctl.early_accepted = accepted;
+        if (tid == 0 && phase != 1) {
             if (!pass2) {
                 ctl.dbg[18] = L.misc[4];
                 ctl.dbg[19] = L.misc[5];
@@ -919,7 +972,7 @@ __device__ __forceinline__ bool bookkeep_cull_small(Seq &S, Ctl &ctl, int par, i
 // =================================================================================================
 // k_track_mid : find_matches pass 1 [+ second pass, if pass 1 found < 50] + bookkeeping + LOST decision + cull
 // =================================================================================================
-__global__ __launch_bounds__(RES_THREADS) void k_track_mid(Seq *seqs, int par) {
+__global__ __launch_bounds__(RES_THREADS) void k_track_mid(Seq *seqs, int par, unsigned seq) {
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     if (!ctl.active) return;
@@ -930,7 +983,12 @@ __global__ __launch_bounds__(RES_THREADS) void k_track_mid(Seq *seqs, int par) {
     }
     if (ctl.first_frame) return;
     RESOLVE_LDS_DECL
-    resolve_body<MODE_MAP>(S, ctl, 0, par, L, r_tab);  // find_matches pass 1 (lists from k_candidates)
+    {   // find_matches pass 1: the points [0, early_done) were resolved by k_early_mid; the greedy scan continues behind them
+        const int n_early = (ctl.early_ran_seq == seq) ? max(ctl.early_done, 0) : 0;
+        resolve_body<MODE_MAP>(S, ctl, 0, par, L, r_tab, n_early > 0 ? 2 : 0, n_early);
+        __syncthreads();
+        if (threadIdx.x == 0) ctl.early_done = 0;  // consumed; this frame's k_pnp publishes the next one
+    }
     __syncthreads();
     if (L.misc[2]) {  // rare (< 50 matches): doubled-radius candidate lists are built by this one block
         {
@@ -953,6 +1011,40 @@ __global__ __launch_bounds__(RES_THREADS) void k_track_mid(Seq *seqs, int par) {
     __syncthreads();
     if (ctl.lost_now) return;
     cull_body(S, ctl, par, L.scan);
+}
+
+// k_early_mid : the greedy resolution of find_matches for the map points [0, early_done) (storage order: their decisions do
+// not depend on the points the previous frame is still appending), on the early stream behind k_early_map
+__global__ __launch_bounds__(RES_THREADS) void k_early_mid(Seq *seqs, int par, unsigned seq) {
+    Seq &S = seqs[blockIdx.z];
+    Ctl &ctl = *S.ctl;
+    const int n_early = (ctl.gate_ok == seq) ? ctl.early_done : 0;
+    if (n_early > 0) {
+        RESOLVE_LDS_DECL
+        resolve_body<MODE_MAP>(S, ctl, 0, par, L, r_tab, 1, n_early);
+        __syncthreads();
+        if (threadIdx.x == 0) ctl.early_ran_seq = seq;  // the late kernels trust early_done only with this confirmation
+    }
+    if (threadIdx.x == 0) {  // the tracking stream's gate polls this: the early stream is done with this frame, whatever it did
+        __threadfence();
+        atomicExch(&ctl.early_fin_seq, seq);
+    }
+}
+
+// the tracking stream's counterpart of k_gate: returns when the early stream has finished this frame.  A barrier packet waiting
+// on an event would do the same, but a queue parked on a barrier stalls the other queues of its hardware pipe (measured: the
+// feature stream only advanced when the tracking stream's barrier resolved), and the event itself costs ~12 us of latency.
+__global__ __launch_bounds__(64) void k_gate_late(Seq *seqs, unsigned seq) {
+    Ctl &ctl = *seqs[blockIdx.z].ctl;
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(&ctl.early_fin_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+        __builtin_amdgcn_s_sleep(64);
+        if (wall_clock64() - t0 > 6000000ull) {  // 60 ms: the early stream's own gate gives up after 20
+            atomicAdd(&ctl.gate_timeouts, 1 << 16);
+            break;
+        }
+    }
 }
 
 // =================================================================================================
@@ -1401,10 +1493,16 @@ __device__ __forceinline__ void pnp_solve(const Params &prm, const Pose &prior, 
         pnp_run(prm, prior, X, obs, err, level, n, sh, red, res, inliers, calls, dbg);
 }
 
-__global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs, int par) {
+__global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs, int par, unsigned seq) {
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
-    if (!ctl.active || ctl.first_frame || ctl.lost_now) return;
+    if (!ctl.active || ctl.first_frame || ctl.lost_now) {
+        if (threadIdx.x == 0) {  // nothing for the next frame to start on (early_done is 0), but its gate must not wait
+            __threadfence();
+            atomicExch(&ctl.pnp_seq, seq);
+        }
+        return;
+    }
     __shared__ PnpShared sh;
     __shared__ double red[384 + 28 * (PNP_THREADS + 8)];
     extern __shared__ __attribute__((aligned(16))) uint8_t pnp_dyn[];
@@ -1419,6 +1517,10 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs, int par) {
         ctl.out_status = 2;
         ctl.counts[C_PNP_ITERS] = calls;
         ctl.counts[C_PNP_INLIERS] = inliers;
+        ctl.early_done = *S.map_n;  // the map after clean_untracked_points: the next frame may start on these points now
+        ctl.early_accepted = 0;
+        __threadfence();
+        atomicExch(&ctl.pnp_seq, seq);  // release: everything the next frame's early kernels read is final
     }
     // update_staged_map_points projects the staged points with the optimised pose (lvt_local_map.cpp:357-368)
     if (S.prm.staged_th > 0) project_staged(S, res, red);

@@ -68,6 +68,16 @@ struct Ctl {
     double mm_last_q[4], mm_ang_vel[4], mm_last_p[3], mm_lin_vel[3];
     double mm_next[14];  // motion-model state after this frame's prediction; committed by k_track_mid (k_project only reads mm_*)
     int mm_pending;
+    // cross-frame overlap: k_pnp of frame t publishes the size of the map after clean_untracked_points; the projection,
+    // candidate lists and greedy resolution of THOSE points for frame t+1 run on a third stream while frame t still
+    // updates its staged points and triangulates (they only append behind early_done)
+    int early_done;      // map points [0, early_done) of the NEXT frame are handled by k_early_map / k_early_mid (0: none)
+    int early_accepted;  // matches accepted among them
+    // hand-over of that work between the streams without a cross-stream event (measured: ~12 us of latency per event against ~3 us
+    // for an in-stream boundary): k_pnp publishes its frame's sequence number, a one-wave gate kernel at the head of the early
+    // stream polls it (with a wall-clock time-out), k_early_mid confirms that the early part really ran
+    unsigned pnp_seq, gate_ok, early_ran_seq, early_fin_seq;
+    int gate_timeouts;
     // per-frame control, written by k_begin / later kernels
     int active;         // 0: LOST at frame start -> every kernel exits
     int first_frame;    // state was NOT_INITIALIZED at frame start
@@ -86,6 +96,10 @@ struct Ctl {
     double out_R[9], out_t[3];
     int out_status;
 };
+
+// frames whose feature stage may be in flight / waiting for their tracking chain: three buffers let the feature stream run a
+// full frame ahead of the tracking stream (with two, the features of frame t+1 only finish when frame t does)
+constexpr int NPAR = 3;
 
 struct FeatCtl {        // per-frame state of the FEATURE stage (own stream, double buffered)
     int ext_corners;    // track_with_external_corners frame
@@ -131,7 +145,7 @@ struct FrameBuf {
 struct Seq {
     Params prm;
     Ctl *ctl;
-    FrameBuf fb[2];
+    FrameBuf fb[NPAR];
     int plane_pitch;            // elements, multiple of 64
     uint32_t *cell_scratch[2];  // global-memory arrays for cells whose raw corners exceed RAW_CAP (6 words / pixel)
     size_t cell_scratch_off[CELLS_MAX];
@@ -149,7 +163,7 @@ struct Seq {
     // pnp input
     double *pnp_X; float *pnp_obs; int *pnp_feat; double *pnp_err; int8_t *pnp_level;
     // row matching / triangulation
-    uint32_t *rcand; int *rncand;   // [2 parities][NF_MAX][KC]: built on the feature stream
+    uint32_t *rcand; int *rncand;   // [NPAR buffers][NF_MAX][KC]: built on the feature stream
     int *pair_l, *pair_r;           // [NF_MAX]
     double *tri_X; int8_t *tri_ok;  // [NF_MAX][3]
 };

@@ -58,11 +58,13 @@ __global__ __launch_bounds__(256) void k_repitch(const uint8_t *src, uint8_t *ds
 struct Context {
     double host_enq_us = 0, host_wait_us = 0;  // host time spent enqueueing / blocking (LVT_AMD_HOST_TIMING=1 prints it at destroy)
     long host_enq_n = 0, host_wait_n = 0;
+    int gate_timeouts_seen = 0;
     int B = 1;                 // sequences advanced in lock-step by one launch chain
     int sensor = 1;
     Params prm{};
     hipStream_t stream = nullptr;    // tracking chain
     hipStream_t stream_f = nullptr;  // feature stage
+    hipStream_t stream_e = nullptr;  // early part of find_matches of the next frame (behind the previous frame's k_pnp)
     bool own_stream = false;
     std::vector<void *> allocs;
     Seq *d_seqs = nullptr;
@@ -70,11 +72,11 @@ struct Context {
     std::vector<Ctl *> d_ctl;
     Ctl *h_ctl = nullptr;          // pinned, RING x B records
     FrameArgs *h_fargs = nullptr;  // pinned, RING x B
-    hipEvent_t ev_feat[2] = {}, ev_track[2] = {}, ev_done[RING] = {};
+    hipEvent_t ev_feat[NPAR] = {}, ev_track[NPAR] = {}, ev_pnp[NPAR] = {}, ev_early[NPAR] = {}, ev_done[RING] = {};
     // owned staging for the host-buffer entry points, per frame parity
-    uint8_t *d_packed[2][2] = {}, *d_img[2][2] = {};
-    float *d_depth[2] = {};
-    float *d_ext[2][2] = {};
+    uint8_t *d_packed[NPAR][2] = {}, *d_img[NPAR][2] = {};
+    float *d_depth[NPAR] = {};
+    float *d_ext[NPAR][2] = {};
     int pitch = 0;
     long enq = 0, done = 0;    // frames enqueued / collected
     int last_slot = 0, last_par = 0;
@@ -103,17 +105,21 @@ struct Context {
     ~Context() {
         if (stream) (void)hipStreamSynchronize(stream);
         if (stream_f) (void)hipStreamSynchronize(stream_f);
+        if (stream_e) (void)hipStreamSynchronize(stream_e);
         for (void *p : allocs) (void)hipFree(p);
         for (auto &e : ev)
             for (auto &x : e)
                 if (x) (void)hipEventDestroy(x);
         for (auto &x : ev_feat) if (x) (void)hipEventDestroy(x);
         for (auto &x : ev_track) if (x) (void)hipEventDestroy(x);
+        for (auto &x : ev_pnp) if (x) (void)hipEventDestroy(x);
+        for (auto &x : ev_early) if (x) (void)hipEventDestroy(x);
         for (auto &x : ev_done) if (x) (void)hipEventDestroy(x);
         if (h_ctl) (void)hipHostFree(h_ctl);
         if (h_fargs) (void)hipHostFree(h_fargs);
         if (stream && own_stream) (void)hipStreamDestroy(stream);
         if (stream_f) (void)hipStreamDestroy(stream_f);
+        if (stream_e) (void)hipStreamDestroy(stream_e);
     }
 };
 
@@ -253,6 +259,7 @@ static void drain(Context *c);
 
 static void reset_state(Context *c) {  // lvt_system::reset (lvt_system.cpp:44-68)
     drain(c);
+    c->gate_timeouts_seen = 0;
     for (int s = 0; s < c->B; s++) {
         Ctl z;
         std::memset(&z, 0, sizeof(z));
@@ -264,6 +271,8 @@ static void reset_state(Context *c) {  // lvt_system::reset (lvt_system.cpp:44-6
         z.optimized.q[0] = z.predicted.q[0] = 1.0;
         z.out_R[0] = z.out_R[4] = z.out_R[8] = 1.0;
         z.out_status = 1;
+        z.pnp_seq = (unsigned)c->enq;  // the next frame's gate waits for this value: nothing is pending
+        z.early_fin_seq = (unsigned)c->enq;
         HIPCHK(c, hipMemcpyAsync(c->d_ctl[s], &z, sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->h_seqs[s].map_n, 0, sizeof(int), c->stream));
         HIPCHK(c, hipMemsetAsync(c->h_seqs[s].map_cur, 0, sizeof(int), c->stream));
@@ -287,9 +296,12 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
         c->prm = prm;
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream_f, hipStreamNonBlocking));
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream_e, hipStreamNonBlocking));
         c->own_stream = true;
         for (auto &e : c->ev_feat) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto &e : c->ev_track) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : c->ev_pnp) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : c->ev_early) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto &e : c->ev_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->pitch = ((prm.W + 63) / 64) * 64;
         HIPCHK(c, hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl) * B * RING, hipHostMallocDefault));
@@ -313,7 +325,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
                 }
             }
             for (int e = 0; e < 2; e++) S.cell_scratch[e] = c->dalloc<uint32_t>((size_t)prm.W * prm.H * 6 + 64);
-            for (int par = 0; par < 2; par++) {
+            for (int par = 0; par < NPAR; par++) {
                 FrameBuf &FB = S.fb[par];
                 FB.fc = c->dalloc<FeatCtl>(1);
                 for (int e = 0; e < 2; e++) {
@@ -358,8 +370,8 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
             S.pnp_feat = c->dalloc<int>(NF_MAX);
             S.pnp_err = c->dalloc<double>((size_t)NF_MAX * 2);
             S.pnp_level = c->dalloc<int8_t>(NF_MAX);
-            S.rcand = c->dalloc<uint32_t>((size_t)2 * NF_MAX * KC);  // per frame parity
-            S.rncand = c->dalloc<int>(2 * NF_MAX);
+            S.rcand = c->dalloc<uint32_t>((size_t)NPAR * NF_MAX * KC);  // per frame buffer
+            S.rncand = c->dalloc<int>(NPAR * NF_MAX);
             S.pair_l = c->dalloc<int>(NF_MAX), S.pair_r = c->dalloc<int>(NF_MAX);
             S.tri_X = c->dalloc<double>((size_t)NF_MAX * 3);
             S.tri_ok = c->dalloc<int8_t>(NF_MAX);
@@ -379,8 +391,8 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
 
 // ---- the per-frame launch chain -------------------------------------------------------------------
 static const char *kProfNames[Context::PROF_SLOTS] = {
-    "k_feat_begin", "", "k_score", "k_cells(pass0)", "k_cells(retry)", "k_gather", "k_brief", "",
-    "k_match_map(begin+project+candidates)", "", "", "", "k_track_mid(resolve+pass2+bookkeep+cull)", "k_pnp(+project staged)", "",
+    "k_feat_begin", "k_gate [early stream: waits for the previous k_pnp]", "k_score", "k_cells(pass0)", "k_cells(retry)", "k_gather", "k_brief", "k_gate_late [waits for the early stream]",
+    "k_match_map(begin + new points)", "k_early_map [early stream]", "k_early_mid [early stream]", "", "k_track_mid(resolve+pass2+bookkeep+cull)", "k_pnp(+project staged)", "",
     "", "k_candidates(staged)", "k_staged", "k_candidates(row) [feature stream]", "", "k_triangulate(row resolve+triangulate+finalize)", "",
     "", ""};
 
@@ -409,13 +421,13 @@ static void enqueue_frame(Context *c) {
     const int B = c->B;
     const Params &p = c->prm;
     Seq *S = c->d_seqs;
-    const int slot = (int)(c->enq % RING), par = (int)(c->enq & 1);
+    const int slot = (int)(c->enq % RING), par = (int)(c->enq % NPAR);
     const FrameArgs *fa = c->h_fargs + (size_t)slot * B;
     const int ext = fa[0].ext_corners;
     hipStream_t sf = c->stream_f, st = c->stream;
     for (int i = 0; i < Context::PROF_SLOTS; i++) c->ev_used[i] = false;
-    // ---- feature stage (stream_f): may start as soon as the tracking chain of frame enq-2 released this parity
-    if (c->enq >= 2) (void)hipStreamWaitEvent(sf, c->ev_track[par], 0);
+    // ---- feature stage (stream_f): may start as soon as the tracking chain of frame enq-NPAR released this buffer
+    if (c->enq >= NPAR) (void)hipStreamWaitEvent(sf, c->ev_track[par], 0);
     if (B == 1) {  // the frame's inputs travel as a kernel argument: no separate "begin" launch, no device read of pinned host memory
         LAUNCH(2, sf, k_score<true>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2), dim3(256), 0, S, c->h_fargs[slot], par);
     } else {
@@ -430,11 +442,23 @@ static void enqueue_frame(Context *c) {
     LAUNCH(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, S, par);
     LAUNCH(18, sf, k_candidates<MODE_ROW>, dim3(256, 1, B), dim3(256), 0, S, 0, par);
     (void)hipEventRecord(c->ev_feat[par], sf);
+    // ---- early stream: projection, candidate lists and greedy resolution of the map points that survived the previous frame,
+    //      as soon as that frame's pose exists (its k_pnp) -- its k_staged / k_triangulate only append behind them
+    const unsigned seq = (unsigned)(c->enq + 1);  // this frame's sequence number; the previous frame's is enq (0: none)
+    {
+        hipStream_t se = c->stream_e;
+        (void)hipStreamWaitEvent(se, c->ev_feat[par], 0);
+        LAUNCH(1, se, k_gate, dim3(1, 1, B), dim3(64), 0, S, (unsigned)c->enq, seq);  // polls the previous frame's k_pnp: no cross-stream event
+        LAUNCH(9, se, k_early_map, dim3(256, 1, B), dim3(256), 0, S, par, seq);
+        LAUNCH(10, se, k_early_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par, seq);
+        (void)hipEventRecord(c->ev_early[par], se);
+    }
     // ---- tracking chain (stream): strictly ordered frame after frame
-    (void)hipStreamWaitEvent(st, c->ev_feat[par], 0);
-    LAUNCH(8, st, k_match_map, dim3(256, 1, B), dim3(256), 0, S, par);
-    LAUNCH(12, st, k_track_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par);
-    LAUNCH(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), PNP_DYN_BYTES, S, par);
+    (void)hipStreamWaitEvent(st, c->ev_feat[par], 0);  // long satisfied: the feature stream runs a frame ahead
+    LAUNCH(7, st, k_gate_late, dim3(1, 1, B), dim3(64), 0, S, seq);  // the early stream is done with this frame (polled, no barrier packet)
+    LAUNCH(8, st, k_match_map, dim3(256, 1, B), dim3(256), 0, S, par, seq);
+    LAUNCH(12, st, k_track_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par, seq);
+    LAUNCH(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), PNP_DYN_BYTES, S, par, seq);
     LAUNCH(16, st, k_candidates<MODE_STAGED>, dim3(64, 1, B), dim3(256), 0, S, 0, par);
     LAUNCH(17, st, k_staged, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par);
     LAUNCH(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, S, par);
@@ -453,7 +477,7 @@ static void collect_oldest(Context *c) {
     const int slot = (int)(c->done % RING);
     HIPCHK(c, hipEventSynchronize(c->ev_done[slot]));
     c->last_slot = slot;
-    c->last_par = (int)(c->done & 1);
+    c->last_par = (int)(c->done % NPAR);
     c->done++;
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) c->set_error(std::string("kernel chain: ") + hipGetErrorString(e));
@@ -472,6 +496,13 @@ static void collect_oldest(Context *c) {
             char buf[128];
             std::snprintf(buf, sizeof(buf), "capacity overflow mask 0x%x in sequence %d", c->h_ctl[(size_t)slot * c->B + s].overflow, s);
             c->set_error(buf);
+        }
+    for (int s = 0; s < c->B; s++)
+        if (c->h_ctl[(size_t)slot * c->B + s].gate_timeouts != c->gate_timeouts_seen) {
+            c->gate_timeouts_seen = c->h_ctl[(size_t)slot * c->B + s].gate_timeouts;
+            // not a wrong result (the frame was tracked without the early stream), but 20 ms were lost: the early stream's gate
+            // did not see the previous frame's k_pnp -- the two streams probably share a hardware queue
+            c->set_error("early-stream gate timed out (results unaffected; streams may share a hardware queue)");
         }
 }
 static void drain(Context *c) {
@@ -704,7 +735,7 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
         return;
     }
     drain(c);
-    const int par = (int)(c->enq & 1);
+    const int par = (int)(c->enq % NPAR);
     hipStream_t sf = c->stream_f;
     // one contiguous H2D copy per image, then a device-side re-pitch (a strided 2-D copy of pageable memory is slow)
     const size_t nbytes = (size_t)n_rows * n_cols;

@@ -381,13 +381,25 @@ __global__ __launch_bounds__(256) void k_match_map(Seq *seqs, int par, unsigned 
 // complete); the prediction is recomputed from the same persistent inputs, so both kernels see the same pose.
 // k_gate : one wavefront per sequence at the head of the early stream; returns when the previous frame's k_pnp has published
 // its sequence number (or after 20 ms of wall clock: then the early kernels stand down and the late ones do all the work)
-__global__ __launch_bounds__(64) void k_gate(Seq *seqs, unsigned want, unsigned seq) {
+// last kernel of the feature stage (one thread per sequence): this buffer's features are complete
+__global__ void k_feat_done(Seq *seqs, int par, unsigned seq) {
+    if (threadIdx.x != 0) return;
+    FeatCtl &fc = *seqs[blockIdx.x].fb[par].fc;
+    __threadfence();
+    atomicExch(&fc.feat_seq, seq);
+}
+
+__global__ __launch_bounds__(64) void k_gate(Seq *seqs, int par, unsigned want, unsigned seq) {
     Ctl &ctl = *seqs[blockIdx.z].ctl;
+    FeatCtl &fc = *seqs[blockIdx.z].fb[par].fc;
     if (threadIdx.x != 0) return;
     bool ok = true;
-    if (want != 0) {
+    {
+        // both conditions are polled: a stream parked on an event barrier stalls the other queues of its hardware pipe until
+        // a time slice expires (the feature stream did not advance while this stream waited for the NEXT frame's features)
         const unsigned long long t0 = wall_clock64();  // 100 MHz
-        while (__hip_atomic_load(&ctl.pnp_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        while (__hip_atomic_load(&ctl.pnp_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want ||
+               __hip_atomic_load(&fc.feat_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
             __builtin_amdgcn_s_sleep(64);
             if (wall_clock64() - t0 > 2000000ull) {
                 ok = false;

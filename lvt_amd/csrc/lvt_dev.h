@@ -107,6 +107,7 @@ struct FeatCtl {        // per-frame state of the FEATURE stage (own stream, dou
     int n_detected[2];  // corners before BRIEF (for the <200 retry, handler.cpp:161)
     int retry[2];
     int overflow;
+    unsigned feat_seq;  // sequence number of the frame whose features this buffer holds, published by k_feat_done (polled by k_gate)
 };
 
 struct Feat {  // one image's lvt_image_features_struct (lvt_image_features_struct.h:62-80), SoA

@@ -441,14 +441,14 @@ static void enqueue_frame(Context *c) {
     LAUNCH(5, sf, k_gather, dim3(1, 2, B), dim3(1024), 0, S, par);
     LAUNCH(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, S, par);
     LAUNCH(18, sf, k_candidates<MODE_ROW>, dim3(256, 1, B), dim3(256), 0, S, 0, par);
+    hipLaunchKernelGGL(k_feat_done, dim3(B), dim3(64), 0, sf, S, par, (unsigned)(c->enq + 1));
     (void)hipEventRecord(c->ev_feat[par], sf);
     // ---- early stream: projection, candidate lists and greedy resolution of the map points that survived the previous frame,
     //      as soon as that frame's pose exists (its k_pnp) -- its k_staged / k_triangulate only append behind them
     const unsigned seq = (unsigned)(c->enq + 1);  // this frame's sequence number; the previous frame's is enq (0: none)
     {
         hipStream_t se = c->stream_e;
-        (void)hipStreamWaitEvent(se, c->ev_feat[par], 0);
-        LAUNCH(1, se, k_gate, dim3(1, 1, B), dim3(64), 0, S, (unsigned)c->enq, seq);  // polls the previous frame's k_pnp: no cross-stream event
+        LAUNCH(1, se, k_gate, dim3(1, 1, B), dim3(64), 0, S, par, (unsigned)c->enq, seq);  // polls the previous k_pnp and this frame's features
         LAUNCH(9, se, k_early_map, dim3(256, 1, B), dim3(256), 0, S, par, seq);
         LAUNCH(10, se, k_early_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par, seq);
         (void)hipEventRecord(c->ev_early[par], se);

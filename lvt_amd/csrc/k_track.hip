@@ -381,6 +381,20 @@ __global__ __launch_bounds__(256) void k_match_map(Seq *seqs, int par, unsigned 
 // complete); the prediction is recomputed from the same persistent inputs, so both kernels see the same pose.
 // k_gate : one wavefront per sequence at the head of the early stream; returns when the previous frame's k_pnp has published
 // its sequence number (or after 20 ms of wall clock: then the early kernels stand down and the late ones do all the work)
+// head of the feature stage: returns when the tracking chain of the frame that used this feature buffer last (NPAR frames ago)
+// is finished.  Polled: a feature stream parked on the event barrier stalls the queues that share its hardware pipe -- with
+// the barrier alone, SHORTENING the feature chain made the whole pipeline slower.  The barrier behind this kernel stays as the
+// guarantee; it is already satisfied when the gate returns.
+__global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, unsigned want) {
+    Ctl &ctl = *seqs[blockIdx.z].ctl;
+    if (threadIdx.x != 0) return;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(&ctl.track_done_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > 6000000ull) break;
+    }
+}
+
 // last kernel of the feature stage (one thread per sequence): this buffer's features are complete
 __global__ void k_feat_done(Seq *seqs, int par, unsigned seq) {
     if (threadIdx.x != 0) return;
@@ -400,7 +414,7 @@ __global__ __launch_bounds__(64) void k_gate(Seq *seqs, int par, unsigned want, 
         const unsigned long long t0 = wall_clock64();  // 100 MHz
         while (__hip_atomic_load(&ctl.pnp_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want ||
                __hip_atomic_load(&fc.feat_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
-            __builtin_amdgcn_s_sleep(64);
+            __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t0 > 2000000ull) {
                 ok = false;
                 break;
@@ -1051,7 +1065,7 @@ __global__ __launch_bounds__(64) void k_gate_late(Seq *seqs, unsigned seq) {
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(&ctl.early_fin_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
-        __builtin_amdgcn_s_sleep(64);
+        __builtin_amdgcn_s_sleep(8);
         if (wall_clock64() - t0 > 6000000ull) {  // 60 ms: the early stream's own gate gives up after 20
             atomicAdd(&ctl.gate_timeouts, 1 << 16);
             break;
@@ -1772,7 +1786,7 @@ __device__ bool triangulate_pair(const Params &p, const double *cml, const doubl
     return true;
 }
 
-__global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par) {
+__global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, unsigned seq) {
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     __shared__ double cml[12], cmr[12], R[9];
@@ -1876,6 +1890,8 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par) {
         ctl.counts[C_STAGED_SIZE] = *S.staged_n;
         ctl.overflow |= S.fb[par].fc->overflow;
         ctl.counts[C_OVERFLOW] = ctl.overflow;
+        __threadfence();
+        atomicExch(&ctl.track_done_seq, seq);  // this frame's feature buffer may be refilled (k_gate_buf polls this)
     }
 }
 

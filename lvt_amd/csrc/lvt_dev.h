@@ -77,6 +77,7 @@ struct Ctl {
     // for an in-stream boundary): k_pnp publishes its frame's sequence number, a one-wave gate kernel at the head of the early
     // stream polls it (with a wall-clock time-out), k_early_mid confirms that the early part really ran
     unsigned pnp_seq, gate_ok, early_ran_seq, early_fin_seq;
+    unsigned track_done_seq;  // last frame whose tracking chain has finished with its feature buffer (polled by k_gate_buf)
     int gate_timeouts;
     // per-frame control, written by k_begin / later kernels
     int active;         // 0: LOST at frame start -> every kernel exits

@@ -273,6 +273,7 @@ static void reset_state(Context *c) {  // lvt_system::reset (lvt_system.cpp:44-6
         z.out_status = 1;
         z.pnp_seq = (unsigned)c->enq;  // the next frame's gate waits for this value: nothing is pending
         z.early_fin_seq = (unsigned)c->enq;
+        z.track_done_seq = (unsigned)c->enq;
         HIPCHK(c, hipMemcpyAsync(c->d_ctl[s], &z, sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->h_seqs[s].map_n, 0, sizeof(int), c->stream));
         HIPCHK(c, hipMemsetAsync(c->h_seqs[s].map_cur, 0, sizeof(int), c->stream));
@@ -427,7 +428,10 @@ static void enqueue_frame(Context *c) {
     hipStream_t sf = c->stream_f, st = c->stream;
     for (int i = 0; i < Context::PROF_SLOTS; i++) c->ev_used[i] = false;
     // ---- feature stage (stream_f): may start as soon as the tracking chain of frame enq-NPAR released this buffer
-    if (c->enq >= NPAR) (void)hipStreamWaitEvent(sf, c->ev_track[par], 0);
+    if (c->enq >= NPAR) {
+        hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, B), dim3(64), 0, sf, S, (unsigned)(c->enq + 1 - NPAR));  // polls; see k_gate_buf
+        (void)hipStreamWaitEvent(sf, c->ev_track[par], 0);
+    }
     if (B == 1) {  // the frame's inputs travel as a kernel argument: no separate "begin" launch, no device read of pinned host memory
         LAUNCH(2, sf, k_score<true>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2), dim3(256), 0, S, c->h_fargs[slot], par);
     } else {
@@ -461,10 +465,10 @@ static void enqueue_frame(Context *c) {
     LAUNCH(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), PNP_DYN_BYTES, S, par, seq);
     LAUNCH(16, st, k_candidates<MODE_STAGED>, dim3(64, 1, B), dim3(256), 0, S, 0, par);
     LAUNCH(17, st, k_staged, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par);
-    LAUNCH(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, S, par);
+    LAUNCH(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, S, par, seq);
+    (void)hipEventRecord(c->ev_track[par], st);  // the feature buffer is free (before the record copy: the gate's barrier resolves at once)
     for (int s = 0; s < B; s++)
         (void)hipMemcpyAsync(&c->h_ctl[(size_t)slot * B + s], c->d_ctl[s], sizeof(Ctl), hipMemcpyDeviceToHost, st);
-    (void)hipEventRecord(c->ev_track[par], st);
     (void)hipEventRecord(c->ev_done[slot], st);
     c->enq++;
 }

@@ -99,6 +99,9 @@ LVT_API void lvt_amd_get_pose(lvt_handle h, double q_wxyz[4], double p[3]);
 LVT_API void lvt_amd_get_predicted_pose(lvt_handle h, double q_wxyz[4], double p[3]);
 /* bring-up profiling: cycle stamps written by detection cell 0 of the left image */
 LVT_API void lvt_amd_get_debug(lvt_handle h, long long out[32]);
+/* wall-clock (100 MHz) start / end stamps of the kernels on the inter-frame critical path, for the frame lvt_amd_wait returned
+ * last (tools/timeline.py); does not drain the pipeline */
+LVT_API void lvt_amd_get_timeline(lvt_handle h, long long out[16]);
 /* raw per-pixel intermediates of the last frame: what = 0 score map (u8, rows x pitch),
  * 1 box-sum map (u16, rows x pitch).  returns bytes written, pitch via *pitch_out (in elements). */
 LVT_API int lvt_amd_get_plane(lvt_handle h, int eye, int what, void *dst, int cap_bytes, int *pitch_out);

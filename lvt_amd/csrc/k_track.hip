@@ -347,6 +347,7 @@ __global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2, int pa
 // derives the per-frame facts it needs (active / first frame / predicted pose) from the PERSISTENT part of Ctl, which
 // nobody writes during this kernel; block 0 additionally publishes them for the rest of the chain.
 __global__ __launch_bounds__(256) void k_match_map(Seq *seqs, int par, unsigned seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[40] = (long long)wall_clock64();
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     const int state = ctl.state;  // persistent; not written by this kernel
@@ -399,11 +400,13 @@ __global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, unsigned want) {
 __global__ void k_feat_done(Seq *seqs, int par, unsigned seq) {
     if (threadIdx.x != 0) return;
     FeatCtl &fc = *seqs[blockIdx.x].fb[par].fc;
+    seqs[blockIdx.x].ctl->dbg[47] = (long long)wall_clock64();  // (written from the feature stream: the frame it belongs to may differ)
     __threadfence();
     atomicExch(&fc.feat_seq, seq);
 }
 
 __global__ __launch_bounds__(64) void k_gate(Seq *seqs, int par, unsigned want, unsigned seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[32] = (long long)wall_clock64();
     Ctl &ctl = *seqs[blockIdx.z].ctl;
     FeatCtl &fc = *seqs[blockIdx.z].fb[par].fc;
     if (threadIdx.x != 0) return;
@@ -412,10 +415,20 @@ __global__ __launch_bounds__(64) void k_gate(Seq *seqs, int par, unsigned want, 
         // both conditions are polled: a stream parked on an event barrier stalls the other queues of its hardware pipe until
         // a time slice expires (the feature stream did not advance while this stream waited for the NEXT frame's features)
         const unsigned long long t0 = wall_clock64();  // 100 MHz
-        while (__hip_atomic_load(&ctl.pnp_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want ||
-               __hip_atomic_load(&fc.feat_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+        // (a) this frame's features: the tracking stream has no barrier of its own on them, so this wait only gives up after
+        //     2 s (a wedged feature stream; reported through lvt_amd_last_error)
+        while (__hip_atomic_load(&fc.feat_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
             __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > 2000000ull) {
+            if (wall_clock64() - t0 > 200000000ull) {
+                atomicAdd(&ctl.gate_timeouts, 1 << 8);
+                break;
+            }
+        }
+        // (b) the previous frame's k_pnp: after 20 ms the early kernels stand down and the late ones do all the work
+        const unsigned long long t1 = wall_clock64();
+        while (__hip_atomic_load(&ctl.pnp_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+            __builtin_amdgcn_s_sleep(8);
+            if (wall_clock64() - t1 > 2000000ull) {
                 ok = false;
                 break;
             }
@@ -423,9 +436,11 @@ __global__ __launch_bounds__(64) void k_gate(Seq *seqs, int par, unsigned want, 
     }
     if (!ok) atomicAdd(&ctl.gate_timeouts, 1);
     ctl.gate_ok = ok ? seq : 0u;
+    ctl.dbg[33] = (long long)wall_clock64();
 }
 
 __global__ __launch_bounds__(256) void k_early_map(Seq *seqs, int par, unsigned seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[34] = (long long)wall_clock64();
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     const int n_early = (ctl.gate_ok == seq) ? ctl.early_done : 0;
@@ -999,6 +1014,7 @@ __device__ __forceinline__ bool bookkeep_cull_small(Seq &S, Ctl &ctl, int par, i
 // k_track_mid : find_matches pass 1 [+ second pass, if pass 1 found < 50] + bookkeeping + LOST decision + cull
 // =================================================================================================
 __global__ __launch_bounds__(RES_THREADS) void k_track_mid(Seq *seqs, int par, unsigned seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[42] = (long long)wall_clock64();
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     if (!ctl.active) return;
@@ -1042,6 +1058,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_track_mid(Seq *seqs, int par, u
 // k_early_mid : the greedy resolution of find_matches for the map points [0, early_done) (storage order: their decisions do
 // not depend on the points the previous frame is still appending), on the early stream behind k_early_map
 __global__ __launch_bounds__(RES_THREADS) void k_early_mid(Seq *seqs, int par, unsigned seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[36] = (long long)wall_clock64();
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     const int n_early = (ctl.gate_ok == seq) ? ctl.early_done : 0;
@@ -1052,6 +1069,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_early_mid(Seq *seqs, int par, u
         if (threadIdx.x == 0) ctl.early_ran_seq = seq;  // the late kernels trust early_done only with this confirmation
     }
     if (threadIdx.x == 0) {  // the tracking stream's gate polls this: the early stream is done with this frame, whatever it did
+        ctl.dbg[37] = (long long)wall_clock64();
         __threadfence();
         atomicExch(&ctl.early_fin_seq, seq);
     }
@@ -1061,6 +1079,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_early_mid(Seq *seqs, int par, u
 // on an event would do the same, but a queue parked on a barrier stalls the other queues of its hardware pipe (measured: the
 // feature stream only advanced when the tracking stream's barrier resolved), and the event itself costs ~12 us of latency.
 __global__ __launch_bounds__(64) void k_gate_late(Seq *seqs, unsigned seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[38] = (long long)wall_clock64();
     Ctl &ctl = *seqs[blockIdx.z].ctl;
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = wall_clock64();
@@ -1520,6 +1539,7 @@ __device__ __forceinline__ void pnp_solve(const Params &prm, const Pose &prior, 
 }
 
 __global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs, int par, unsigned seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[44] = (long long)wall_clock64();
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     if (!ctl.active || ctl.first_frame || ctl.lost_now) {
@@ -1545,6 +1565,7 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs, int par, unsigne
         ctl.counts[C_PNP_INLIERS] = inliers;
         ctl.early_done = *S.map_n;  // the map after clean_untracked_points: the next frame may start on these points now
         ctl.early_accepted = 0;
+        ctl.dbg[45] = (long long)wall_clock64();
         __threadfence();
         atomicExch(&ctl.pnp_seq, seq);  // release: everything the next frame's early kernels read is final
     }
@@ -1786,7 +1807,7 @@ __device__ bool triangulate_pair(const Params &p, const double *cml, const doubl
     return true;
 }
 
-__global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, unsigned seq) {
+__global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, unsigned seq, Ctl *rec_out) {
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     __shared__ double cml[12], cmr[12], R[9];
@@ -1890,8 +1911,19 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, unsign
         ctl.counts[C_STAGED_SIZE] = *S.staged_n;
         ctl.overflow |= S.fb[par].fc->overflow;
         ctl.counts[C_OVERFLOW] = ctl.overflow;
+        ctl.dbg[46] = (long long)wall_clock64();
         __threadfence();
         atomicExch(&ctl.track_done_seq, seq);  // this frame's feature buffer may be refilled (k_gate_buf polls this)
+    }
+    // ---- the frame's result record goes straight into the caller's pinned ring slot (device-visible host memory): an
+    //      asynchronous copy engine transfer at this point of the stream cost ~20 us of the inter-frame critical path
+    __syncthreads();
+    {
+        static_assert(sizeof(Ctl) % 8 == 0, "record copy");
+        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&ctl);
+        unsigned long long *dst = reinterpret_cast<unsigned long long *>(rec_out + blockIdx.z);
+        for (int i = tid; i < (int)(sizeof(Ctl) / 8); i += 1024) dst[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __threadfence_system();
     }
 }
 

@@ -92,7 +92,8 @@ struct Ctl {
     Pose predicted, optimized;
     int counts[N_COUNTS];
     int overflow;
-    long long dbg[32];  // phase cycle stamps of cell 0 / eye 0 (bring-up profiling)
+    long long dbg[48];  // [0..31] phase cycle stamps of single-workgroup kernels; [32..47] wall-clock (100 MHz) start / end of the
+                        // kernels on the inter-frame critical path (tools/timeline.py)
     // result record copied to the host
     double out_R[9], out_t[3];
     int out_status;

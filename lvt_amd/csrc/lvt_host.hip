@@ -71,6 +71,7 @@ struct Context {
     std::vector<Seq> h_seqs;   // host mirror (device pointers inside)
     std::vector<Ctl *> d_ctl;
     Ctl *h_ctl = nullptr;          // pinned, RING x B records
+    Ctl *h_ctl_dev = nullptr;      // the same memory as the device sees it (k_triangulate writes each frame's record there)
     FrameArgs *h_fargs = nullptr;  // pinned, RING x B
     hipEvent_t ev_feat[NPAR] = {}, ev_track[NPAR] = {}, ev_pnp[NPAR] = {}, ev_early[NPAR] = {}, ev_done[RING] = {};
     // owned staging for the host-buffer entry points, per frame parity
@@ -306,6 +307,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
         for (auto &e : c->ev_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->pitch = ((prm.W + 63) / 64) * 64;
         HIPCHK(c, hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl) * B * RING, hipHostMallocDefault));
+        HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_ctl_dev, c->h_ctl, 0));
         HIPCHK(c, hipHostMalloc((void **)&c->h_fargs, sizeof(FrameArgs) * B * RING, hipHostMallocDefault));
         c->h_seqs.resize(B);
         c->d_ctl.resize(B);
@@ -430,7 +432,7 @@ static void enqueue_frame(Context *c) {
     // ---- feature stage (stream_f): may start as soon as the tracking chain of frame enq-NPAR released this buffer
     if (c->enq >= NPAR) {
         hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, B), dim3(64), 0, sf, S, (unsigned)(c->enq + 1 - NPAR));  // polls; see k_gate_buf
-        (void)hipStreamWaitEvent(sf, c->ev_track[par], 0);
+        (void)hipStreamWaitEvent(sf, c->ev_done[(int)((c->enq - NPAR) % RING)], 0);
     }
     if (B == 1) {  // the frame's inputs travel as a kernel argument: no separate "begin" launch, no device read of pinned host memory
         LAUNCH(2, sf, k_score<true>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2), dim3(256), 0, S, c->h_fargs[slot], par);
@@ -458,18 +460,16 @@ static void enqueue_frame(Context *c) {
         (void)hipEventRecord(c->ev_early[par], se);
     }
     // ---- tracking chain (stream): strictly ordered frame after frame
-    (void)hipStreamWaitEvent(st, c->ev_feat[par], 0);  // long satisfied: the feature stream runs a frame ahead
+    // (no barrier on the features here: k_gate_late returns only after the early stream's gate has seen them complete, and
+    //  every barrier / event packet costs this stream 3-4 us per frame)
     LAUNCH(7, st, k_gate_late, dim3(1, 1, B), dim3(64), 0, S, seq);  // the early stream is done with this frame (polled, no barrier packet)
     LAUNCH(8, st, k_match_map, dim3(256, 1, B), dim3(256), 0, S, par, seq);
     LAUNCH(12, st, k_track_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par, seq);
     LAUNCH(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), PNP_DYN_BYTES, S, par, seq);
     LAUNCH(16, st, k_candidates<MODE_STAGED>, dim3(64, 1, B), dim3(256), 0, S, 0, par);
     LAUNCH(17, st, k_staged, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par);
-    LAUNCH(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, S, par, seq);
-    (void)hipEventRecord(c->ev_track[par], st);  // the feature buffer is free (before the record copy: the gate's barrier resolves at once)
-    for (int s = 0; s < B; s++)
-        (void)hipMemcpyAsync(&c->h_ctl[(size_t)slot * B + s], c->d_ctl[s], sizeof(Ctl), hipMemcpyDeviceToHost, st);
-    (void)hipEventRecord(c->ev_done[slot], st);
+    LAUNCH(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, S, par, seq, c->h_ctl_dev + (size_t)slot * B);  // writes the result record itself
+    (void)hipEventRecord(c->ev_done[slot], st);  // the one event of the tracking stream per frame: result record written, feature buffer free
     c->enq++;
 }
 
@@ -933,6 +933,10 @@ LVT_API void lvt_amd_get_debug(lvt_handle h, long long out[32]) {
         for (int i = 0; i < 32; i++) out[i] = last_ctl(c).dbg[i];
     } catch (...) {
     }
+}
+LVT_API void lvt_amd_get_timeline(lvt_handle h, long long out[16]) {  // of the frame lvt_amd_wait returned last; does not drain
+    Context *c = static_cast<Context *>(h);
+    for (int i = 0; i < 16; i++) out[i] = last_ctl(c).dbg[32 + i];
 }
 LVT_API int lvt_amd_get_plane(lvt_handle h, int eye, int what, void *dst, int cap_bytes, int *pitch_out) {
     Context *c = static_cast<Context *>(h);

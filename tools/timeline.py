@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Inter-frame critical path in wall-clock time (no profiler attached): the kernels stamp wall_clock64() at their start / end
+into Ctl::dbg[32..47]; this prints the medians over the asynchronous steady state.  python tools/timeline.py"""
+import os
+import sys
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import numpy as np
+import torch
+
+import lvt_amd
+from lvt_amd.synth import make_world
+
+w = make_world("kitti", seed=0)
+prm = lvt_amd.kitti_params()
+H, W = w.H, w.W
+pitch = ((W + 63) // 64) * 64
+n = 160
+frames = torch.zeros((n, 2, H, pitch), dtype=torch.uint8, device="cuda")
+for i in range(n):
+    frames[i, :, :, :W] = w.render_stereo_torch(i, device="cuda")
+torch.cuda.synchronize()
+vo = lvt_amd.LvtSystem.create(prm, 1)
+base, fs = frames.data_ptr(), 2 * H * pitch
+tl = []
+inflight = 0
+for i in range(n):
+    vo.track_device_async(base + i * fs, base + i * fs + H * pitch, H, W, pitch)
+    inflight += 1
+    if inflight >= 4:
+        vo.wait(); inflight -= 1
+        tl.append(vo.timeline().copy())
+while inflight:
+    vo.wait(); inflight -= 1
+    tl.append(vo.timeline().copy())
+tl = np.array(tl[40:], dtype=np.float64) / 100.0  # us
+names = ["gate start", "gate end", "early_map start", "-", "early_mid start", "early_mid end", "gate_late start", "-", "match_map start", "-",
+         "track_mid start", "-", "pnp start", "pnp end", "triangulate end", "feat_done"]
+# The early-stream kernels of frame k+1 run during the tail of frame k: if their stamps are in record k (copied after
+# k_triangulate(k)) they belong to frame k+1, otherwise they are one frame older.  Decide per record by comparing with pnp end.
+def med(x): return float(np.median(x))
+r, nx = tl[:-1], tl[1:]
+same = r[:, 1] > r[:, 13]           # gate end after this record's pnp end -> early stamps of frame k+1 are in record k
+print("records whose early-stream stamps belong to the NEXT frame: %d of %d" % (int(same.sum()), len(same)))
+r, nx = r[same], nx[same]
+print("frame period (pnp start to pnp start)            : %6.1f us" % med(np.diff(tl[:, 12])))
+print("pnp(k) end -> gate(k+1) end                       : %6.1f us   (gate started %.1f us before pnp(k) end)" % (med(r[:, 1] - r[:, 13]), med(r[:, 13] - r[:, 0])))
+print("gate end -> early_map start                       : %6.1f us" % med(r[:, 2] - r[:, 1]))
+print("early_map start -> early_mid start                : %6.1f us" % med(r[:, 4] - r[:, 2]))
+print("early_mid start -> early_mid end                  : %6.1f us" % med(r[:, 5] - r[:, 4]))
+print("pnp(k) end -> triangulate(k) end                  : %6.1f us" % med(r[:, 14] - r[:, 13]))
+print("early_mid(k+1) end -> match_map(k+1) start        : %6.1f us   (gate_late started %.1f us before early_mid end)" % (med(nx[:, 8] - r[:, 5]), med(r[:, 5] - nx[:, 6])))
+print("triangulate(k) end -> match_map(k+1) start        : %6.1f us" % med(nx[:, 8] - r[:, 14]))
+print("match_map start -> track_mid start -> pnp start   : %6.1f + %.1f us" % (med(nx[:, 10] - nx[:, 8]), med(nx[:, 12] - nx[:, 10])))
+print("pnp start -> pnp end                              : %6.1f us" % med(nx[:, 13] - nx[:, 12]))

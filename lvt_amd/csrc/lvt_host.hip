@@ -73,7 +73,7 @@ struct Context {
     Ctl *h_ctl = nullptr;          // pinned, RING x B records
     Ctl *h_ctl_dev = nullptr;      // the same memory as the device sees it (k_triangulate writes each frame's record there)
     FrameArgs *h_fargs = nullptr;  // pinned, RING x B
-    hipEvent_t ev_feat[NPAR] = {}, ev_track[NPAR] = {}, ev_pnp[NPAR] = {}, ev_early[NPAR] = {}, ev_done[RING] = {};
+    hipEvent_t ev_done[RING] = {};  // the only events: everything between the streams is handed over by polling gates (k_gate*)
     // owned staging for the host-buffer entry points, per frame parity
     uint8_t *d_packed[NPAR][2] = {}, *d_img[NPAR][2] = {};
     float *d_depth[NPAR] = {};
@@ -111,10 +111,6 @@ struct Context {
         for (auto &e : ev)
             for (auto &x : e)
                 if (x) (void)hipEventDestroy(x);
-        for (auto &x : ev_feat) if (x) (void)hipEventDestroy(x);
-        for (auto &x : ev_track) if (x) (void)hipEventDestroy(x);
-        for (auto &x : ev_pnp) if (x) (void)hipEventDestroy(x);
-        for (auto &x : ev_early) if (x) (void)hipEventDestroy(x);
         for (auto &x : ev_done) if (x) (void)hipEventDestroy(x);
         if (h_ctl) (void)hipHostFree(h_ctl);
         if (h_fargs) (void)hipHostFree(h_fargs);
@@ -300,10 +296,6 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream_f, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream_e, hipStreamNonBlocking));
         c->own_stream = true;
-        for (auto &e : c->ev_feat) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (auto &e : c->ev_track) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (auto &e : c->ev_pnp) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        for (auto &e : c->ev_early) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto &e : c->ev_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         c->pitch = ((prm.W + 63) / 64) * 64;
         HIPCHK(c, hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl) * B * RING, hipHostMallocDefault));
@@ -448,7 +440,6 @@ static void enqueue_frame(Context *c) {
     LAUNCH(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, S, par);
     LAUNCH(18, sf, k_candidates<MODE_ROW>, dim3(256, 1, B), dim3(256), 0, S, 0, par);
     hipLaunchKernelGGL(k_feat_done, dim3(B), dim3(64), 0, sf, S, par, (unsigned)(c->enq + 1));
-    (void)hipEventRecord(c->ev_feat[par], sf);
     // ---- early stream: projection, candidate lists and greedy resolution of the map points that survived the previous frame,
     //      as soon as that frame's pose exists (its k_pnp) -- its k_staged / k_triangulate only append behind them
     const unsigned seq = (unsigned)(c->enq + 1);  // this frame's sequence number; the previous frame's is enq (0: none)
@@ -457,7 +448,6 @@ static void enqueue_frame(Context *c) {
         LAUNCH(1, se, k_gate, dim3(1, 1, B), dim3(64), 0, S, par, (unsigned)c->enq, seq);  // polls the previous k_pnp and this frame's features
         LAUNCH(9, se, k_early_map, dim3(256, 1, B), dim3(256), 0, S, par, seq);
         LAUNCH(10, se, k_early_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par, seq);
-        (void)hipEventRecord(c->ev_early[par], se);
     }
     // ---- tracking chain (stream): strictly ordered frame after frame
     // (no barrier on the features here: k_gate_late returns only after the early stream's gate has seen them complete, and

@@ -223,10 +223,15 @@ def main():
             tf = torch.zeros((B, N), dtype=torch.uint8, device=dev)
             out = torch.zeros((B, M, 4), dtype=torch.int32, device=dev)
             torch.cuda.synchronize()
+            qxy, txy = qxy.contiguous(), txy.contiguous()
+            # warm-up: the launch time keeps falling for the first ~50 launches after the light pipeline phase (270 -> 229 us
+            # measured) while the clocks ramp up under the sustained load; the steady state is what is reported
+            for _ in range(8):
+                lvt_amd.hamming_match_batched(qd, qxy, td, txy, tf, 625.0, 0, H, W, out, launches=10)
             us = []
-            for _ in range(6):  # 5 launches back to back per timing: the average excludes the ~5 us of launch latency
-                us.append(lvt_amd.hamming_match_batched(qd, qxy.contiguous(), td, txy.contiguous(), tf, 625.0, 0, H, W, out, launches=5))
-            us = sorted(us[1:])
+            for _ in range(7):  # 5 launches back to back per timing: the average excludes the ~5 us of launch latency
+                us.append(lvt_amd.hamming_match_batched(qd, qxy, td, txy, tf, 625.0, 0, H, W, out, launches=5))
+            us = sorted(us)
             med = us[len(us) // 2]
             byts = float(B) * bmatch(M, N)
             ach = byts / (med * 1e-6) / 1e9
@@ -243,12 +248,32 @@ def main():
                     traffic_src = "profiles/hamming_pmc.json (%s)" % pm.get("source", "rocprofv3 --pmc")
             except Exception:  # noqa: BLE001
                 pass
+            # what a plain device copy of the same byte count reaches on this box (read half + write half): the achievable
+            # streaming rate, reported beside the 8 TB/s spec peak that `frac` is priced against
+            copy_gbs = None
+            try:
+                cx = torch.empty(int(byts) // 2, dtype=torch.uint8, device=dev)
+                cy = torch.empty_like(cx)
+                for _ in range(30):
+                    cy.copy_(cx)
+                c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                c0.record()
+                for _ in range(10):
+                    cy.copy_(cx)
+                c1.record()
+                torch.cuda.synchronize()
+                copy_gbs = byts / (c0.elapsed_time(c1) * 1e-4) / 1e9
+                del cx, cy
+            except Exception:  # noqa: BLE001
+                pass
             hb = {"kernel": "lvt::k_hamming_batched<0,3,1,2> (masked 2-NN Hamming matcher, radius mode)", "bound": "hbm", "achieved": round(ach, 1),
                   "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
                   "avg_us": round(med, 2), "launch": {"B": B, "M": M, "N": N, "algorithmic_bytes": byts},
                   "traffic_source": traffic_src,
+                  "device_copy_same_bytes_GBs": None if copy_gbs is None else round(copy_gbs, 1),
+                  "frac_of_device_copy": None if copy_gbs is None else round(ach / copy_gbs, 4),
                   "note": "B independent KITTI-nominal problems per launch; algorithmic bytes 40(M+N)+N+16M each (SURVEY 8d); average of 5 "
-                          "back-to-back launches between two HIP events on the launch stream, median of 5 such timings; traffic = "
+                          "back-to-back launches between two HIP events on the launch stream, median of 7 such timings after 80 warm-up launches; traffic = "
                           "2*FETCH_SIZE + WRITE_SIZE of the same launch from the committed rocprofv3 PMC passes"}
         except Exception as e:  # noqa: BLE001
             hb = {"error": str(e)}

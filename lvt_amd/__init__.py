@@ -18,7 +18,7 @@ import numpy as np
 from .params import LvtParameters, ParamsPOD, kitti_params, euroc_params, tum_params  # noqa: F401
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblvt_c.so")
+LIB_PATH = os.environ.get("LVT_AMD_LIB") or os.path.join(_HERE, "lib", "liblvt_c.so")  # override: kernel A/B experiments
 
 # every symbol include/lvt_c.h and include/lvt_amd_ext.h declare
 ABI_SYMBOLS = [

@@ -54,6 +54,13 @@ __device__ __forceinline__ float div_cell(float y) {
     return __builtin_fmaf(__builtin_fmaf(-25.0f, q0, y), c, q0);
 }
 
+// mask = 2 * mask + (d2 < r2): compare into VCC, add-with-carry shifts the mask and appends the bit -- two instructions
+// per candidate where (compare, select, or) plus a materialised bit constant cost four.  The candidates are walked from
+// the last to the first, so candidate v still lands in bit v.
+__device__ __forceinline__ void push_bit(uint32_t &mask, float d2, float r2) {
+    asm("v_cmp_gt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(d2), "v"(r2) : "vcc");
+}
+
 // NSP = number of candidate ranges a query keeps in registers: 1 (row mode), 3 (csr 1), 5 (csr 2); 0 = any csr, the
 // ranges are walked one after the other (no flattening)
 template <int MODE, int NSP, int QPT, int TPT>  // QPT = ceil(M / 512) rounds of queries, TPT = ceil(N / 512) train features per thread
@@ -88,24 +95,27 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     // ---- 1. everything this thread needs from HBM for the sort, issued back to back (indices clamped: no branches)
     float2 tp[TPT];
     bool tv[TPT];
+    uint8_t tfl[TPT];
     uint4 tdlo[TPT], tdhi[TPT];
     float2 qp[QPT];
 #pragma unroll
     for (int k = 0; k < TPT; k++) {
         const int j = tid + k * HB_THREADS;
         const int jc = max(min(j, N - 1), 0);
-        tv[k] = false;
+        tfl[k] = 1;
         tp[k] = make_float2(0.f, 0.f);
         tdlo[k] = tdhi[k] = make_uint4(0, 0, 0, 0);
-        if (N > 0) {
+        if (N > 0) {  // the flag is only LOOKED AT after every load is in flight (a compare here would wait for it)
             tp[k] = txy[jc];
-            tv[k] = (j < N) && (tf[jc] == 0);
+            tfl[k] = tf[jc];
             tdlo[k] = td[2 * jc];
             tdhi[k] = td[2 * jc + 1];
         }
     }
 #pragma unroll
     for (int k = 0; k < QPT; k++) qp[k] = qxy[min(tid + k * HB_THREADS, M - 1)];
+#pragma unroll
+    for (int k = 0; k < TPT; k++) tv[k] = (tid + k * HB_THREADS < N) & (tfl[k] == 0);
     for (int i = tid; i <= nbins; i += HB_THREADS) s_start[i] = 0;
     if (tid < HB_HIST) s_hist[tid] = 0;
     __syncthreads();
@@ -260,6 +270,29 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         if (NS > 4) o_ = ((v) >= c4) ? o4 : o_;     \
         dst = (v) + o_;                             \
     }
+    // stage A: radius test of the candidates [lo_v, hi_v) of the flattened index space, last to first, two per step (the
+    // pair shares the packed fp32 subtract / multiply / add); candidate v lands in bit v - lo_v of the mask
+#define LVT_RADIUS_BITS(mask, lo_v, hi_v)                                      \
+    {                                                                          \
+        int v_ = (hi_v)-1;                                                     \
+        for (; v_ > (lo_v); v_ -= 2) {                                         \
+            int ia_, ib_;                                                      \
+            LVT_POS_OF(ia_, v_)                                                \
+            LVT_POS_OF(ib_, v_ - 1)                                            \
+            const float2 ra_ = s_xy[ia_], rb_ = s_xy[ib_];                     \
+            const float dxa_ = ra_.x - p.x, dya_ = ra_.y - p.y;                \
+            const float dxb_ = rb_.x - p.x, dyb_ = rb_.y - p.y;                \
+            push_bit(mask, dxa_ * dxa_ + dya_ * dya_, a.r2);                   \
+            push_bit(mask, dxb_ * dxb_ + dyb_ * dyb_, a.r2);                   \
+        }                                                                      \
+        if (v_ == (lo_v)) {                                                    \
+            int ia_;                                                           \
+            LVT_POS_OF(ia_, v_)                                                \
+            const float2 ra_ = s_xy[ia_];                                      \
+            const float dxa_ = ra_.x - p.x, dya_ = ra_.y - p.y;                \
+            push_bit(mask, dxa_ * dxa_ + dya_ * dya_, a.r2);                   \
+        }                                                                      \
+    }
     // all candidates of the ranges, filter and distance in one pass (row mode, any-csr mode, over-long windows)
     auto walk_all = [&](float2 p, float fy0, float fy1, uint64_t d0, uint64_t d1, uint64_t d2, uint64_t d3, uint32_t &k1, uint32_t &k2,
                         int total, int o0, int c1, int o1, int c2, int o2, int c3, int o3, int c4, int o4) {
@@ -345,21 +378,8 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
                     } else {
                         uint32_t lo = 0, hi = 0;
                         const int t0 = min(total, 32);
-#pragma unroll 4
-                        for (int v = 0; v < t0; v++) {
-                            int it;
-                            LVT_POS_OF(it, v)
-                            const float2 r = s_xy[it];
-                            const float dx = r.x - p.x, dy = r.y - p.y;
-                            lo |= ((dx * dx + dy * dy) < a.r2) ? (1u << v) : 0u;
-                        }
-                        for (int v = 32; v < total; v++) {
-                            int it;
-                            LVT_POS_OF(it, v)
-                            const float2 r = s_xy[it];
-                            const float dx = r.x - p.x, dy = r.y - p.y;
-                            hi |= ((dx * dx + dy * dy) < a.r2) ? (1u << (v - 32)) : 0u;
-                        }
+LVT_RADIUS_BITS(lo, 0, t0)
+                        LVT_RADIUS_BITS(hi, 32, total)
                         s_q[3 * q + 2] = lo;
                         s_q[3 * q + 1] = (W1 & 0x7FFFFFu) | (hi << 23);
                         aq[j] = q;
@@ -478,21 +498,8 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
                         } else {
                             uint32_t lo = 0, hi = 0;
                             const int t0 = min(total, 32);
-#pragma unroll 4
-                            for (int v = 0; v < t0; v++) {
-                                int it;
-                                LVT_POS_OF(it, v)
-                                const float2 r = s_xy[it];
-                                const float dx = r.x - p.x, dy = r.y - p.y;
-                                lo |= ((dx * dx + dy * dy) < a.r2) ? (1u << v) : 0u;
-                            }
-                            for (int v = 32; v < total; v++) {
-                                int it;
-                                LVT_POS_OF(it, v)
-                                const float2 r = s_xy[it];
-                                const float dx = r.x - p.x, dy = r.y - p.y;
-                                hi |= ((dx * dx + dy * dy) < a.r2) ? (1u << (v - 32)) : 0u;
-                            }
+LVT_RADIUS_BITS(lo, 0, t0)
+                            LVT_RADIUS_BITS(hi, 32, total)
                             s_mask[q] = make_uint2(lo, hi);
                             aq[j] = q;
                             akey[j] = HB_HIST - 1 - min(__popc(lo) + __popc(hi), HB_HIST - 1);
@@ -578,6 +585,7 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             q = qn, w0 = nw0, w1 = nw1, p = np;
         }
     }
+#undef LVT_RADIUS_BITS
 #undef LVT_POS_OF
     if (dbg) dbg[6] = clock64();
 }

@@ -413,28 +413,43 @@ __global__ __launch_bounds__(64) void k_gate(Seq *seqs, int par, unsigned want, 
     bool ok = true;
     {
         // both conditions are polled: a stream parked on an event barrier stalls the other queues of its hardware pipe until
-        // a time slice expires (the feature stream did not advance while this stream waited for the NEXT frame's features)
-        const unsigned long long t0 = wall_clock64();  // 100 MHz
-        // (a) this frame's features: the tracking stream has no barrier of its own on them, so this wait only gives up after
-        //     2 s (a wedged feature stream; reported through lvt_amd_last_error)
+        // a time slice expires (the feature stream did not advance while this stream waited for the NEXT frame's features).
+        // After 20 ms of wall clock (100 MHz) on either, the early kernels stand down and the late ones do all the work --
+        // that happens when a tool serialises the dispatches of all queues (rocprofv3 --pmc): this kernel then holds the only
+        // dispatch slot and what it waits for cannot start.
+        const unsigned long long t0 = wall_clock64();
+        // (a) this frame's features
         while (__hip_atomic_load(&fc.feat_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
             __builtin_amdgcn_s_sleep(8);
-            if (wall_clock64() - t0 > 200000000ull) {
+            if (wall_clock64() - t0 > 2000000ull) {
                 atomicAdd(&ctl.gate_timeouts, 1 << 8);
+                ok = false;
                 break;
             }
         }
-        // (b) the previous frame's k_pnp: after 20 ms the early kernels stand down and the late ones do all the work
+        // (b) the previous frame's k_pnp
         const unsigned long long t1 = wall_clock64();
-        while (__hip_atomic_load(&ctl.pnp_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+        while (ok && __hip_atomic_load(&ctl.pnp_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
             __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t1 > 2000000ull) {
+                atomicAdd(&ctl.gate_timeouts, 1);
                 ok = false;
                 break;
             }
         }
     }
-    if (!ok) atomicAdd(&ctl.gate_timeouts, 1);
+    // claim the frame (or record that nothing will be done); if the tracking stream has cancelled it meanwhile, stand down
+    const unsigned mine = 4u * seq + (ok ? 1u : 3u);
+    unsigned cur = __hip_atomic_load(&ctl.early_state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    for (;;) {
+        if (cur >= 4u * seq + 1u) {
+            ok = false;
+            break;
+        }
+        const unsigned seen = atomicCAS(&ctl.early_state, cur, mine);
+        if (seen == cur) break;
+        cur = seen;
+    }
     ctl.gate_ok = ok ? seq : 0u;
     ctl.dbg[33] = (long long)wall_clock64();
 }
@@ -1068,25 +1083,40 @@ __global__ __launch_bounds__(RES_THREADS) void k_early_mid(Seq *seqs, int par, u
         __syncthreads();
         if (threadIdx.x == 0) ctl.early_ran_seq = seq;  // the late kernels trust early_done only with this confirmation
     }
-    if (threadIdx.x == 0) {  // the tracking stream's gate polls this: the early stream is done with this frame, whatever it did
+    if (threadIdx.x == 0) {  // the tracking stream's gate polls this: the early stream has finished what it claimed
         ctl.dbg[37] = (long long)wall_clock64();
         __threadfence();
-        atomicExch(&ctl.early_fin_seq, seq);
+        if (n_early > 0 || ctl.gate_ok == seq) atomicCAS(&ctl.early_state, 4u * seq + 1u, 4u * seq + 2u);
     }
 }
 
 // the tracking stream's counterpart of k_gate: returns when the early stream has finished this frame.  A barrier packet waiting
 // on an event would do the same, but a queue parked on a barrier stalls the other queues of its hardware pipe (measured: the
 // feature stream only advanced when the tracking stream's barrier resolved), and the event itself costs ~12 us of latency.
-__global__ __launch_bounds__(64) void k_gate_late(Seq *seqs, unsigned seq) {
+__global__ __launch_bounds__(64) void k_gate_late(Seq *seqs, int par, unsigned seq) {
     if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[38] = (long long)wall_clock64();
     Ctl &ctl = *seqs[blockIdx.z].ctl;
+    FeatCtl &fc = *seqs[blockIdx.z].fb[par].fc;
     if (threadIdx.x != 0) return;
-    const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(&ctl.early_fin_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+    unsigned long long t0 = wall_clock64();
+    for (;;) {
+        const unsigned cur = __hip_atomic_load(&ctl.early_state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        if (cur >= 4u * seq + 2u) break;  // finished, stood down or cancelled
         __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > 6000000ull) {  // 60 ms: the early stream's own gate gives up after 20
+        if (wall_clock64() - t0 > 6000000ull) {  // 60 ms: the early stream's own gate gives up after 2 x 20
             atomicAdd(&ctl.gate_timeouts, 1 << 16);
+            // not claimed yet: cancel it (an early kernel arriving later does nothing).  Claimed: its kernels are running, wait on.
+            if (cur < 4u * seq + 1u && atomicCAS(&ctl.early_state, cur, 4u * seq + 3u) == cur) break;
+            t0 = wall_clock64();
+        }
+    }
+    // this stream has no barrier of its own on the frame's features (the early stream normally vouches for them): make sure
+    t0 = wall_clock64();
+    while (__hip_atomic_load(&fc.feat_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > 200000000ull) {  // 2 s: the feature stream is wedged -- nothing valid to track on.  LOST is the
+            ctl.state = 3;                          // reference's "cannot continue" state; reported through lvt_amd_last_error
+            atomicAdd(&ctl.gate_timeouts, 1 << 24);
             break;
         }
     }

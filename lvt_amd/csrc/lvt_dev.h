@@ -76,7 +76,11 @@ struct Ctl {
     // hand-over of that work between the streams without a cross-stream event (measured: ~12 us of latency per event against ~3 us
     // for an in-stream boundary): k_pnp publishes its frame's sequence number, a one-wave gate kernel at the head of the early
     // stream polls it (with a wall-clock time-out), k_early_mid confirms that the early part really ran
-    unsigned pnp_seq, gate_ok, early_ran_seq, early_fin_seq;
+    unsigned pnp_seq, gate_ok, early_ran_seq;
+    // ownership of frame seq's early work, 4 * seq + phase, only ever increasing: 1 = the early stream has claimed it (running),
+    // 2 = it has finished with results, 3 = nothing was done (it stood down, or the tracking stream cancelled it after a
+    // time-out: an early kernel that arrives later finds the claim taken and does nothing)
+    unsigned early_state;
     unsigned track_done_seq;  // last frame whose tracking chain has finished with its feature buffer (polled by k_gate_buf)
     int gate_timeouts;
     // per-frame control, written by k_begin / later kernels

@@ -73,7 +73,13 @@ struct Context {
     Ctl *h_ctl = nullptr;          // pinned, RING x B records
     Ctl *h_ctl_dev = nullptr;      // the same memory as the device sees it (k_triangulate writes each frame's record there)
     FrameArgs *h_fargs = nullptr;  // pinned, RING x B
-    hipEvent_t ev_done[RING] = {};  // the only events: everything between the streams is handed over by polling gates (k_gate*)
+    hipEvent_t ev_done[RING] = {};  // the only events of the normal mode: the streams hand over through polling gates (k_gate*)
+    // LVT_AMD_ORDERING=events: the streams are ordered by event barriers only and the early stream is not used (the tracking chain
+    // does all the matching).  Slower (~6 300 instead of ~7 000 frames/s), but free of kernels that wait for another queue's
+    // kernels -- required under tools that serialise the dispatches of all queues (rocprofv3 --pmc): a polling gate then holds
+    // the only dispatch slot while what it waits for cannot start.
+    bool events_only = false;
+    hipEvent_t ev_feat[NPAR] = {};
     // owned staging for the host-buffer entry points, per frame parity
     uint8_t *d_packed[NPAR][2] = {}, *d_img[NPAR][2] = {};
     float *d_depth[NPAR] = {};
@@ -112,6 +118,7 @@ struct Context {
             for (auto &x : e)
                 if (x) (void)hipEventDestroy(x);
         for (auto &x : ev_done) if (x) (void)hipEventDestroy(x);
+        for (auto &x : ev_feat) if (x) (void)hipEventDestroy(x);
         if (h_ctl) (void)hipHostFree(h_ctl);
         if (h_fargs) (void)hipHostFree(h_fargs);
         if (stream && own_stream) (void)hipStreamDestroy(stream);
@@ -269,7 +276,7 @@ static void reset_state(Context *c) {  // lvt_system::reset (lvt_system.cpp:44-6
         z.out_R[0] = z.out_R[4] = z.out_R[8] = 1.0;
         z.out_status = 1;
         z.pnp_seq = (unsigned)c->enq;  // the next frame's gate waits for this value: nothing is pending
-        z.early_fin_seq = (unsigned)c->enq;
+        z.early_state = 4u * (unsigned)c->enq + 3u;
         z.track_done_seq = (unsigned)c->enq;
         HIPCHK(c, hipMemcpyAsync(c->d_ctl[s], &z, sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->h_seqs[s].map_n, 0, sizeof(int), c->stream));
@@ -297,6 +304,11 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream_e, hipStreamNonBlocking));
         c->own_stream = true;
         for (auto &e : c->ev_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        for (auto &e : c->ev_feat) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        {
+            const char *o = std::getenv("LVT_AMD_ORDERING");
+            c->events_only = o && std::strcmp(o, "events") == 0;
+        }
         c->pitch = ((prm.W + 63) / 64) * 64;
         HIPCHK(c, hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl) * B * RING, hipHostMallocDefault));
         HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_ctl_dev, c->h_ctl, 0));
@@ -422,8 +434,9 @@ static void enqueue_frame(Context *c) {
     hipStream_t sf = c->stream_f, st = c->stream;
     for (int i = 0; i < Context::PROF_SLOTS; i++) c->ev_used[i] = false;
     // ---- feature stage (stream_f): may start as soon as the tracking chain of frame enq-NPAR released this buffer
+    const bool evo = c->events_only;
     if (c->enq >= NPAR) {
-        hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, B), dim3(64), 0, sf, S, (unsigned)(c->enq + 1 - NPAR));  // polls; see k_gate_buf
+        if (!evo) hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, B), dim3(64), 0, sf, S, (unsigned)(c->enq + 1 - NPAR));  // polls; see k_gate_buf
         (void)hipStreamWaitEvent(sf, c->ev_done[(int)((c->enq - NPAR) % RING)], 0);
     }
     if (B == 1) {  // the frame's inputs travel as a kernel argument: no separate "begin" launch, no device read of pinned host memory
@@ -440,10 +453,11 @@ static void enqueue_frame(Context *c) {
     LAUNCH(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, S, par);
     LAUNCH(18, sf, k_candidates<MODE_ROW>, dim3(256, 1, B), dim3(256), 0, S, 0, par);
     hipLaunchKernelGGL(k_feat_done, dim3(B), dim3(64), 0, sf, S, par, (unsigned)(c->enq + 1));
+    if (evo) (void)hipEventRecord(c->ev_feat[par], sf);
     // ---- early stream: projection, candidate lists and greedy resolution of the map points that survived the previous frame,
     //      as soon as that frame's pose exists (its k_pnp) -- its k_staged / k_triangulate only append behind them
     const unsigned seq = (unsigned)(c->enq + 1);  // this frame's sequence number; the previous frame's is enq (0: none)
-    {
+    if (!evo) {
         hipStream_t se = c->stream_e;
         LAUNCH(1, se, k_gate, dim3(1, 1, B), dim3(64), 0, S, par, (unsigned)c->enq, seq);  // polls the previous k_pnp and this frame's features
         LAUNCH(9, se, k_early_map, dim3(256, 1, B), dim3(256), 0, S, par, seq);
@@ -452,7 +466,10 @@ static void enqueue_frame(Context *c) {
     // ---- tracking chain (stream): strictly ordered frame after frame
     // (no barrier on the features here: k_gate_late returns only after the early stream's gate has seen them complete, and
     //  every barrier / event packet costs this stream 3-4 us per frame)
-    LAUNCH(7, st, k_gate_late, dim3(1, 1, B), dim3(64), 0, S, seq);  // the early stream is done with this frame (polled, no barrier packet)
+    if (evo)
+        (void)hipStreamWaitEvent(st, c->ev_feat[par], 0);  // (the early stream never claims the frame: early_ran_seq stays behind)
+    else
+        LAUNCH(7, st, k_gate_late, dim3(1, 1, B), dim3(64), 0, S, par, seq);  // the early stream is done with this frame (polled, no barrier packet)
     LAUNCH(8, st, k_match_map, dim3(256, 1, B), dim3(256), 0, S, par, seq);
     LAUNCH(12, st, k_track_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par, seq);
     LAUNCH(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), PNP_DYN_BYTES, S, par, seq);
@@ -494,9 +511,12 @@ static void collect_oldest(Context *c) {
     for (int s = 0; s < c->B; s++)
         if (c->h_ctl[(size_t)slot * c->B + s].gate_timeouts != c->gate_timeouts_seen) {
             c->gate_timeouts_seen = c->h_ctl[(size_t)slot * c->B + s].gate_timeouts;
-            // not a wrong result (the frame was tracked without the early stream), but 20 ms were lost: the early stream's gate
-            // did not see the previous frame's k_pnp -- the two streams probably share a hardware queue
-            c->set_error("early-stream gate timed out (results unaffected; streams may share a hardware queue)");
+            if (c->gate_timeouts_seen >> 24)
+                c->set_error("feature stage did not complete within 2 s: the frame could not be tracked (state LOST); under a tool that "
+                             "serialises kernel dispatches (rocprofv3 --pmc) set LVT_AMD_ORDERING=events");
+            else  // not a wrong result (the frame was tracked without the early stream), but >= 20 ms were lost: the streams do
+                  // not run concurrently (shared hardware queue, or a tool that serialises the dispatches)
+                c->set_error("early-stream gate timed out (results unaffected; the streams do not run concurrently: LVT_AMD_ORDERING=events avoids the waits)");
         }
 }
 static void drain(Context *c) {

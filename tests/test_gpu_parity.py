@@ -158,6 +158,40 @@ def test_async_pipeline_equals_synchronous(hip_lib):
     assert b.get_state() == 2 and b.last_error() == ""
 
 
+def test_event_ordering_mode_equals_gated_pipeline(hip_lib, monkeypatch):
+    """LVT_AMD_ORDERING=events (event barriers only, no early stream, no polling gates: the mode for tools that serialise
+    kernel dispatches) tracks exactly like the default three-stream pipeline, several frames in flight"""
+    import torch
+    world, prm, sensor = make_case("kitti", 14, 0.5)
+    n = 20
+    pitch = ((world.W + 63) // 64) * 64
+    dev = torch.zeros((n, 2, world.H, pitch), dtype=torch.uint8, device="cuda")
+    for i in range(n):
+        L, R = world.render_stereo(i)
+        dev[i, 0, :, :world.W] = torch.from_numpy(L).cuda(); dev[i, 1, :, :world.W] = torch.from_numpy(R).cuda()
+    torch.cuda.synchronize()
+    a = hip_lib.LvtSystem.create(prm, 1)
+    monkeypatch.setenv("LVT_AMD_ORDERING", "events")  # read by lvt_create
+    b = hip_lib.LvtSystem.create(prm, 1)
+    monkeypatch.delenv("LVT_AMD_ORDERING")
+    out = {}
+    for name, vo in (("gated", a), ("events", b)):
+        got, inflight = [], 0
+        for i in range(n):
+            p = dev[i].data_ptr()
+            vo.track_device_async(p, p + world.H * pitch, world.H, world.W, pitch)
+            inflight += 1
+            if inflight >= 4:
+                got.append(vo.wait()); inflight -= 1
+        while inflight:
+            got.append(vo.wait()); inflight -= 1
+        out[name] = got
+    for i, ((Ra, ta), (Rb, tb)) in enumerate(zip(out["gated"], out["events"])):
+        assert np.array_equal(ta, tb) and np.array_equal(Ra, Rb), f"frame {i}"
+    assert a.counts() == b.counts()
+    assert a.last_error() == "" and b.last_error() == "" and b.get_state() == 2
+
+
 def test_lockstep_batch_equals_independent_handles(hip_lib):
     """B sequences through ONE launch chain (lvt_amd_batch_*) == B independent handles, pose for pose"""
     import torch

@@ -11,8 +11,10 @@ BENCH="python $ROOT/bench.py --steps 400 --warmup 20 --no-cpu --profile-steps 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_trace -o bench -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_batch -o bench -- python $ROOT/bench.py --steps 100 --warmup 10 --seqs-per-gpu 16 --depth 2 > $OUT/bench_batch16_under_rocprof.json 2> /dev/null
 # PMC: separate passes, counters only (no trace domains) -- FETCH_SIZE and WRITE_SIZE cannot share a pass
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -o bench -- python $ROOT/bench.py --steps 60 --warmup 5 --no-cpu --profile-steps 0 > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -o bench -- python $ROOT/bench.py --steps 60 --warmup 5 --no-cpu --profile-steps 0 > /dev/null 2>&1
+# (counter collection serialises the dispatches of all queues: the pipeline must not use its polling gates -> LVT_AMD_ORDERING=events;
+#  the timeout only guards the box)
+LVT_AMD_ORDERING=events timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -o bench -- python $ROOT/bench.py --steps 60 --warmup 5 --no-cpu --profile-steps 0 > $OUT/bench_under_pmc.json 2>&1
+LVT_AMD_ORDERING=events timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -o bench -- python $ROOT/bench.py --steps 60 --warmup 5 --no-cpu --profile-steps 0 > /dev/null 2>&1
 python - "$OUT" <<'PY'
 import csv, sys, glob, collections
 out = sys.argv[1]

@@ -1150,6 +1150,39 @@ __device__ __forceinline__ void cam_refresh(CamRegs &c, const double r[4], const
 // 1 / sqrt(s) for s > 0 in the normal range: hardware seed (v_rsq_f64, ~26 bits) + two Newton steps in fma form.
 // One dependency chain of ~10 instructions where sqrt followed by a division costs ~45 -- thread 0 runs the pose solve
 // alone, so these chains ARE its time.  The result is within 1 ulp of the correctly rounded value.
+// 1 / s from the hardware seed (v_rcp_f64) and two Newton steps: five instructions where the IEEE division expands to twelve
+__device__ __forceinline__ double rcp_nr(double s) {
+    double y = __builtin_amdgcn_rcp(s);
+#pragma unroll
+    for (int it = 0; it < 2; it++) y = __builtin_fma(__builtin_fma(-s, y, 1.0), y, y);
+    return y;
+}
+// log(a) for finite a >= 1 (the Cauchy kernel's 1 + e^2 / delta^2): a = 2^e m with m in [sqrt(1/2), sqrt(2)),
+// log m = 2 atanh(s), s = (m - 1) / (m + 1), |s| <= 0.172: ten odd terms reach 2^-56.  ~30 instructions against the ~55 of
+// the library routine (which also handles denormals, zero, negative and non-finite arguments); error < 2 ulp.
+__device__ __forceinline__ double log_ge1(double a) {
+    int e = __builtin_amdgcn_frexp_exp(a);
+    double m = __builtin_amdgcn_frexp_mant(a);  // [0.5, 1)
+    const bool lo = m < 0.70710678118654752440;
+    m = lo ? m + m : m;
+    e = lo ? e - 1 : e;
+    const double s = (m - 1.0) * rcp_nr(m + 1.0);
+    const double z = s * s;
+    double p = 1.0 / 21.0;
+    p = __builtin_fma(p, z, 1.0 / 19.0);
+    p = __builtin_fma(p, z, 1.0 / 17.0);
+    p = __builtin_fma(p, z, 1.0 / 15.0);
+    p = __builtin_fma(p, z, 1.0 / 13.0);
+    p = __builtin_fma(p, z, 1.0 / 11.0);
+    p = __builtin_fma(p, z, 1.0 / 9.0);
+    p = __builtin_fma(p, z, 1.0 / 7.0);
+    p = __builtin_fma(p, z, 1.0 / 5.0);
+    p = __builtin_fma(p, z, 1.0 / 3.0);
+    const double sz = s * z;
+    const double ed = (double)e;
+    // e ln2_hi is exact (ln2_hi has 11 trailing zero bits), the rest is added smallest first
+    return __builtin_fma(ed, 6.93147180369123816490e-01, (s + s) + __builtin_fma(ed, 1.90821492927058770002e-10, (sz + sz) * p));
+}
 __device__ __forceinline__ double rsqrt_nr(double s) {
     double y = __builtin_amdgcn_rsq(s);
 #pragma unroll
@@ -1286,7 +1319,7 @@ struct PnpShared {
 // WANT_H -- the edge's contribution to H (upper triangle, acc[0..20]) and b (acc[21..26]) linearised at the same
 // estimate (EdgeProjectP2MC::computeError / linearizeOplus / constructQuadraticForm with the Cauchy weight, A.6).
 template <bool WANT_H>
-__device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3], double fx, double fy, double dsqr, double dsqrReci,
+__device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3], double fx, double fy, double cx, double cy, double dsqr, double dsqrReci,
                                           const double *__restrict__ X, const float *__restrict__ obs, double *__restrict__ err,
                                           const int8_t *__restrict__ level, int n, double (&acc)[28]) {
 #pragma unroll
@@ -1294,28 +1327,32 @@ __device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3]
     // One edge, straight-line: an inactive slot (past the end, or an edge of level 1) runs the same instructions on a
     // clamped index with its weights selected to zero, so the PNP_ILP edges of one iteration sit in one basic block
     // and their fp64 dependency chains interleave (there is one wavefront per SIMD: nothing else hides the latency).
+    // The sweep is the one place of the path that runs at the fp64 issue rate of a CU (one wave64 instruction per 8 cycles
+    // per SIMD), so it is written for instruction count: multiply-adds are fused (contract(fast) + explicit fma
+    // accumulators) and the four divisions of an edge are reciprocal seeds with two Newton steps.  Every value is within a
+    // rounding or two of the unfused form the oracle evaluates (deviations): 400 -> 2xx instructions per edge.
     auto edge = [&](int i_raw) {
+#pragma clang fp contract(fast)
         const int i = min(i_raw, n - 1);
         const bool active = (i_raw < n) && (level[i] == 0);
         const double x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2];
-        const double *c = cam.w2i;
-        const double px = ((c[0] * x + c[1] * y) + c[2] * z) + c[3];
-        const double py = ((c[4] * x + c[5] * y) + c[6] * z) + c[7];
-        const double pz = ((c[8] * x + c[9] * y) + c[10] * z) + c[11];
-        const double e0 = px / pz - (double)obs[2 * i], e1 = py / pz - (double)obs[2 * i + 1];
+        // pixel = K * (normalised camera point): u = fx pcx / pcz + cx (w2i = K w2n, whose third row is w2n's), so the
+        // error needs the camera-frame point only -- the same one the Jacobian is built from
+        const double *w = cam.w2n;
+        const double pcx = ((w[0] * x + w[1] * y) + w[2] * z) + w[3];
+        const double pcy = ((w[4] * x + w[5] * y) + w[6] * z) + w[7];
+        const double pcz = ((w[8] * x + w[9] * y) + w[10] * z) + w[11];
+        const double ipcz = rcp_nr(pcz);
+        const double e0 = fx * (pcx * ipcz) + (cx - (double)obs[2 * i]), e1 = fy * (pcy * ipcz) + (cy - (double)obs[2 * i + 1]);
         if (active) {
             err[2 * i] = e0;
             err[2 * i + 1] = e1;
         }
         const double aux = dsqrReci * (e0 * e0 + e1 * e1) + 1.0;
-        const double chi = dsqr * log(aux);
+        const double chi = dsqr * log_ge1(aux);
         acc[27] += active ? chi : 0.0;
         if (WANT_H) {
-            const double *w = cam.w2n;
-            const double pcx = ((w[0] * x + w[1] * y) + w[2] * z) + w[3];
-            const double pcy = ((w[4] * x + w[5] * y) + w[6] * z) + w[7];
-            const double pcz = ((w[8] * x + w[9] * y) + w[10] * z) + w[11];
-            const double ipz2 = 1.0 / (pcz * pcz);
+            const double ipz2 = ipcz * ipcz;
             const double ipz2fx = active ? ipz2 * fx : 0.0, ipz2fy = active ? ipz2 * fy : 0.0;
             const double pwt[3] = {x - ct[0], y - ct[1], z - ct[2]};
             double J0[6], J1[6];
@@ -1324,19 +1361,19 @@ __device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3]
             const double a1 = (w[4] * pwt[0] + w[5] * pwt[1]) + w[6] * pwt[2];
             const double a2 = (w[8] * pwt[0] + w[9] * pwt[1]) + w[10] * pwt[2];
             {
-                const double dp0 = 0.0, dp1 = 2.0 * a2, dp2 = -2.0 * a1;  // dRdx
-                J0[3] = (pcz * dp0 - pcx * dp2) * ipz2fx;
+                const double dp1 = 2.0 * a2, dp2 = -2.0 * a1;  // dRdx (dp0 = 0)
+                J0[3] = (-pcx * dp2) * ipz2fx;
                 J1[3] = (pcz * dp1 - pcy * dp2) * ipz2fy;
             }
             {
-                const double dp0 = -2.0 * a2, dp1 = 0.0, dp2 = 2.0 * a0;  // dRdy
+                const double dp0 = -2.0 * a2, dp2 = 2.0 * a0;  // dRdy (dp1 = 0)
                 J0[4] = (pcz * dp0 - pcx * dp2) * ipz2fx;
-                J1[4] = (pcz * dp1 - pcy * dp2) * ipz2fy;
+                J1[4] = (-pcy * dp2) * ipz2fy;
             }
             {
-                const double dp0 = 2.0 * a1, dp1 = -2.0 * a0, dp2 = 0.0;  // dRdz
-                J0[5] = (pcz * dp0 - pcx * dp2) * ipz2fx;
-                J1[5] = (pcz * dp1 - pcy * dp2) * ipz2fy;
+                const double dp0 = 2.0 * a1, dp1 = -2.0 * a0;  // dRdz (dp2 = 0)
+                J0[5] = (pcz * dp0) * ipz2fx;
+                J1[5] = (pcz * dp1) * ipz2fy;
             }
 #pragma unroll
             for (int cc = 0; cc < 3; cc++) {
@@ -1344,16 +1381,17 @@ __device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3]
                 J0[cc] = (pcz * dp0 - pcx * dp2) * ipz2fx;
                 J1[cc] = (pcz * dp1 - pcy * dp2) * ipz2fy;
             }
-            const double rho1 = active ? 1.0 / aux : 0.0;
-            const double wr0 = active ? -e0 * rho1 : 0.0, wr1 = active ? -e1 * rho1 : 0.0;
+            const double rho1 = active ? rcp_nr(aux) : 0.0;
+            const double wr0 = -e0 * rho1, wr1 = -e1 * rho1;
             int k = 0;
 #pragma unroll
             for (int a = 0; a < 6; a++) {
+                const double j0r = J0[a] * rho1, j1r = J1[a] * rho1;
 #pragma unroll
-                for (int cc = a; cc < 6; cc++) acc[k++] += (J0[a] * rho1) * J0[cc] + (J1[a] * rho1) * J1[cc];
+                for (int cc = a; cc < 6; cc++, k++) acc[k] = __builtin_fma(j0r, J0[cc], __builtin_fma(j1r, J1[cc], acc[k]));
             }
 #pragma unroll
-            for (int a = 0; a < 6; a++) acc[21 + a] += J0[a] * wr0 + J1[a] * wr1;
+            for (int a = 0; a < 6; a++) acc[21 + a] = __builtin_fma(J0[a], wr0, __builtin_fma(J1[a], wr1, acc[21 + a]));
         }
     };
     if (n <= 0) return;
@@ -1410,7 +1448,7 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
             long long c0 = clock64();
             if (!have_sys) {
                 double acc[28];
-                pnp_sweep<true>(cam, ct, fx, fy, dsqr, dsqrReci, X, obs, err, level, n, acc);
+                pnp_sweep<true>(cam, ct, fx, fy, cx, cy, dsqr, dsqrReci, X, obs, err, level, n, acc);
                 block_sum<28>(acc, red, sh.sys[sh.cur]);
             }
             t_sweep += clock64() - c0;
@@ -1470,13 +1508,13 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
                 {
                     double acc[28];
                     if (speculate) {
-                        pnp_sweep<true>(cam, ct, fx, fy, dsqr, dsqrReci, X, obs, err, level, n, acc);
+                        pnp_sweep<true>(cam, ct, fx, fy, cx, cy, dsqr, dsqrReci, X, obs, err, level, n, acc);
                         const long long c2 = clock64();
                         block_sum<28>(acc, red, sh.sys[sh.cur ^ 1], bs);  // the trial's system goes to the spare slot
                         t_red += clock64() - c2;
                         tempChi = sh.sys[sh.cur ^ 1][27];
                     } else {
-                        pnp_sweep<false>(cam, ct, fx, fy, dsqr, dsqrReci, X, obs, err, level, n, acc);
+                        pnp_sweep<false>(cam, ct, fx, fy, cx, cy, dsqr, dsqrReci, X, obs, err, level, n, acc);
                         double ch[1] = {acc[27]};
                         block_sum<1>(ch, red);
                         tempChi = ch[0];

@@ -1321,7 +1321,7 @@ struct PnpShared {
 template <bool WANT_H>
 __device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3], double fx, double fy, double cx, double cy, double dsqr, double dsqrReci,
                                           const double *__restrict__ X, const float *__restrict__ obs, double *__restrict__ err,
-                                          const int8_t *__restrict__ level, int n, double (&acc)[28]) {
+                                          double *__restrict__ sink, const int8_t *__restrict__ level, int n, double (&acc)[28]) {
 #pragma unroll
     for (int k = 0; k < 28; k++) acc[k] = 0.0;
     // One edge, straight-line: an inactive slot (past the end, or an edge of level 1) runs the same instructions on a
@@ -1334,7 +1334,8 @@ __device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3]
     auto edge = [&](int i_raw) {
 #pragma clang fp contract(fast)
         const int i = min(i_raw, n - 1);
-        const bool active = (i_raw < n) && (level[i] == 0);
+        const int8_t lv = level[i];
+        const bool active = (i_raw < n) & (lv == 0);  // (no short circuit: a guarded load would split the block)
         const double x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2];
         // pixel = K * (normalised camera point): u = fx pcx / pcz + cx (w2i = K w2n, whose third row is w2n's), so the
         // error needs the camera-frame point only -- the same one the Jacobian is built from
@@ -1344,9 +1345,11 @@ __device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3]
         const double pcz = ((w[8] * x + w[9] * y) + w[10] * z) + w[11];
         const double ipcz = rcp_nr(pcz);
         const double e0 = fx * (pcx * ipcz) + (cx - (double)obs[2 * i]), e1 = fy * (pcy * ipcz) + (cy - (double)obs[2 * i + 1]);
-        if (active) {
-            err[2 * i] = e0;
-            err[2 * i + 1] = e1;
+        {  // an inactive slot stores into the sink: a conditional store would split the block and the three edges of an
+           // iteration would no longer interleave
+            double *ep = active ? err + 2 * i : sink;
+            ep[0] = e0;
+            ep[1] = e1;
         }
         const double aux = dsqrReci * (e0 * e0 + e1 * e1) + 1.0;
         const double chi = dsqr * log_ge1(aux);
@@ -1406,8 +1409,8 @@ __device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3]
 // accumulates H and b at the trial estimate: when the trial is ACCEPTED, the next solve()'s computeActiveErrors and
 // buildSystem would recompute exactly those values (same estimate, same active edges, same arithmetic), so they are
 // reused; a rejected last trial or a new pass falls back to a fresh sweep.
-__device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, const double *X, const float *obs, double *err, int8_t *level,
-                        int n, PnpShared &sh, double *red, Pose &result, int &inliers, int &solve_calls, long long *dbg = nullptr) {
+__device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, const double *X, const float *obs, double *err, double *sink,
+                        int8_t *level, int n, PnpShared &sh, double *red, Pose &result, int &inliers, int &solve_calls, long long *dbg = nullptr) {
     const int tid = threadIdx.x;
     long long t_sweep = 0, t_solve = 0, t_dec = 0, t_red = 0, t_all = clock64();
     long long bs[5] = {0, 0, 0, 0, 0};
@@ -1448,7 +1451,7 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
             long long c0 = clock64();
             if (!have_sys) {
                 double acc[28];
-                pnp_sweep<true>(cam, ct, fx, fy, cx, cy, dsqr, dsqrReci, X, obs, err, level, n, acc);
+                pnp_sweep<true>(cam, ct, fx, fy, cx, cy, dsqr, dsqrReci, X, obs, err, sink, level, n, acc);
                 block_sum<28>(acc, red, sh.sys[sh.cur]);
             }
             t_sweep += clock64() - c0;
@@ -1508,13 +1511,13 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
                 {
                     double acc[28];
                     if (speculate) {
-                        pnp_sweep<true>(cam, ct, fx, fy, cx, cy, dsqr, dsqrReci, X, obs, err, level, n, acc);
+                        pnp_sweep<true>(cam, ct, fx, fy, cx, cy, dsqr, dsqrReci, X, obs, err, sink, level, n, acc);
                         const long long c2 = clock64();
                         block_sum<28>(acc, red, sh.sys[sh.cur ^ 1], bs);  // the trial's system goes to the spare slot
                         t_red += clock64() - c2;
                         tempChi = sh.sys[sh.cur ^ 1][27];
                     } else {
-                        pnp_sweep<false>(cam, ct, fx, fy, cx, cy, dsqr, dsqrReci, X, obs, err, level, n, acc);
+                        pnp_sweep<false>(cam, ct, fx, fy, cx, cy, dsqr, dsqrReci, X, obs, err, sink, level, n, acc);
                         double ch[1] = {acc[27]};
                         block_sum<1>(ch, red);
                         tempChi = ch[0];
@@ -1599,11 +1602,11 @@ __device__ __forceinline__ void pnp_solve(const Params &prm, const Pose &prior, 
         for (int i = threadIdx.x; i < 2 * n; i += PNP_THREADS) sObs[i] = obs[i];
         for (int i = threadIdx.x; i < n; i += PNP_THREADS) sLvl[i] = level[i];
         __syncthreads();
-        pnp_run(prm, prior, sX, sObs, sErr, sLvl, n, sh, red, res, inliers, calls, dbg);
+        pnp_run(prm, prior, sX, sObs, sErr, red + 382, sLvl, n, sh, red, res, inliers, calls, dbg);  // red[382..383]: free (block_sum uses [0, 32) and [384, ...))
         for (int i = threadIdx.x; i < 2 * n; i += PNP_THREADS) err[i] = sErr[i];
         for (int i = threadIdx.x; i < n; i += PNP_THREADS) level[i] = sLvl[i];
     } else
-        pnp_run(prm, prior, X, obs, err, level, n, sh, red, res, inliers, calls, dbg);
+        pnp_run(prm, prior, X, obs, err, err + 2 * (size_t)n, level, n, sh, red, res, inliers, calls, dbg);  // the caller allocates 2 n + 2 doubles
 }
 
 __global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs, int par, unsigned seq) {

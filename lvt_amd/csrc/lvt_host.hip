@@ -375,7 +375,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
             S.pnp_X = c->dalloc<double>((size_t)NF_MAX * 3);
             S.pnp_obs = c->dalloc<float>((size_t)NF_MAX * 2);
             S.pnp_feat = c->dalloc<int>(NF_MAX);
-            S.pnp_err = c->dalloc<double>((size_t)NF_MAX * 2);
+            S.pnp_err = c->dalloc<double>((size_t)NF_MAX * 2 + 2);  // + the sink slot of inactive sweep lanes (pnp_solve)
             S.pnp_level = c->dalloc<int8_t>(NF_MAX);
             S.rcand = c->dalloc<uint32_t>((size_t)NPAR * NF_MAX * KC);  // per frame buffer
             S.rncand = c->dalloc<int>(NPAR * NF_MAX);
@@ -980,7 +980,7 @@ LVT_API int lvt_amd_pnp(const lvt_amd_params *pin, const double q_in[4], const d
     int *dInfo = nullptr;
     int rc = -1;
     const size_t nn = (size_t)std::max(n, 1);
-    if (hipMalloc((void **)&dX, nn * 24) == hipSuccess && hipMalloc((void **)&dErr, nn * 16) == hipSuccess &&
+    if (hipMalloc((void **)&dX, nn * 24) == hipSuccess && hipMalloc((void **)&dErr, nn * 16 + 16) == hipSuccess &&
         hipMalloc((void **)&dObs, nn * 8) == hipSuccess && hipMalloc((void **)&dLevel, nn) == hipSuccess &&
         hipMalloc((void **)&dOut, sizeof(Pose)) == hipSuccess && hipMalloc((void **)&dInfo, 8) == hipSuccess) {
         (void)hipMemcpy(dX, pts, (size_t)n * 24, hipMemcpyHostToDevice);

@@ -383,16 +383,20 @@ __global__ __launch_bounds__(256) void k_match_map(Seq *seqs, int par, unsigned 
 // k_gate : one wavefront per sequence at the head of the early stream; returns when the previous frame's k_pnp has published
 // its sequence number (or after 20 ms of wall clock: then the early kernels stand down and the late ones do all the work)
 // head of the feature stage: returns when the tracking chain of the frame that used this feature buffer last (NPAR frames ago)
-// is finished.  Polled: a feature stream parked on the event barrier stalls the queues that share its hardware pipe -- with
-// the barrier alone, SHORTENING the feature chain made the whole pipeline slower.  The barrier behind this kernel stays as the
-// guarantee; it is already satisfied when the gate returns.
+// is finished.  Polled: a feature stream parked on an event barrier stalls the queues that share its hardware pipe -- with
+// the barrier, SHORTENING the feature chain made the whole pipeline slower -- and the event record costs the tracking stream
+// 3-4 us per frame.  (LVT_AMD_ORDERING=events uses the barrier instead of this kernel.)
 __global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, unsigned want) {
     Ctl &ctl = *seqs[blockIdx.z].ctl;
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(&ctl.track_done_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
         __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > 6000000ull) break;
+        if (wall_clock64() - t0 > 200000000ull) {  // 2 s: the tracking stream is wedged (or a tool serialises the dispatches and
+            ctl.state = 3;                          // this kernel holds the slot): the buffer is about to be overwritten under a
+            atomicAdd(&ctl.gate_timeouts, 1 << 24);  // frame that still needs it -- LOST, reported through lvt_amd_last_error
+            break;
+        }
     }
 }
 
@@ -1878,7 +1882,7 @@ __device__ bool triangulate_pair(const Params &p, const double *cml, const doubl
     return true;
 }
 
-__global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, unsigned seq, Ctl *rec_out) {
+__global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, unsigned seq, Ctl *rec_out, unsigned *done_out) {
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     __shared__ double cml[12], cmr[12], R[9];
@@ -1995,6 +1999,9 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, unsign
         unsigned long long *dst = reinterpret_cast<unsigned long long *>(rec_out + blockIdx.z);
         for (int i = tid; i < (int)(sizeof(Ctl) / 8); i += 1024) dst[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __threadfence_system();
+        __syncthreads();
+        // the completion flag the host polls, behind the record (release at system scope)
+        if (tid == 0) __hip_atomic_store(done_out + blockIdx.z, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 

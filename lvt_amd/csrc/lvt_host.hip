@@ -72,6 +72,10 @@ struct Context {
     std::vector<Ctl *> d_ctl;
     Ctl *h_ctl = nullptr;          // pinned, RING x B records
     Ctl *h_ctl_dev = nullptr;      // the same memory as the device sees it (k_triangulate writes each frame's record there)
+    // completion flags, pinned + coherent, RING x B: k_triangulate stores the frame's sequence number behind its record and the
+    // host polls it -- an event record on the tracking stream costs that stream 3-4 us per frame (measured), and nothing else
+    // on the device needs the event in the normal mode
+    unsigned *h_done = nullptr, *h_done_dev = nullptr;
     FrameArgs *h_fargs = nullptr;  // pinned, RING x B
     hipEvent_t ev_done[RING] = {};  // the only events of the normal mode: the streams hand over through polling gates (k_gate*)
     // LVT_AMD_ORDERING=events: the streams are ordered by event barriers only and the early stream is not used (the tracking chain
@@ -120,6 +124,7 @@ struct Context {
         for (auto &x : ev_done) if (x) (void)hipEventDestroy(x);
         for (auto &x : ev_feat) if (x) (void)hipEventDestroy(x);
         if (h_ctl) (void)hipHostFree(h_ctl);
+        if (h_done) (void)hipHostFree(h_done);
         if (h_fargs) (void)hipHostFree(h_fargs);
         if (stream && own_stream) (void)hipStreamDestroy(stream);
         if (stream_f) (void)hipStreamDestroy(stream_f);
@@ -310,8 +315,11 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
             c->events_only = o && std::strcmp(o, "events") == 0;
         }
         c->pitch = ((prm.W + 63) / 64) * 64;
-        HIPCHK(c, hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl) * B * RING, hipHostMallocDefault));
+        HIPCHK(c, hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl) * B * RING, hipHostMallocCoherent));
         HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_ctl_dev, c->h_ctl, 0));
+        HIPCHK(c, hipHostMalloc((void **)&c->h_done, sizeof(unsigned) * B * RING, hipHostMallocCoherent));
+        HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_done_dev, c->h_done, 0));
+        std::memset(c->h_done, 0, sizeof(unsigned) * B * RING);
         HIPCHK(c, hipHostMalloc((void **)&c->h_fargs, sizeof(FrameArgs) * B * RING, hipHostMallocDefault));
         c->h_seqs.resize(B);
         c->d_ctl.resize(B);
@@ -436,8 +444,10 @@ static void enqueue_frame(Context *c) {
     // ---- feature stage (stream_f): may start as soon as the tracking chain of frame enq-NPAR released this buffer
     const bool evo = c->events_only;
     if (c->enq >= NPAR) {
-        if (!evo) hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, B), dim3(64), 0, sf, S, (unsigned)(c->enq + 1 - NPAR));  // polls; see k_gate_buf
-        (void)hipStreamWaitEvent(sf, c->ev_done[(int)((c->enq - NPAR) % RING)], 0);
+        if (!evo)
+            hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, B), dim3(64), 0, sf, S, (unsigned)(c->enq + 1 - NPAR));  // polls; see k_gate_buf
+        else
+            (void)hipStreamWaitEvent(sf, c->ev_done[(int)((c->enq - NPAR) % RING)], 0);
     }
     if (B == 1) {  // the frame's inputs travel as a kernel argument: no separate "begin" launch, no device read of pinned host memory
         LAUNCH(2, sf, k_score<true>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2), dim3(256), 0, S, c->h_fargs[slot], par);
@@ -475,8 +485,9 @@ static void enqueue_frame(Context *c) {
     LAUNCH(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), PNP_DYN_BYTES, S, par, seq);
     LAUNCH(16, st, k_candidates<MODE_STAGED>, dim3(64, 1, B), dim3(256), 0, S, 0, par);
     LAUNCH(17, st, k_staged, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par);
-    LAUNCH(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, S, par, seq, c->h_ctl_dev + (size_t)slot * B);  // writes the result record itself
-    (void)hipEventRecord(c->ev_done[slot], st);  // the one event of the tracking stream per frame: result record written, feature buffer free
+    LAUNCH(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, S, par, seq, c->h_ctl_dev + (size_t)slot * B,
+           c->h_done_dev + (size_t)slot * B);  // writes the result record and the completion flag itself
+    if (evo) (void)hipEventRecord(c->ev_done[slot], st);  // (events-only ordering: the feature stream's barrier needs it)
     c->enq++;
 }
 
@@ -486,7 +497,31 @@ static void collect_oldest(Context *c) {
     c->host_wait_n++;
     if (c->done >= c->enq) return;
     const int slot = (int)(c->done % RING);
-    HIPCHK(c, hipEventSynchronize(c->ev_done[slot]));
+    {   // the frame is complete when every sequence's flag carries its number (the flags follow the records: system-scope
+        // release in k_triangulate, acquire here)
+        const unsigned want = (unsigned)(c->done + 1);
+        unsigned spins = 0;
+        for (int s = 0; s < c->B; s++) {
+            volatile unsigned *f = c->h_done + (size_t)slot * c->B + s;
+            while (__atomic_load_n(f, __ATOMIC_ACQUIRE) != want) {
+                __builtin_ia32_pause();
+                if ((++spins & 0xFFFFF) == 0) {  // every ~10 ms: a dead stream must not hang the caller
+                    const hipError_t q = hipStreamQuery(c->stream);
+                    if (q != hipSuccess && q != hipErrorNotReady) {
+                        c->set_error(std::string("tracking stream: ") + hipGetErrorString(q));
+                        s = c->B;
+                        break;
+                    }
+                    if (q == hipSuccess && __atomic_load_n(f, __ATOMIC_ACQUIRE) != want) {  // stream empty but no flag: cannot happen
+                        c->set_error("tracking stream finished without a result record");
+                        s = c->B;
+                        break;
+                    }
+                }
+            }
+        }
+        if (c->prof) HIPCHK(c, hipStreamSynchronize(c->stream));  // the per-kernel timing events are read below
+    }
     c->last_slot = slot;
     c->last_par = (int)(c->done % NPAR);
     c->done++;
@@ -512,7 +547,7 @@ static void collect_oldest(Context *c) {
         if (c->h_ctl[(size_t)slot * c->B + s].gate_timeouts != c->gate_timeouts_seen) {
             c->gate_timeouts_seen = c->h_ctl[(size_t)slot * c->B + s].gate_timeouts;
             if (c->gate_timeouts_seen >> 24)
-                c->set_error("feature stage did not complete within 2 s: the frame could not be tracked (state LOST); under a tool that "
+                c->set_error("a stream waited 2 s for another one (features / buffer hand-over): the frame could not be tracked (state LOST); under a tool that "
                              "serialises kernel dispatches (rocprofv3 --pmc) set LVT_AMD_ORDERING=events");
             else  // not a wrong result (the frame was tracked without the early stream), but >= 20 ms were lost: the streams do
                   // not run concurrently (shared hardware queue, or a tool that serialises the dispatches)

@@ -1673,11 +1673,8 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp_standalone(Params prm, Pose
 // as it is below 250 (every matched point is promoted while the map is small), so promotions and their
 // destinations come from two prefix sums.
 // =================================================================================================
-__global__ __launch_bounds__(RES_THREADS) void k_staged(Seq *seqs, int par) {
-    Seq &S = seqs[blockIdx.z];
-    Ctl &ctl = *S.ctl;
-    if (!ctl.active || ctl.lost_now) return;
-    RESOLVE_LDS_DECL
+// (runs at the head of k_triangulate: both are single-workgroup stages of 1024 threads, a kernel boundary between them bought nothing)
+__device__ __forceinline__ void staged_body(Seq &S, Ctl &ctl, int par, ResolveLds &L, uint32_t *r_tab) {
     const int tid = threadIdx.x;
     if (!ctl.first_frame && S.prm.staged_th > 0) {
         const Feat &T = S.fb[par].feat[0];
@@ -1889,11 +1886,15 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, unsign
     __shared__ Pose cam;
     __shared__ int scan[32];
     const int tid = threadIdx.x;
+    RESOLVE_LDS_DECL
+    if (ctl.active && !ctl.lost_now) {  // update_staged_map_points + the triangulation policy (block-uniform condition)
+        staged_body(S, ctl, par, L, r_tab);
+        __syncthreads();  // need_tri / dont_stage / map_n / staged_n / the marks: written above, read below by other threads
+    }
     const bool run = ctl.active && !ctl.lost_now && ctl.need_tri;  // block-uniform
     if (run) {
     int n_pairs = 0;
     if (S.prm.sensor == 1) {  // row_match (lvt_image_features_handler.cpp:299-326): greedy resolution of the lists k_candidates<ROW> built
-        RESOLVE_LDS_DECL
         resolve_body<MODE_ROW>(S, ctl, 0, par, L, r_tab);
         __syncthreads();
         n_pairs = L.misc[2];

@@ -408,7 +408,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
 static const char *kProfNames[Context::PROF_SLOTS] = {
     "k_feat_begin", "k_gate [early stream: waits for the previous k_pnp]", "k_score", "k_cells(pass0)", "k_cells(retry)", "k_gather", "k_brief", "k_gate_late [waits for the early stream]",
     "k_match_map(begin + new points)", "k_early_map [early stream]", "k_early_mid [early stream]", "", "k_track_mid(resolve+pass2+bookkeep+cull)", "k_pnp(+project staged)", "",
-    "", "k_candidates(staged)", "k_staged", "k_candidates(row) [feature stream]", "", "k_triangulate(row resolve+triangulate+finalize)", "",
+    "", "k_candidates(staged)", "k_staged", "k_candidates(row) [feature stream]", "", "k_triangulate(staged update+row resolve+triangulate+finalize)", "",
     "", ""};
 
 #define LAUNCH(slot, st, kern, grid, block, lds, ...)                              \
@@ -484,7 +484,6 @@ static void enqueue_frame(Context *c) {
     LAUNCH(12, st, k_track_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par, seq);
     LAUNCH(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), PNP_DYN_BYTES, S, par, seq);
     LAUNCH(16, st, k_candidates<MODE_STAGED>, dim3(64, 1, B), dim3(256), 0, S, 0, par);
-    LAUNCH(17, st, k_staged, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par);
     LAUNCH(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, S, par, seq, c->h_ctl_dev + (size_t)slot * B,
            c->h_done_dev + (size_t)slot * B);  // writes the result record and the completion flag itself
     if (evo) (void)hipEventRecord(c->ev_done[slot], st);  // (events-only ordering: the feature stream's barrier needs it)

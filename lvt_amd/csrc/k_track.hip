@@ -1331,10 +1331,12 @@ __device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3]
     // One edge, straight-line: an inactive slot (past the end, or an edge of level 1) runs the same instructions on a
     // clamped index with its weights selected to zero, so the PNP_ILP edges of one iteration sit in one basic block
     // and their fp64 dependency chains interleave (there is one wavefront per SIMD: nothing else hides the latency).
-    // The sweep is the one place of the path that runs at the fp64 issue rate of a CU (one wave64 instruction per 8 cycles
-    // per SIMD), so it is written for instruction count: multiply-adds are fused (contract(fast) + explicit fma
-    // accumulators) and the four divisions of an edge are reciprocal seeds with two Newton steps.  Every value is within a
-    // rounding or two of the unfused form the oracle evaluates (deviations): 400 -> 2xx instructions per edge.
+    // The sweep runs at the fp64 issue rate of a CU -- measured: v_mul_f64 / v_add_f64 issue in 4 cycles per wave64, v_fma_f64
+    // in 8, and the loop's cycle count is the sum of those whatever the order (a stage-interleaved version of the three edges
+    // ran at exactly the same speed) -- so it is written for operation count: the four IEEE divisions of an edge are
+    // reciprocal seeds with two Newton steps, the pixel error is formed from the camera-frame point the Jacobian needs anyway,
+    // the logarithm is specialised to arguments >= 1 (400 -> 223 instructions per edge).  Multiply-adds are fused where that
+    // saves an instruction slot.  Every value is within a rounding or two of the form the oracle evaluates (deviations).
     auto edge = [&](int i_raw) {
 #pragma clang fp contract(fast)
         const int i = min(i_raw, n - 1);

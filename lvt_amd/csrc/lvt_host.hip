@@ -46,13 +46,29 @@ __global__ void k_feat_begin(Seq *seqs, const FrameArgs *fa, int par) {
     feat_begin(seqs[blockIdx.x], fa[blockIdx.x], par);
 }
 
-// tightly packed host-layout image (stride == cols) -> pitched device image
-__global__ __launch_bounds__(256) void k_repitch(const uint8_t *src, uint8_t *dst, int W, int H, int pitch) {
-    const size_t n = (size_t)W * H;
-    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
-        const int y = (int)(i / W), x = (int)(i - (size_t)y * W);
-        dst[(size_t)y * pitch + x] = src[i];
+// tightly packed host-layout images (stride == cols) -> pitched device images.
+// Host images enter through a pinned staging buffer that this kernel reads over PCIe (16 B per lane) and writes as the
+// pitched planes k_score wants: blockIdx.y = image.  One launch replaces two pageable H2D copies + two re-pitch kernels
+// (0.32 ms per stereo pair -> see DESIGN.md section 6).
+__global__ __launch_bounds__(256) void k_stage_in(const uint8_t *src0, const uint8_t *src1, uint8_t *dst0, uint8_t *dst1, int W, int H, int pitch) {
+    const uint8_t *src = blockIdx.y ? src1 : src0;
+    uint8_t *dst = blockIdx.y ? dst1 : dst0;
+    const size_t n = (size_t)W * H, nv = (n + 15) / 16;  // the staging buffer is padded to 16 B
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (size_t)gridDim.x * blockDim.x) {
+        const uint4 q = reinterpret_cast<const uint4 *>(src)[v];
+        const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+        size_t i = v * 16;
+        int y = (int)(i / (size_t)W), x = (int)(i - (size_t)y * W);
+#pragma unroll
+        for (int k = 0; k < 16; k++, i++) {
+            if (i < n) dst[(size_t)y * pitch + x] = (uint8_t)(wds[k >> 2] >> (8 * (k & 3)));
+            if (++x == W) x = 0, y++;
+        }
     }
+}
+// plain 16-B copy of the (unpitched) depth image out of the staging buffer
+__global__ __launch_bounds__(256) void k_stage_copy(const uint4 *src, uint4 *dst, size_t nv) {
+    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (size_t)gridDim.x * blockDim.x) dst[v] = src[v];
 }
 
 struct Context {
@@ -85,7 +101,9 @@ struct Context {
     bool events_only = false;
     hipEvent_t ev_feat[NPAR] = {};
     // owned staging for the host-buffer entry points, per frame parity
-    uint8_t *d_packed[NPAR][2] = {}, *d_img[NPAR][2] = {};
+    uint8_t *d_img[NPAR][2] = {};
+    uint8_t *h_stage[NPAR] = {}, *h_stage_dev[NPAR] = {};  // pinned staging of host images (lvt_track): [left | right or depth]
+    size_t stage_img = 0;                                    // bytes reserved per 8-bit image (16-B multiple)
     float *d_depth[NPAR] = {};
     float *d_ext[NPAR][2] = {};
     int pitch = 0;
@@ -123,6 +141,7 @@ struct Context {
                 if (x) (void)hipEventDestroy(x);
         for (auto &x : ev_done) if (x) (void)hipEventDestroy(x);
         for (auto &x : ev_feat) if (x) (void)hipEventDestroy(x);
+        for (auto &x : h_stage) if (x) (void)hipHostFree(x);
         if (h_ctl) (void)hipHostFree(h_ctl);
         if (h_done) (void)hipHostFree(h_done);
         if (h_fargs) (void)hipHostFree(h_fargs);
@@ -356,12 +375,11 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
                     alloc_feat(c, FB.feat[e]);
                     if (s == 0) {
                         c->d_ext[par][e] = c->dalloc<float>((size_t)EXT_MAX * 2);
-                        c->d_packed[par][e] = c->dalloc<uint8_t>((size_t)prm.W * prm.H + 64);
                         c->d_img[par][e] = c->dalloc<uint8_t>(plane + 64);
                     }
                     FB.ext_xy[e] = c->d_ext[par][e];
                 }
-                if (s == 0 && sensor == 2) c->d_depth[par] = c->dalloc<float>((size_t)prm.W * prm.H);
+                if (s == 0 && sensor == 2) c->d_depth[par] = c->dalloc<float>((size_t)prm.W * prm.H + 4);
             }
             for (int k = 0; k < 2; k++) {
                 alloc_points(c, S.map[k], MAP_MAX);
@@ -785,10 +803,19 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
     drain(c);
     const int par = (int)(c->enq % NPAR);
     hipStream_t sf = c->stream_f;
-    // one contiguous H2D copy per image, then a device-side re-pitch (a strided 2-D copy of pageable memory is slow)
     const size_t nbytes = (size_t)n_rows * n_cols;
-    HIPCHK(c, hipMemcpyAsync(c->d_packed[par][0], left, nbytes, hipMemcpyHostToDevice, sf));
-    hipLaunchKernelGGL(k_repitch, dim3(512), dim3(256), 0, sf, c->d_packed[par][0], c->d_img[par][0], n_cols, n_rows, c->pitch);
+    if (!c->h_stage[par]) {  // first host-buffer call: [image | image] or [image | depth f32], each part padded to 16 B
+        c->stage_img = (nbytes + 15) & ~(size_t)15;
+        const size_t second_bytes = rgbd ? ((sizeof(float) * nbytes + 15) & ~(size_t)15) : c->stage_img;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_stage[par], c->stage_img + second_bytes, hipHostMallocDefault));
+        HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_stage_dev[par], c->h_stage[par], 0));
+    }
+    // the borrowed buffers are copied into pinned memory by the CPU (they may be reused the moment this call returns) and the
+    // GPU pulls them from there
+    std::memcpy(c->h_stage[par], left, nbytes);
+    std::memcpy(c->h_stage[par] + c->stage_img, second, rgbd ? sizeof(float) * nbytes : nbytes);
+    const uint8_t *s0 = c->h_stage_dev[par], *s1 = c->h_stage_dev[par] + c->stage_img;
+    hipLaunchKernelGGL(k_stage_in, dim3(128, rgbd ? 1 : 2), dim3(256), 0, sf, s0, s1, c->d_img[par][0], c->d_img[par][1], n_cols, n_rows, c->pitch);
     FrameArgs &f = c->h_fargs[(size_t)(c->enq % RING) * c->B];
     f.img[0] = c->d_img[par][0];
     f.img[1] = c->d_img[par][1];
@@ -796,12 +823,10 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
     f.depth = nullptr;
     f.depth_pitch = 0;
     if (rgbd) {
-        HIPCHK(c, hipMemcpyAsync(c->d_depth[par], second, sizeof(float) * nbytes, hipMemcpyHostToDevice, sf));
+        const size_t nv = (sizeof(float) * nbytes + 15) / 16;
+        hipLaunchKernelGGL(k_stage_copy, dim3(256), dim3(256), 0, sf, reinterpret_cast<const uint4 *>(s1), reinterpret_cast<uint4 *>(c->d_depth[par]), nv);
         f.depth = c->d_depth[par];
         f.depth_pitch = n_cols;
-    } else {
-        HIPCHK(c, hipMemcpyAsync(c->d_packed[par][1], second, nbytes, hipMemcpyHostToDevice, sf));
-        hipLaunchKernelGGL(k_repitch, dim3(512), dim3(256), 0, sf, c->d_packed[par][1], c->d_img[par][1], n_cols, n_rows, c->pitch);
     }
     f.ext_corners = ext;
     f.n_ext[0] = ncl;

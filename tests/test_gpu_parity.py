@@ -192,6 +192,50 @@ def test_event_ordering_mode_equals_gated_pipeline(hip_lib, monkeypatch):
     assert a.last_error() == "" and b.last_error() == "" and b.get_state() == 2
 
 
+_FEWER_QUEUES = r"""
+import json, os, sys
+sys.path.insert(0, os.path.join(sys.argv[1], "tests")); sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, lvt_amd
+from parity_util import make_case
+world, prm, sensor = make_case("kitti", 16, 0.5)
+n = 16
+pitch = ((world.W + 63) // 64) * 64
+dev = torch.zeros((n, 2, world.H, pitch), dtype=torch.uint8, device="cuda")
+for i in range(n):
+    L, R = world.render_stereo(i)
+    dev[i, 0, :, :world.W] = torch.from_numpy(L).cuda(); dev[i, 1, :, :world.W] = torch.from_numpy(R).cuda()
+torch.cuda.synchronize()
+vo = lvt_amd.LvtSystem.create(prm, 1)
+out, inflight = [], 0
+for i in range(n):
+    p = dev[i].data_ptr()
+    vo.track_device_async(p, p + world.H * pitch, world.H, world.W, pitch); inflight += 1
+    if inflight >= 4:
+        out.append(vo.wait()); inflight -= 1
+while inflight:
+    out.append(vo.wait()); inflight -= 1
+print("RESULT " + json.dumps({"t": [t.tolist() for _, t in out], "R": [R.tolist() for R, _ in out], "err": vo.last_error(), "state": vo.get_state()}))
+"""
+
+
+@pytest.mark.parametrize("queues", ["1", "2"])
+def test_fewer_hardware_queues_than_streams(hip_lib, queues):
+    """Every polling gate waits only for work the host enqueued BEFORE it, so multiplexing the three streams onto fewer
+    hardware queues (GPU_MAX_HW_QUEUES=1 / 2: in-order execution of interleaved streams) can neither deadlock nor time
+    out, and the poses are those of the default configuration"""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = {}
+    for name, env_extra in (("default", {}), ("fewer", {"GPU_MAX_HW_QUEUES": queues})):
+        env = dict(os.environ); env.update(env_extra)
+        r = subprocess.run([sys.executable, "-c", _FEWER_QUEUES, root], env=env, capture_output=True, text=True, timeout=240)
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+        assert r.returncode == 0 and line, r.stderr[-2000:]
+        runs[name] = json.loads(line[-1][7:])
+    assert runs["fewer"]["err"] == "" and runs["fewer"]["state"] == 2
+    assert runs["fewer"]["t"] == runs["default"]["t"] and runs["fewer"]["R"] == runs["default"]["R"]
+
+
 def test_lockstep_batch_equals_independent_handles(hip_lib):
     """B sequences through ONE launch chain (lvt_amd_batch_*) == B independent handles, pose for pose"""
     import torch

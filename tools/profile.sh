@@ -26,6 +26,17 @@ def stats(src, dst):
     csv.writer(open(dst, "w")).writerows(keep)
     print("==", dst); [print(",".join(r[:4])) for r in keep]
 stats("/tmp/prof_trace", out + "/kernel_stats_single.csv")
+# per-dispatch durations of the matcher (bench.py: 80 warm-up launches while the clocks ramp up, then 35 timed ones)
+f = glob.glob("/tmp/prof_trace/**/*kernel_trace.csv", recursive=True)
+if f:
+    rd = csv.DictReader(open(f[0]))
+    d = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rd if "k_hamming_batched" in r["Kernel_Name"]]
+    d.sort()
+    w = csv.writer(open(out + "/hamming_dispatch_durations.csv", "w")); w.writerow(["dispatch", "duration_ns"])
+    for i, (_, ns) in enumerate(d): w.writerow([i, ns])
+    if len(d) >= 35:
+        last = [ns for _, ns in d[-35:]]
+        print("== matcher dispatches:", len(d), "mean of all %.1f us, of the last 35 (the timed ones) %.1f us" % (sum(ns for _, ns in d) / len(d) / 1e3, sum(last) / 35e3))
 stats("/tmp/prof_batch", out + "/kernel_stats_batch16.csv")
 def pmc(src, name, dst):
     f = glob.glob(src + "/**/*counter_collection.csv", recursive=True)

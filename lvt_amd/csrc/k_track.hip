@@ -1,16 +1,19 @@
 // k_track.hip -- map<->frame matching, motion-only BA, map maintenance, stereo triangulation (gfx950).
 //
-//   k_project    : frame prologue (motion model, state machine) + is_point_visible / projection of the map points
-//                                                                               (lvt_system.cpp:157-197, lvt_local_map.cpp:62-82,152)
-//   k_candidates : masked Hamming candidate lists, one wavefront per query      (lvt_image_features_struct.cpp:68-148)
-//   k_track_mid  : the order-dependent accept/mark pass of find_matches (pass 1, rare pass 2), counters / ages / PnP
-//                  input, LOST decision, clean_untracked_points
-//                                      (lvt_local_map.cpp:146-224,393-413, lvt_system.cpp:267-274)
-//   k_pnp        : g2o Levenberg-Marquardt, 2 passes x optimize(5), on device; projects the staged points with the result
+//   T = tracking stream (the frame period), E = early stream (frame t+1's share of find_matches, behind k_pnp(t)), F = feature stream
+//   k_candidates<ROW|STAGED> : masked Hamming candidate lists, one wavefront per query   (lvt_image_features_struct.cpp:68-148)
+//   k_gate / k_gate_buf / k_gate_late / k_feat_done : the polling hand-over between the streams
+//   E k_early_map  : projection + candidate lists of the map points that survived the previous frame's clean-up
+//   E k_early_mid  : their greedy accept/mark scan (the first part of find_matches' storage-order scan)
+//   T k_match_map  : frame prologue (motion model, state machine; lvt_system.cpp:157-197) + is_point_visible / projection
+//                    and candidate lists of the points appended since                        (lvt_local_map.cpp:62-82,152)
+//   T k_track_mid  : the rest of the accept/mark scan of find_matches (pass 1, rare pass 2), counters / ages / PnP input,
+//                    LOST decision, clean_untracked_points   (lvt_local_map.cpp:146-224,393-413, lvt_system.cpp:267-274)
+//   T k_pnp        : g2o Levenberg-Marquardt, 2 passes x optimize(5), on device; projects the staged points with the result
 //                                                                               (lvt_pnp_solver.cpp:60-128)
-//   k_staged     : update_staged_map_points + triangulation policy              (lvt_local_map.cpp:355-391, lvt_system.cpp:308-334)
-//   k_triangulate: row_match accept/mark pass, linear-LS triangulation + gates, append to map / staged, frame epilogue
-//                                      (handler.cpp:302-323, lvt_local_map.cpp:231-353, lvt_system.cpp:185-193)
+//   T k_triangulate: update_staged_map_points + triangulation policy (lvt_local_map.cpp:355-391, lvt_system.cpp:308-334),
+//                    row_match accept/mark scan, linear-LS triangulation + gates, append to map / staged, frame epilogue,
+//                    result record              (handler.cpp:302-323, lvt_local_map.cpp:231-353, lvt_system.cpp:185-193)
 //
 // The Hamming distance evaluation is parallel (k_candidates); only the accept/mark scan is sequential,
 // and it walks pre-sorted candidate lists so it touches a few words per query.
@@ -22,10 +25,8 @@ namespace lvt {
 enum : int { MODE_MAP = 0, MODE_STAGED = 1, MODE_ROW = 2 };
 
 // =================================================================================================
-// k_project : frame prologue (the head of lvt_system::track, lvt_system.cpp:157-167,196-197) + is_point_visible /
-// projection of the map points.  Every block derives the per-frame facts it needs (active / first frame / predicted
-// pose) from the PERSISTENT part of Ctl, which nobody writes during this kernel; block 0 additionally publishes
-// them for the rest of the chain.  The motion model's next state goes to a shadow (mm_next) committed by k_track_mid.
+// frame prologue (the head of lvt_system::track, lvt_system.cpp:157-167,196-197), evaluated by k_match_map.  The motion
+// model's next state goes to a shadow (mm_next) committed by k_track_mid.
 // =================================================================================================
 __device__ __forceinline__ void frame_prologue(Seq &S, Ctl &c, int par, const Pose &predicted, const double mm_next[14], bool active,
                                                bool first) {
@@ -55,42 +56,6 @@ __device__ __forceinline__ void frame_prologue(Seq &S, Ctl &c, int par, const Po
         c.predicted = predicted;
         for (int k = 0; k < 14; k++) c.mm_next[k] = mm_next[k];
         c.mm_pending = 1;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_project(Seq *seqs, int par) {
-    Seq &S = seqs[blockIdx.z];
-    Ctl &ctl = *S.ctl;
-    const int state = ctl.state;  // persistent; not written by this kernel
-    const bool active = (state != 3), first = (state == 1);
-    __shared__ double w2c[12];
-    if (threadIdx.x == 0) {
-        Pose predicted;
-        double mmn[14];
-        if (active && !first) {
-            motion_predict(ctl, ctl.last_pose, predicted, mmn);
-            world_to_camera(predicted, w2c);
-        }
-        if (blockIdx.x == 0) frame_prologue(S, ctl, par, predicted, mmn, active, first);
-    }
-    if (!active || first) return;
-    __syncthreads();
-    const int M = *S.map_n;
-    MapSoA &P = S.map[*S.map_cur];
-    if (blockIdx.x == 0 && threadIdx.x == 0) ctl.counts[C_MAP_SIZE_AT_MATCH] = M;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < M; i += gridDim.x * blockDim.x) {
-        const double X[3] = {P.pos[3 * i], P.pos[3 * i + 1], P.pos[3 * i + 2]};
-        double u, v;
-        if (is_point_visible(X, w2c, S.prm, u, v)) {
-            S.proj[2 * i] = (float)u;
-            S.proj[2 * i + 1] = (float)v;
-            S.vis[i] = 1;
-            S.match[i] = -1;
-        } else {
-            S.vis[i] = 0;
-            P.counter[i] += 1;  // lvt_local_map.cpp:154
-            S.match[i] = -2;
-        }
     }
 }
 
@@ -377,7 +342,7 @@ __global__ __launch_bounds__(256) void k_match_map(Seq *seqs, int par, unsigned 
 }
 
 // k_early_map : projection + candidate lists of the map points that survived the PREVIOUS frame's clean-up, launched on its own
-// stream as soon as that frame's pose is known (after its k_pnp) -- k_staged / k_triangulate of that frame only append points
+// stream as soon as that frame's pose is known (after its k_pnp) -- k_triangulate of that frame (staged update, triangulation) only appends points
 // behind early_done.  Nothing of the per-frame state is published here (k_match_map does that when the previous frame is
 // complete); the prediction is recomputed from the same persistent inputs, so both kernels see the same pose.
 // k_gate : one wavefront per sequence at the head of the early stream; returns when the previous frame's k_pnp has published
@@ -822,7 +787,7 @@ __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int pa
             const int lq = tid + u * RES_THREADS, q = b0 + lq;
             if (lq >= used) continue;
             if (MODE == MODE_MAP) {
-                if (ncand[q] > 0) S.match[q] = acc[u];  // invisible / candidate-less points keep -2 / -1 (k_project)
+                if (ncand[q] > 0) S.match[q] = acc[u];  // invisible / candidate-less points keep -2 / -1 (k_match_map / k_early_map)
             } else if (acc[u] >= 0) {
                 const int slot = accepted + (u ? tot0 + ex1 : ex0);
                 S.pair_l[slot] = q;
@@ -864,17 +829,6 @@ __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int pa
             L.misc[2] = accepted;
         }
     }
-}
-
-template <int MODE>
-__global__ __launch_bounds__(RES_THREADS) void k_resolve(Seq *seqs, int pass2, int par) {
-    Seq &S = seqs[blockIdx.z];
-    Ctl &ctl = *S.ctl;
-    if (!ctl.active) return;
-    if (MODE == MODE_MAP && ctl.first_frame) return;
-    if (MODE == MODE_ROW && (!ctl.need_tri || ctl.lost_now || S.prm.sensor != 1)) return;
-    RESOLVE_LDS_DECL
-    resolve_body<MODE>(S, ctl, pass2, par, L, r_tab);
 }
 
 // =================================================================================================
@@ -1037,7 +991,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_track_mid(Seq *seqs, int par, u
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     if (!ctl.active) return;
-    if (threadIdx.x == 0 && ctl.mm_pending) {  // commit the motion model state shadowed by k_project
+    if (threadIdx.x == 0 && ctl.mm_pending) {  // commit the motion model state shadowed by the prologue
         for (int k = 0; k < 4; k++) ctl.mm_last_q[k] = ctl.mm_next[k], ctl.mm_ang_vel[k] = ctl.mm_next[4 + k];
         for (int k = 0; k < 3; k++) ctl.mm_last_p[k] = ctl.mm_next[8 + k], ctl.mm_lin_vel[k] = ctl.mm_next[11 + k];
         ctl.mm_pending = 0;
@@ -1669,7 +1623,7 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp_standalone(Params prm, Pose
 }
 
 // =================================================================================================
-// k_staged : update_staged_map_points (lvt_local_map.cpp:355-391) then the triangulation policy.
+// staged_body : update_staged_map_points (lvt_local_map.cpp:355-391) then the triangulation policy.
 // Matching = the same block-wide fixpoint; the promotion rule "counter == staged_threshold || map_size < 250"
 // depends on the RUNNING map size, which has the closed form  map_n0 + #(matched staged points before i)  as long
 // as it is below 250 (every matched point is promoted while the map is small), so promotions and their
@@ -2012,7 +1966,5 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, unsign
 template __global__ void k_candidates<MODE_MAP>(Seq *, int, int);
 template __global__ void k_candidates<MODE_STAGED>(Seq *, int, int);
 template __global__ void k_candidates<MODE_ROW>(Seq *, int, int);
-template __global__ void k_resolve<MODE_MAP>(Seq *, int, int);
-template __global__ void k_resolve<MODE_ROW>(Seq *, int, int);
 
 }  // namespace lvt

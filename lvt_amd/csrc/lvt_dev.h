@@ -66,7 +66,7 @@ struct Ctl {
     int last_matches[3];
     Pose last_pose;
     double mm_last_q[4], mm_ang_vel[4], mm_last_p[3], mm_lin_vel[3];
-    double mm_next[14];  // motion-model state after this frame's prediction; committed by k_track_mid (k_project only reads mm_*)
+    double mm_next[14];  // motion-model state after this frame's prediction; committed by k_track_mid (the prologue only reads mm_*)
     int mm_pending;
     // cross-frame overlap: k_pnp of frame t publishes the size of the map after clean_untracked_points; the projection,
     // candidate lists and greedy resolution of THOSE points for frame t+1 run on a third stream while frame t still

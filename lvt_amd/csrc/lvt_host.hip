@@ -426,7 +426,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
 static const char *kProfNames[Context::PROF_SLOTS] = {
     "k_feat_begin", "k_gate [early stream: waits for the previous k_pnp]", "k_score", "k_cells(pass0)", "k_cells(retry)", "k_gather", "k_brief", "k_gate_late [waits for the early stream]",
     "k_match_map(begin + new points)", "k_early_map [early stream]", "k_early_mid [early stream]", "", "k_track_mid(resolve+pass2+bookkeep+cull)", "k_pnp(+project staged)", "",
-    "", "k_candidates(staged)", "k_staged", "k_candidates(row) [feature stream]", "", "k_triangulate(staged update+row resolve+triangulate+finalize)", "",
+    "", "k_candidates(staged)", "", "k_candidates(row) [feature stream]", "", "k_triangulate(staged update+row resolve+triangulate+finalize)", "",
     "", ""};
 
 #define LAUNCH(slot, st, kern, grid, block, lds, ...)                              \
@@ -483,7 +483,7 @@ static void enqueue_frame(Context *c) {
     hipLaunchKernelGGL(k_feat_done, dim3(B), dim3(64), 0, sf, S, par, (unsigned)(c->enq + 1));
     if (evo) (void)hipEventRecord(c->ev_feat[par], sf);
     // ---- early stream: projection, candidate lists and greedy resolution of the map points that survived the previous frame,
-    //      as soon as that frame's pose exists (its k_pnp) -- its k_staged / k_triangulate only append behind them
+    //      as soon as that frame's pose exists (its k_pnp) -- its k_triangulate only appends behind them
     const unsigned seq = (unsigned)(c->enq + 1);  // this frame's sequence number; the previous frame's is enq (0: none)
     if (!evo) {
         hipStream_t se = c->stream_e;

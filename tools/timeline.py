@@ -36,20 +36,22 @@ while inflight:
 tl = np.array(tl[40:], dtype=np.float64) / 100.0  # us
 names = ["gate start", "gate end", "early_map start", "-", "early_mid start", "early_mid end", "gate_late start", "-", "match_map start", "-",
          "track_mid start", "-", "pnp start", "pnp end", "triangulate end", "feat_done"]
-# The early-stream kernels of frame k+1 run during the tail of frame k: if their stamps are in record k (copied after
-# k_triangulate(k)) they belong to frame k+1, otherwise they are one frame older.  Decide per record by comparing with pnp end.
-def med(x): return float(np.median(x))
+# The early-stream kernels of frame k+1 run during the tail of frame k, so each of their stamps is either already in record k
+# (copied at the end of k_triangulate(k): then it is later than that record's pnp end) or still in record k+1 (then it is earlier
+# than THAT record's pnp end, i.e. not yet overwritten by frame k+2's early kernels).
+def med(x): return float(np.nanmedian(x))
 r, nx = tl[:-1], tl[1:]
-same = r[:, 1] > r[:, 13]           # gate end after this record's pnp end -> early stamps of frame k+1 are in record k
-print("records whose early-stream stamps belong to the NEXT frame: %d of %d" % (int(same.sum()), len(same)))
-r, nx = r[same], nx[same]
+def early(j):
+    v = np.where(r[:, j] > r[:, 13], r[:, j], np.where(nx[:, j] < nx[:, 13], nx[:, j], np.nan))
+    return np.where(v > r[:, 13] - 1000.0, v, np.nan)  # (a stamp older than 1 ms before pnp end is a stale one)
+g0, g1, em0, ed0, ed1 = early(0), early(1), early(2), early(4), early(5)
 print("frame period (pnp start to pnp start)            : %6.1f us" % med(np.diff(tl[:, 12])))
-print("pnp(k) end -> gate(k+1) end                       : %6.1f us   (gate started %.1f us before pnp(k) end)" % (med(r[:, 1] - r[:, 13]), med(r[:, 13] - r[:, 0])))
-print("gate end -> early_map start                       : %6.1f us" % med(r[:, 2] - r[:, 1]))
-print("early_map start -> early_mid start                : %6.1f us" % med(r[:, 4] - r[:, 2]))
-print("early_mid start -> early_mid end                  : %6.1f us" % med(r[:, 5] - r[:, 4]))
+print("pnp(k) end -> gate(k+1) end                       : %6.1f us   (gate started %.1f us before pnp(k) end)" % (med(g1 - r[:, 13]), med(r[:, 13] - g0)))
+print("gate end -> early_map start                       : %6.1f us" % med(em0 - g1))
+print("early_map start -> early_mid start                : %6.1f us" % med(ed0 - em0))
+print("early_mid start -> early_mid end                  : %6.1f us" % med(ed1 - ed0))
 print("pnp(k) end -> triangulate(k) end                  : %6.1f us" % med(r[:, 14] - r[:, 13]))
-print("early_mid(k+1) end -> match_map(k+1) start        : %6.1f us   (gate_late started %.1f us before early_mid end)" % (med(nx[:, 8] - r[:, 5]), med(r[:, 5] - nx[:, 6])))
+print("early_mid(k+1) end -> match_map(k+1) start        : %6.1f us   (gate_late started %.1f us after early_mid end)" % (med(nx[:, 8] - ed1), med(nx[:, 6] - ed1)))
 print("triangulate(k) end -> match_map(k+1) start        : %6.1f us" % med(nx[:, 8] - r[:, 14]))
 print("match_map start -> track_mid start -> pnp start   : %6.1f + %.1f us" % (med(nx[:, 10] - nx[:, 8]), med(nx[:, 12] - nx[:, 10])))
 print("pnp start -> pnp end                              : %6.1f us" % med(nx[:, 13] - nx[:, 12]))

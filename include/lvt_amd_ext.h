@@ -139,6 +139,26 @@ LVT_API int lvt_amd_rectify_device(lvt_amd_rectifier r, const void *d_src, int s
 LVT_API int lvt_amd_rectify(lvt_amd_rectifier r, const unsigned char *src, unsigned char *dst);
 LVT_API int lvt_amd_rectifier_get_maps(lvt_amd_rectifier r, float *map1, float *map2);
 
+/* ---- odometry accumulator: the consumer right behind the path -----------------------------------------------
+ * What the reference's ROS node does with every pose (lvt/src/lvt_ros.cpp:86-92 constructor, :215-311 on_stereo_image), without
+ * ROS: poses are re-expressed in an x-forward / z-up frame (rot_fix = Rz(-pi/2) Rx(-pi/2)), the frame-to-frame delta is moved
+ * into the base frame (base_to_sensor, identity by default) and accumulated into base_to_odom; a frame with an older time stamp
+ * is ignored; when tracking is LOST the odometry resets the tracker (lvt_system::reset) and -- if reset_pose_on_lost -- its own
+ * accumulated pose, and publishes nothing for that frame.
+ *   pose_out  : position x y z + orientation qx qy qz qw of the base in the odom frame
+ *   twist_out : linear xyz, angular xyz (delta / time since the previous published frame; zeros for the first frame or dt = 0)
+ * lvt_amd_odometry_push_pose is the pure host-side step (a pose that was tracked elsewhere; `h` may be NULL at creation);
+ * lvt_amd_odometry_update = lvt_track + lvt_get_status + that step (+ the reset on LOST).
+ * Return value of both: 1 = published, 0 = nothing published (LOST and reset, or stale time stamp), -1 = bad arguments. */
+typedef void *lvt_amd_odometry;
+LVT_API lvt_amd_odometry lvt_amd_odometry_create(lvt_handle h, const double base_to_sensor[12] /* 3x4 row-major or NULL */, int reset_pose_on_lost);
+LVT_API void lvt_amd_odometry_destroy(lvt_amd_odometry o);
+LVT_API void lvt_amd_odometry_reset(lvt_amd_odometry o); /* the node's reset_vo service: tracker reset, deltas restart (pose kept) */
+LVT_API int lvt_amd_odometry_push_pose(lvt_amd_odometry o, const double R[3][3], const double t[3], int status, double stamp_sec,
+                                       double pose_out[7], double twist_out[6]);
+LVT_API int lvt_amd_odometry_update(lvt_amd_odometry o, unsigned char *left, unsigned char *right, int n_rows, int n_cols, double stamp_sec,
+                                    double pose_out[7], double twist_out[6]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -29,7 +29,8 @@ ABI_SYMBOLS = [
     "lvt_amd_get_matches", "lvt_amd_get_row_matches", "lvt_amd_get_map", "lvt_amd_get_staged",
     "lvt_amd_get_pose", "lvt_amd_get_predicted_pose", "lvt_amd_get_plane", "lvt_amd_pnp",
     "lvt_amd_hamming_match_batched", "lvt_amd_hamming_match_batched_n", "lvt_amd_rectifier_create", "lvt_amd_rectifier_destroy",
-    "lvt_amd_rectify_device", "lvt_amd_rectify", "lvt_amd_rectifier_get_maps", "lvt_amd_profile_enable", "lvt_amd_profile_read", "lvt_amd_get_debug", "lvt_amd_get_timeline",
+    "lvt_amd_rectify_device", "lvt_amd_rectify", "lvt_amd_rectifier_get_maps",
+    "lvt_amd_odometry_create", "lvt_amd_odometry_destroy", "lvt_amd_odometry_reset", "lvt_amd_odometry_push_pose", "lvt_amd_odometry_update", "lvt_amd_profile_enable", "lvt_amd_profile_read", "lvt_amd_get_debug", "lvt_amd_get_timeline",
     "lvt_amd_batch_create", "lvt_amd_batch_size", "lvt_amd_batch_track_device_async", "lvt_amd_batch_wait",
     "lvt_amd_batch_get_counts",
 ]
@@ -100,6 +101,14 @@ def load_library():
     L.lvt_amd_rectify_device.argtypes = [vp, vp, C.c_int, vp, C.c_int, vp]
     L.lvt_amd_rectify.argtypes = [vp, vp, vp]
     L.lvt_amd_rectifier_get_maps.argtypes = [vp, vp, vp]
+    L.lvt_amd_odometry_create.restype = vp
+    L.lvt_amd_odometry_create.argtypes = [vp, vp, C.c_int]
+    L.lvt_amd_odometry_destroy.argtypes = [vp]
+    L.lvt_amd_odometry_reset.argtypes = [vp]
+    L.lvt_amd_odometry_push_pose.restype = C.c_int
+    L.lvt_amd_odometry_push_pose.argtypes = [vp, vp, vp, C.c_int, C.c_double, vp, vp]
+    L.lvt_amd_odometry_update.restype = C.c_int
+    L.lvt_amd_odometry_update.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_double, vp, vp]
     L.lvt_amd_hamming_match_batched_n.restype = C.c_float
     L.lvt_amd_hamming_match_batched_n.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp, C.c_int]
     L.lvt_amd_profile_enable.argtypes = [vp, C.c_int]
@@ -392,6 +401,49 @@ class Rectifier:
     def close(self):
         if self._h:
             load_library().lvt_amd_rectifier_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:  # noqa: BLE001
+            pass
+
+
+class Odometry:
+    """What the reference's ROS node does with every pose (lvt_ros.cpp:215-311), without ROS: x-forward / z-up re-expression,
+    base-frame deltas accumulated into base_to_odom, stale frames ignored, tracker (+ optionally pose) reset on LOST."""
+
+    def __init__(self, system=None, base_to_sensor=None, reset_pose_on_lost=True):
+        L = load_library()
+        self._sys = system
+        b = None if base_to_sensor is None else np.ascontiguousarray(base_to_sensor, dtype=np.float64).reshape(12)
+        self._h = L.lvt_amd_odometry_create(system._h if system is not None else None, None if b is None else _p(b), 1 if reset_pose_on_lost else 0)
+        if not self._h:
+            raise RuntimeError("lvt_amd_odometry_create returned NULL")
+
+    def _call(self, fn, *args):
+        pose = np.zeros(7); twist = np.zeros(6)
+        rc = fn(self._h, *args, _p(pose), _p(twist))
+        if rc < 0:
+            raise ValueError("bad arguments")
+        return (pose, twist) if rc == 1 else None
+
+    def push_pose(self, R, t, status, stamp):
+        """returns (pose[x y z qx qy qz qw], twist[6]) or None (LOST -> reset, or a stale time stamp)"""
+        Rm = np.ascontiguousarray(R, dtype=np.float64).reshape(3, 3); tv = np.ascontiguousarray(t, dtype=np.float64).reshape(3)
+        return self._call(load_library().lvt_amd_odometry_push_pose, _p(Rm), _p(tv), int(status), float(stamp))
+
+    def update(self, left, right, stamp):
+        a, b = _u8(left), _u8(right)
+        return self._call(load_library().lvt_amd_odometry_update, _p(a), _p(b), a.shape[0], a.shape[1], float(stamp))
+
+    def reset(self):
+        load_library().lvt_amd_odometry_reset(self._h)
+
+    def close(self):
+        if self._h:
+            load_library().lvt_amd_odometry_destroy(self._h)
             self._h = None
 
     def __del__(self):

@@ -398,6 +398,7 @@ __global__ __launch_bounds__(64) void k_gate(Seq *seqs, int par, unsigned want, 
         }
         // (b) the previous frame's k_pnp
         const unsigned long long t1 = wall_clock64();
+        ctl.dbg[35] = (long long)t1;  // (tools/timeline.py: when this frame's features were seen)
         while (ok && __hip_atomic_load(&ctl.pnp_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
             __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t1 > 2000000ull) {

@@ -16,6 +16,7 @@
 #include "k_track.hip"
 #include "k_hamming.hip"
 #include "k_rectify.hip"
+#include "lvt_odometry.h"
 
 #include <cmath>
 #include <chrono>
@@ -1235,6 +1236,55 @@ LVT_API int lvt_amd_rectifier_get_maps(lvt_amd_rectifier h, float *map1, float *
     if (!r || !map1 || !map2) return -1;
     const size_t n = (size_t)r->w * r->h * 4;
     return (hipMemcpy(map1, r->d_map1, n, hipMemcpyDeviceToHost) == hipSuccess && hipMemcpy(map2, r->d_map2, n, hipMemcpyDeviceToHost) == hipSuccess) ? 0 : -1;
+}
+
+// ---- odometry accumulator (lvt_ros.cpp:215-311 without ROS) -----------------------------------------------
+LVT_API lvt_amd_odometry lvt_amd_odometry_create(lvt_handle h, const double base_to_sensor[12], int reset_pose_on_lost) {
+    try {
+        Odometry *o = new Odometry();
+        o->tracker = h;
+        o->reset_pose_on_lost = reset_pose_on_lost != 0;
+        if (base_to_sensor)
+            for (int i = 0; i < 3; i++) {
+                for (int j = 0; j < 3; j++) o->base_to_sensor.R[3 * i + j] = base_to_sensor[4 * i + j];
+                o->base_to_sensor.p[i] = base_to_sensor[4 * i + 3];
+            }
+        return o;
+    } catch (...) {
+        return nullptr;
+    }
+}
+LVT_API void lvt_amd_odometry_destroy(lvt_amd_odometry o) { delete static_cast<Odometry *>(o); }
+LVT_API void lvt_amd_odometry_reset(lvt_amd_odometry op) {  // reset_vo (lvt_ros.cpp:184-198)
+    Odometry *o = static_cast<Odometry *>(op);
+    if (!o) return;
+    if (o->tracker) lvt_amd_reset(o->tracker);
+    o->restart_deltas();
+    o->base_to_odom = Rigid();
+}
+LVT_API int lvt_amd_odometry_push_pose(lvt_amd_odometry op, const double R[3][3], const double t[3], int status, double stamp_sec,
+                                       double pose_out[7], double twist_out[6]) {
+    Odometry *o = static_cast<Odometry *>(op);
+    if (!o || !R || !t) return -1;
+    if (o->have_time && o->last_time > stamp_sec) return 0;  // older than the last published frame: ignored (lvt_ros.cpp:224-229)
+    if (status == 3) {  // LOST: reset the tracker, optionally the accumulated pose; nothing is published (lvt_ros.cpp:241-253)
+        if (o->tracker) lvt_amd_reset(o->tracker);
+        if (o->reset_pose_on_lost) {
+            o->base_to_odom = Rigid();
+            o->restart_deltas();
+        }
+        return 0;
+    }
+    return o->push(&R[0][0], t, stamp_sec, pose_out, twist_out) ? 1 : 0;
+}
+LVT_API int lvt_amd_odometry_update(lvt_amd_odometry op, unsigned char *left, unsigned char *right, int n_rows, int n_cols, double stamp_sec,
+                                    double pose_out[7], double twist_out[6]) {
+    Odometry *o = static_cast<Odometry *>(op);
+    if (!o || !o->tracker || !left || !right) return -1;
+    if (o->have_time && o->last_time > stamp_sec) return 0;  // (checked before tracking, like the node)
+    double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, t[3] = {0, 0, 0};
+    lvt_track(o->tracker, left, right, n_rows, n_cols, R, t);
+    return lvt_amd_odometry_push_pose(op, R, t, lvt_get_status(o->tracker), stamp_sec, pose_out, twist_out);
 }
 
 }  // extern "C"

@@ -263,3 +263,28 @@ def test_lockstep_batch_equals_independent_handles(hip_lib):
     for s in range(B):
         assert batch.counts(s) == singles[s].counts()
     assert batch.last_error() == ""
+
+
+def test_odometry_update_follows_the_tracker(hip_lib):
+    """lvt_amd_odometry_update = lvt_track + the node's pose handling: compared with the same arithmetic applied to the poses
+    of a second, plain handle; a LOST frame (40-frame jump with a tiny search radius) resets the tracker and publishes nothing"""
+    from test_odometry import NodeModel, _same_rotation
+    world, prm, sensor = make_case("kitti", 21, 0.5)
+    a = hip_lib.LvtSystem.create(prm, 1); b = hip_lib.LvtSystem.create(prm, 1)
+    od, ref = hip_lib.Odometry(a, None, True), NodeModel(None, True)
+    frames = list(range(10)) + list(range(60, 66))
+    published = 0
+    for k, i in enumerate(frames):
+        L, R = world.render_stereo(i)
+        got = od.update(L, R, 0.1 * k)
+        Rb, tb = b.track(L, R)
+        st = b.get_state()
+        exp = ref.push(Rb, tb, st, 0.1 * k)
+        if st == 3:
+            b.reset()
+        assert (got is None) == (exp is None), f"frame {i}"
+        if got is not None:
+            published += 1
+            assert np.allclose(got[0][:3], exp[0][:3], atol=1e-9) and _same_rotation(got[0][3:], exp[0][3:])
+            assert np.allclose(got[1], exp[1], atol=1e-6)
+    assert published >= 10 and a.last_error() == ""

@@ -44,7 +44,13 @@ r, nx = tl[:-1], tl[1:]
 def early(j):
     v = np.where(r[:, j] > r[:, 13], r[:, j], np.where(nx[:, j] < nx[:, 13], nx[:, j], np.nan))
     return np.where(v > r[:, 13] - 1000.0, v, np.nan)  # (a stamp older than 1 ms before pnp end is a stale one)
-g0, g1, em0, ed0, ed1 = early(0), early(1), early(2), early(4), early(5)
+g0, g1, em0, ed0, ed1 = r[:, 0], early(1), early(2), early(4), early(5)  # (the gate itself starts long before pnp(k) ends)
+def pct(x):
+    x = x[~np.isnan(x)]
+    return "p10 %.1f  p50 %.1f  p90 %.1f" % tuple(np.percentile(x, [10, 50, 90])) if len(x) else "-"
+print("early path of frame k+1 after pnp(k) end, us: gate end [%s]  early_mid end [%s]" % (pct(g1 - r[:, 13]), pct(ed1 - r[:, 13])))
+print("features of frame k+1 seen by its gate, us after pnp(k) end (negative = the feature stream was ahead): [%s]" % pct(np.where(r[:, 3] > r[:, 13] - 1000.0, r[:, 3], nx[:, 3]) - r[:, 13]))
+print("tracking path: triangulate(k) end [%s]  gate_late(k+1) start [%s]  match_map(k+1) start [%s]" % (pct(r[:, 14] - r[:, 13]), pct(nx[:, 6] - r[:, 13]), pct(nx[:, 8] - r[:, 13])))
 print("frame period (pnp start to pnp start)            : %6.1f us" % med(np.diff(tl[:, 12])))
 print("pnp(k) end -> gate(k+1) end                       : %6.1f us   (gate started %.1f us before pnp(k) end)" % (med(g1 - r[:, 13]), med(r[:, 13] - g0)))
 print("gate end -> early_map start                       : %6.1f us" % med(em0 - g1))

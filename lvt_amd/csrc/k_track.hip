@@ -359,7 +359,7 @@ __global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, unsigned want) {
         __builtin_amdgcn_s_sleep(8);
         if (wall_clock64() - t0 > 200000000ull) {  // 2 s: the tracking stream is wedged (or a tool serialises the dispatches and
             ctl.state = 3;                          // this kernel holds the slot): the buffer is about to be overwritten under a
-            atomicAdd(&ctl.gate_timeouts, 1 << 24);  // frame that still needs it -- LOST, reported through lvt_amd_last_error
+            atomicAdd(&ctl.gate_fatal, 1);  // frame that still needs it -- LOST, reported through lvt_amd_last_error
             break;
         }
     }
@@ -391,7 +391,7 @@ __global__ __launch_bounds__(64) void k_gate(Seq *seqs, int par, unsigned want, 
         while (__hip_atomic_load(&fc.feat_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
             __builtin_amdgcn_s_sleep(8);
             if (wall_clock64() - t0 > 2000000ull) {
-                atomicAdd(&ctl.gate_timeouts, 1 << 8);
+                atomicAdd(&ctl.gate_timeouts, 1);
                 ok = false;
                 break;
             }
@@ -1063,7 +1063,7 @@ __global__ __launch_bounds__(64) void k_gate_late(Seq *seqs, int par, unsigned s
         if (cur >= 4u * seq + 2u) break;  // finished, stood down or cancelled
         __builtin_amdgcn_s_sleep(8);
         if (wall_clock64() - t0 > 6000000ull) {  // 60 ms: the early stream's own gate gives up after 2 x 20
-            atomicAdd(&ctl.gate_timeouts, 1 << 16);
+            atomicAdd(&ctl.gate_timeouts, 1);
             // not claimed yet: cancel it (an early kernel arriving later does nothing).  Claimed: its kernels are running, wait on.
             if (cur < 4u * seq + 1u && atomicCAS(&ctl.early_state, cur, 4u * seq + 3u) == cur) break;
             t0 = wall_clock64();
@@ -1075,7 +1075,7 @@ __global__ __launch_bounds__(64) void k_gate_late(Seq *seqs, int par, unsigned s
         __builtin_amdgcn_s_sleep(8);
         if (wall_clock64() - t0 > 200000000ull) {  // 2 s: the feature stream is wedged -- nothing valid to track on.  LOST is the
             ctl.state = 3;                          // reference's "cannot continue" state; reported through lvt_amd_last_error
-            atomicAdd(&ctl.gate_timeouts, 1 << 24);
+            atomicAdd(&ctl.gate_fatal, 1);
             break;
         }
     }

@@ -82,7 +82,8 @@ struct Ctl {
     // time-out: an early kernel that arrives later finds the claim taken and does nothing)
     unsigned early_state;
     unsigned track_done_seq;  // last frame whose tracking chain has finished with its feature buffer (polled by k_gate_buf)
-    int gate_timeouts;
+    int gate_timeouts;  // a gate gave up waiting and its stream stood down / cancelled (results unaffected)
+    int gate_fatal;     // a stream waited 2 s for data it cannot do without: the sequence was set LOST
     // per-frame control, written by k_begin / later kernels
     int active;         // 0: LOST at frame start -> every kernel exits
     int first_frame;    // state was NOT_INITIALIZED at frame start

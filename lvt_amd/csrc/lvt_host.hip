@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void k_stage_copy(const uint4 *src, uint4 *dst
 struct Context {
     double host_enq_us = 0, host_wait_us = 0;  // host time spent enqueueing / blocking (LVT_AMD_HOST_TIMING=1 prints it at destroy)
     long host_enq_n = 0, host_wait_n = 0;
-    int gate_timeouts_seen = 0;
+    int gate_timeouts_seen = 0, gate_fatal_seen = 0;
     int B = 1;                 // sequences advanced in lock-step by one launch chain
     int sensor = 1;
     Params prm{};
@@ -288,7 +288,7 @@ static void drain(Context *c);
 
 static void reset_state(Context *c) {  // lvt_system::reset (lvt_system.cpp:44-68)
     drain(c);
-    c->gate_timeouts_seen = 0;
+    c->gate_timeouts_seen = 0, c->gate_fatal_seen = 0;
     for (int s = 0; s < c->B; s++) {
         Ctl z;
         std::memset(&z, 0, sizeof(z));
@@ -562,15 +562,19 @@ static void collect_oldest(Context *c) {
             c->set_error(buf);
         }
     for (int s = 0; s < c->B; s++)
-        if (c->h_ctl[(size_t)slot * c->B + s].gate_timeouts != c->gate_timeouts_seen) {
-            c->gate_timeouts_seen = c->h_ctl[(size_t)slot * c->B + s].gate_timeouts;
-            if (c->gate_timeouts_seen >> 24)
-                c->set_error("a stream waited 2 s for another one (features / buffer hand-over): the frame could not be tracked (state LOST); under a tool that "
-                             "serialises kernel dispatches (rocprofv3 --pmc) set LVT_AMD_ORDERING=events");
-            else  // not a wrong result (the frame was tracked without the early stream), but >= 20 ms were lost: the streams do
-                  // not run concurrently (shared hardware queue, or a tool that serialises the dispatches)
-                c->set_error("early-stream gate timed out (results unaffected; the streams do not run concurrently: LVT_AMD_ORDERING=events avoids the waits)");
+    {
+        const Ctl &r = c->h_ctl[(size_t)slot * c->B + s];
+        if (r.gate_fatal != c->gate_fatal_seen) {
+            c->gate_fatal_seen = r.gate_fatal;
+            c->set_error("a stream waited 2 s for another one (features / buffer hand-over): the frame could not be tracked (state LOST); under a tool that "
+                         "serialises kernel dispatches (rocprofv3 --pmc) set LVT_AMD_ORDERING=events");
+        } else if (r.gate_timeouts != c->gate_timeouts_seen) {
+            c->gate_timeouts_seen = r.gate_timeouts;
+            // not a wrong result (the frame was tracked without the early stream), but >= 20 ms were lost: the streams do
+            // not run concurrently (shared hardware queue, or a tool that serialises the dispatches)
+            c->set_error("early-stream gate timed out (results unaffected; the streams do not run concurrently: LVT_AMD_ORDERING=events avoids the waits)");
         }
+    }
 }
 static void drain(Context *c) {
     while (c->done < c->enq) collect_oldest(c);

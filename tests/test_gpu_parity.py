@@ -288,3 +288,50 @@ def test_odometry_update_follows_the_tracker(hip_lib):
             assert np.allclose(got[0][:3], exp[0][:3], atol=1e-9) and _same_rotation(got[0][3:], exp[0][3:])
             assert np.allclose(got[1], exp[1], atol=1e-6)
     assert published >= 10 and a.last_error() == ""
+
+
+_UNDER_PMC = r"""
+import json, os, sys
+sys.path.insert(0, os.path.join(sys.argv[1], "tests")); sys.path.insert(0, sys.argv[1])
+import numpy as np, lvt_amd
+from parity_util import make_case
+world, prm, sensor = make_case("kitti", 16, 0.5)
+vo = lvt_amd.LvtSystem.create(prm, 1)
+out = []
+for i in range(4):
+    L, R = world.render_stereo(i)
+    Rm, t = vo.track(L, R)
+    out.append({"t": t.tolist(), "state": vo.get_state(), "err": vo.last_error()})
+print("RESULT " + json.dumps(out))
+"""
+
+
+def test_serialised_dispatches_are_reported_not_silently_wrong(hip_lib, tmp_path):
+    """rocprofv3 --pmc serialises the dispatches of all queues: a polling gate then holds the only dispatch slot.  In the default
+    ordering the library must say so (error string; LOST when a frame's features never arrived) -- and every pose it does return
+    must be the right one; with LVT_AMD_ORDERING=events the same run is clean."""
+    import json, os, shutil, subprocess, sys
+    if not shutil.which("rocprofv3"):
+        pytest.skip("rocprofv3 not on PATH")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    runs = {}
+    for name, extra in (("plain", None), ("pmc_default", {}), ("pmc_events", {"LVT_AMD_ORDERING": "events"})):
+        env = dict(os.environ); env["TMPDIR"] = str(tmp_path)
+        cmd = [sys.executable, "-c", _UNDER_PMC, root]
+        if extra is not None:
+            env.update(extra)
+            cmd = ["rocprofv3", "--pmc", "SQ_WAVES", "-d", str(tmp_path / name), "-o", "x", "--"] + cmd
+        r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=300, cwd=str(tmp_path))
+        line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
+        assert line, (name, r.stdout[-1500:], r.stderr[-1500:])
+        runs[name] = json.loads(line[-1][7:])
+    ref = runs["plain"]
+    assert all(f["state"] == 2 and f["err"] == "" for f in ref)
+    assert [f["t"] for f in runs["pmc_events"]] == [f["t"] for f in ref] and all(f["err"] == "" for f in runs["pmc_events"])
+    saw_report = False
+    for f, g in zip(runs["pmc_default"], ref):
+        saw_report |= f["err"] != ""
+        assert f["state"] == 3 or f["t"] == g["t"]      # a returned TRACKING pose is the right pose
+        if f["state"] == 3:
+            assert f["err"] != ""                        # LOST is never silent
+    assert saw_report

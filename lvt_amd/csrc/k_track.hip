@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2, int pa
 // k_match_map : frame prologue + projection of the map points + their candidate lists (find_matches pass 1).  Every block
 // derives the per-frame facts it needs (active / first frame / predicted pose) from the PERSISTENT part of Ctl, which
 // nobody writes during this kernel; block 0 additionally publishes them for the rest of the chain.
-__global__ __launch_bounds__(256) void k_match_map(Seq *seqs, int par, unsigned seq) {
+__global__ __launch_bounds__(256) void k_match_map(Seq *seqs, int par, seq_t seq) {
     if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[40] = (long long)wall_clock64();
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
@@ -351,7 +351,7 @@ __global__ __launch_bounds__(256) void k_match_map(Seq *seqs, int par, unsigned 
 // is finished.  Polled: a feature stream parked on an event barrier stalls the queues that share its hardware pipe -- with
 // the barrier, SHORTENING the feature chain made the whole pipeline slower -- and the event record costs the tracking stream
 // 3-4 us per frame.  (LVT_AMD_ORDERING=events uses the barrier instead of this kernel.)
-__global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, unsigned want) {
+__global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, seq_t want) {
     Ctl &ctl = *seqs[blockIdx.z].ctl;
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = wall_clock64();
@@ -366,7 +366,7 @@ __global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, unsigned want) {
 }
 
 // last kernel of the feature stage (one thread per sequence): this buffer's features are complete
-__global__ void k_feat_done(Seq *seqs, int par, unsigned seq) {
+__global__ void k_feat_done(Seq *seqs, int par, seq_t seq) {
     if (threadIdx.x != 0) return;
     FeatCtl &fc = *seqs[blockIdx.x].fb[par].fc;
     seqs[blockIdx.x].ctl->dbg[47] = (long long)wall_clock64();  // (written from the feature stream: the frame it belongs to may differ)
@@ -374,7 +374,7 @@ __global__ void k_feat_done(Seq *seqs, int par, unsigned seq) {
     atomicExch(&fc.feat_seq, seq);
 }
 
-__global__ __launch_bounds__(64) void k_gate(Seq *seqs, int par, unsigned want, unsigned seq) {
+__global__ __launch_bounds__(64) void k_gate(Seq *seqs, int par, seq_t want, seq_t seq) {
     if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[32] = (long long)wall_clock64();
     Ctl &ctl = *seqs[blockIdx.z].ctl;
     FeatCtl &fc = *seqs[blockIdx.z].fb[par].fc;
@@ -409,22 +409,22 @@ __global__ __launch_bounds__(64) void k_gate(Seq *seqs, int par, unsigned want, 
         }
     }
     // claim the frame (or record that nothing will be done); if the tracking stream has cancelled it meanwhile, stand down
-    const unsigned mine = 4u * seq + (ok ? 1u : 3u);
-    unsigned cur = __hip_atomic_load(&ctl.early_state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    const seq_t mine = 4u * seq + (ok ? 1u : 3u);
+    seq_t cur = __hip_atomic_load(&ctl.early_state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
     for (;;) {
         if (cur >= 4u * seq + 1u) {
             ok = false;
             break;
         }
-        const unsigned seen = atomicCAS(&ctl.early_state, cur, mine);
+        const seq_t seen = atomicCAS(&ctl.early_state, cur, mine);
         if (seen == cur) break;
         cur = seen;
     }
-    ctl.gate_ok = ok ? seq : 0u;
+    ctl.gate_ok = ok ? seq : (seq_t)0;
     ctl.dbg[33] = (long long)wall_clock64();
 }
 
-__global__ __launch_bounds__(256) void k_early_map(Seq *seqs, int par, unsigned seq) {
+__global__ __launch_bounds__(256) void k_early_map(Seq *seqs, int par, seq_t seq) {
     if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[34] = (long long)wall_clock64();
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
@@ -987,7 +987,7 @@ __device__ __forceinline__ bool bookkeep_cull_small(Seq &S, Ctl &ctl, int par, i
 // =================================================================================================
 // k_track_mid : find_matches pass 1 [+ second pass, if pass 1 found < 50] + bookkeeping + LOST decision + cull
 // =================================================================================================
-__global__ __launch_bounds__(RES_THREADS) void k_track_mid(Seq *seqs, int par, unsigned seq) {
+__global__ __launch_bounds__(RES_THREADS) void k_track_mid(Seq *seqs, int par, seq_t seq) {
     if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[42] = (long long)wall_clock64();
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
@@ -1031,7 +1031,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_track_mid(Seq *seqs, int par, u
 
 // k_early_mid : the greedy resolution of find_matches for the map points [0, early_done) (storage order: their decisions do
 // not depend on the points the previous frame is still appending), on the early stream behind k_early_map
-__global__ __launch_bounds__(RES_THREADS) void k_early_mid(Seq *seqs, int par, unsigned seq) {
+__global__ __launch_bounds__(RES_THREADS) void k_early_mid(Seq *seqs, int par, seq_t seq) {
     if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[36] = (long long)wall_clock64();
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
@@ -1052,14 +1052,14 @@ __global__ __launch_bounds__(RES_THREADS) void k_early_mid(Seq *seqs, int par, u
 // the tracking stream's counterpart of k_gate: returns when the early stream has finished this frame.  A barrier packet waiting
 // on an event would do the same, but a queue parked on a barrier stalls the other queues of its hardware pipe (measured: the
 // feature stream only advanced when the tracking stream's barrier resolved), and the event itself costs ~12 us of latency.
-__global__ __launch_bounds__(64) void k_gate_late(Seq *seqs, int par, unsigned seq) {
+__global__ __launch_bounds__(64) void k_gate_late(Seq *seqs, int par, seq_t seq) {
     if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[38] = (long long)wall_clock64();
     Ctl &ctl = *seqs[blockIdx.z].ctl;
     FeatCtl &fc = *seqs[blockIdx.z].fb[par].fc;
     if (threadIdx.x != 0) return;
     unsigned long long t0 = wall_clock64();
     for (;;) {
-        const unsigned cur = __hip_atomic_load(&ctl.early_state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+        const seq_t cur = __hip_atomic_load(&ctl.early_state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
         if (cur >= 4u * seq + 2u) break;  // finished, stood down or cancelled
         __builtin_amdgcn_s_sleep(8);
         if (wall_clock64() - t0 > 6000000ull) {  // 60 ms: the early stream's own gate gives up after 2 x 20
@@ -1570,7 +1570,7 @@ __device__ __forceinline__ void pnp_solve(const Params &prm, const Pose &prior, 
         pnp_run(prm, prior, X, obs, err, err + 2 * (size_t)n, level, n, sh, red, res, inliers, calls, dbg);  // the caller allocates 2 n + 2 doubles
 }
 
-__global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs, int par, unsigned seq) {
+__global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs, int par, seq_t seq) {
     if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[44] = (long long)wall_clock64();
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
@@ -1836,7 +1836,7 @@ __device__ bool triangulate_pair(const Params &p, const double *cml, const doubl
     return true;
 }
 
-__global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, unsigned seq, Ctl *rec_out, unsigned *done_out) {
+__global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, seq_t seq, Ctl *rec_out, seq_t *done_out) {
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     __shared__ double cml[12], cmr[12], R[9];

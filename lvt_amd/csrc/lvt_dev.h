@@ -59,6 +59,9 @@ struct Pose {  // camera-to-world, quaternion (w,x,y,z) + position
     double p[3];
 };
 
+// frame sequence numbers handed between the streams: 64 bits (32 would wrap after 149 h at 8 000 frames/s, 4 * seq after 37 h)
+using seq_t = unsigned long long;
+
 struct Ctl {
     // persistent state (lvt_system.h:96-108, lvt_motion_model.h:43-46)
     int state;          // 1 NOT_INITIALIZED, 2 TRACKING, 3 LOST
@@ -76,12 +79,12 @@ struct Ctl {
     // hand-over of that work between the streams without a cross-stream event (measured: ~12 us of latency per event against ~3 us
     // for an in-stream boundary): k_pnp publishes its frame's sequence number, a one-wave gate kernel at the head of the early
     // stream polls it (with a wall-clock time-out), k_early_mid confirms that the early part really ran
-    unsigned pnp_seq, gate_ok, early_ran_seq;
+    seq_t pnp_seq, gate_ok, early_ran_seq;
     // ownership of frame seq's early work, 4 * seq + phase, only ever increasing: 1 = the early stream has claimed it (running),
     // 2 = it has finished with results, 3 = nothing was done (it stood down, or the tracking stream cancelled it after a
     // time-out: an early kernel that arrives later finds the claim taken and does nothing)
-    unsigned early_state;
-    unsigned track_done_seq;  // last frame whose tracking chain has finished with its feature buffer (polled by k_gate_buf)
+    seq_t early_state;
+    seq_t track_done_seq;  // last frame whose tracking chain has finished with its feature buffer (polled by k_gate_buf)
     int gate_timeouts;  // a gate gave up waiting and its stream stood down / cancelled (results unaffected)
     int gate_fatal;     // a stream waited 2 s for data it cannot do without: the sequence was set LOST
     // per-frame control, written by k_begin / later kernels
@@ -114,7 +117,7 @@ struct FeatCtl {        // per-frame state of the FEATURE stage (own stream, dou
     int n_detected[2];  // corners before BRIEF (for the <200 retry, handler.cpp:161)
     int retry[2];
     int overflow;
-    unsigned feat_seq;  // sequence number of the frame whose features this buffer holds, published by k_feat_done (polled by k_gate)
+    seq_t feat_seq;  // sequence number of the frame whose features this buffer holds, published by k_feat_done (polled by k_gate)
 };
 
 struct Feat {  // one image's lvt_image_features_struct (lvt_image_features_struct.h:62-80), SoA

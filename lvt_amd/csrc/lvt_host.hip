@@ -92,7 +92,7 @@ struct Context {
     // completion flags, pinned + coherent, RING x B: k_triangulate stores the frame's sequence number behind its record and the
     // host polls it -- an event record on the tracking stream costs that stream 3-4 us per frame (measured), and nothing else
     // on the device needs the event in the normal mode
-    unsigned *h_done = nullptr, *h_done_dev = nullptr;
+    seq_t *h_done = nullptr, *h_done_dev = nullptr;
     FrameArgs *h_fargs = nullptr;  // pinned, RING x B
     hipEvent_t ev_done[RING] = {};  // the only events of the normal mode: the streams hand over through polling gates (k_gate*)
     // LVT_AMD_ORDERING=events: the streams are ordered by event barriers only and the early stream is not used (the tracking chain
@@ -300,9 +300,9 @@ static void reset_state(Context *c) {  // lvt_system::reset (lvt_system.cpp:44-6
         z.optimized.q[0] = z.predicted.q[0] = 1.0;
         z.out_R[0] = z.out_R[4] = z.out_R[8] = 1.0;
         z.out_status = 1;
-        z.pnp_seq = (unsigned)c->enq;  // the next frame's gate waits for this value: nothing is pending
-        z.early_state = 4u * (unsigned)c->enq + 3u;
-        z.track_done_seq = (unsigned)c->enq;
+        z.pnp_seq = (seq_t)c->enq;  // the next frame's gate waits for this value: nothing is pending
+        z.early_state = 4u * (seq_t)c->enq + 3u;
+        z.track_done_seq = (seq_t)c->enq;
         HIPCHK(c, hipMemcpyAsync(c->d_ctl[s], &z, sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->h_seqs[s].map_n, 0, sizeof(int), c->stream));
         HIPCHK(c, hipMemsetAsync(c->h_seqs[s].map_cur, 0, sizeof(int), c->stream));
@@ -337,9 +337,9 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
         c->pitch = ((prm.W + 63) / 64) * 64;
         HIPCHK(c, hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl) * B * RING, hipHostMallocCoherent));
         HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_ctl_dev, c->h_ctl, 0));
-        HIPCHK(c, hipHostMalloc((void **)&c->h_done, sizeof(unsigned) * B * RING, hipHostMallocCoherent));
+        HIPCHK(c, hipHostMalloc((void **)&c->h_done, sizeof(seq_t) * B * RING, hipHostMallocCoherent));
         HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_done_dev, c->h_done, 0));
-        std::memset(c->h_done, 0, sizeof(unsigned) * B * RING);
+        std::memset(c->h_done, 0, sizeof(seq_t) * B * RING);
         HIPCHK(c, hipHostMalloc((void **)&c->h_fargs, sizeof(FrameArgs) * B * RING, hipHostMallocDefault));
         c->h_seqs.resize(B);
         c->d_ctl.resize(B);
@@ -464,7 +464,7 @@ static void enqueue_frame(Context *c) {
     const bool evo = c->events_only;
     if (c->enq >= NPAR) {
         if (!evo)
-            hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, B), dim3(64), 0, sf, S, (unsigned)(c->enq + 1 - NPAR));  // polls; see k_gate_buf
+            hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, B), dim3(64), 0, sf, S, (seq_t)(c->enq + 1 - NPAR));  // polls; see k_gate_buf
         else
             (void)hipStreamWaitEvent(sf, c->ev_done[(int)((c->enq - NPAR) % RING)], 0);
     }
@@ -481,14 +481,14 @@ static void enqueue_frame(Context *c) {
     LAUNCH(5, sf, k_gather, dim3(1, 2, B), dim3(1024), 0, S, par);
     LAUNCH(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, S, par);
     LAUNCH(18, sf, k_candidates<MODE_ROW>, dim3(256, 1, B), dim3(256), 0, S, 0, par);
-    hipLaunchKernelGGL(k_feat_done, dim3(B), dim3(64), 0, sf, S, par, (unsigned)(c->enq + 1));
+    hipLaunchKernelGGL(k_feat_done, dim3(B), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));
     if (evo) (void)hipEventRecord(c->ev_feat[par], sf);
     // ---- early stream: projection, candidate lists and greedy resolution of the map points that survived the previous frame,
     //      as soon as that frame's pose exists (its k_pnp) -- its k_triangulate only appends behind them
-    const unsigned seq = (unsigned)(c->enq + 1);  // this frame's sequence number; the previous frame's is enq (0: none)
+    const seq_t seq = (seq_t)(c->enq + 1);  // this frame's sequence number; the previous frame's is enq (0: none)
     if (!evo) {
         hipStream_t se = c->stream_e;
-        LAUNCH(1, se, k_gate, dim3(1, 1, B), dim3(64), 0, S, par, (unsigned)c->enq, seq);  // polls the previous k_pnp and this frame's features
+        LAUNCH(1, se, k_gate, dim3(1, 1, B), dim3(64), 0, S, par, (seq_t)c->enq, seq);  // polls the previous k_pnp and this frame's features
         LAUNCH(9, se, k_early_map, dim3(256, 1, B), dim3(256), 0, S, par, seq);
         LAUNCH(10, se, k_early_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par, seq);
     }
@@ -517,10 +517,10 @@ static void collect_oldest(Context *c) {
     const int slot = (int)(c->done % RING);
     {   // the frame is complete when every sequence's flag carries its number (the flags follow the records: system-scope
         // release in k_triangulate, acquire here)
-        const unsigned want = (unsigned)(c->done + 1);
+        const seq_t want = (seq_t)(c->done + 1);
         unsigned spins = 0;
         for (int s = 0; s < c->B; s++) {
-            volatile unsigned *f = c->h_done + (size_t)slot * c->B + s;
+            volatile seq_t *f = c->h_done + (size_t)slot * c->B + s;
             while (__atomic_load_n(f, __ATOMIC_ACQUIRE) != want) {
                 __builtin_ia32_pause();
                 if ((++spins & 0xFFFFF) == 0) {  // every ~10 ms: a dead stream must not hang the caller

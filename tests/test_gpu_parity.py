@@ -335,3 +335,36 @@ def test_serialised_dispatches_are_reported_not_silently_wrong(hip_lib, tmp_path
         if f["state"] == 3:
             assert f["err"] != ""                        # LOST is never silent
     assert saw_report
+
+
+def test_lockstep_batch_with_one_sequence_lost(hip_lib):
+    """sequences of one batch are independent state machines: one of them sees a nearly empty frame (second pass, then LOST
+    and the sticky last pose) while the other keeps tracking -- both equal their stand-alone handles, frame for frame"""
+    import torch
+    worlds = [make_case("kitti", 30, 0.5)[0], make_case("kitti", 31, 0.5)[0]]
+    prm = make_case("kitti", 30, 0.5, {"min_num_matches_for_tracking": 60})[1]
+    n = 10
+    W, H = worlds[0].W, worlds[0].H
+    pitch = ((W + 63) // 64) * 64
+    dev = torch.zeros((2, n, 2, H, pitch), dtype=torch.uint8, device="cuda")
+    for s in range(2):
+        for k in range(n):
+            L, R = sparse_pair(worlds[s]) if (s == 1 and k == 5) else worlds[s].render_stereo(k)
+            dev[s, k, 0, :, :W] = torch.from_numpy(L).cuda(); dev[s, k, 1, :, :W] = torch.from_numpy(R).cuda()
+    torch.cuda.synchronize()
+    singles = [hip_lib.LvtSystem.create(prm, 1) for _ in range(2)]
+    batch = hip_lib.LvtBatch(prm, 2)
+    states = []
+    for k in range(n):
+        lp = [dev[s, k, 0].data_ptr() for s in range(2)]; rp = [dev[s, k, 1].data_ptr() for s in range(2)]
+        batch.track_device_async(lp, rp, H, W, pitch)
+        Rb, tb, st = batch.wait()
+        for s in range(2):
+            Rs, ts = singles[s].track_device(lp[s], rp[s], H, W, pitch)
+            assert np.array_equal(ts, tb[s]) and np.array_equal(Rs, Rb[s]), f"sequence {s} frame {k}"
+            assert st[s] == singles[s].get_state()
+        states.append([int(x) for x in st])
+    assert states[4] == [2, 2] and states[5] == [2, 3] and states[-1] == [2, 3], states   # LOST is sticky, the other one tracks on
+    for s in range(2):
+        assert batch.counts(s) == singles[s].counts()
+    assert batch.last_error() == ""

@@ -804,17 +804,20 @@ __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int pa
     if (MODE == MODE_MAP) {
         // a failed pass 1 (< 50) is discarded: pass 2 rebuilds the marks from scratch
         for (int j = tid; j < N; j += RES_THREADS) S.fb[par].feat[0].flag[j] = L.flag[j];
-        if (tid == 0 && phase == 1) ctl.early_accepted = accepted;
+        if (tid == 0 && phase == 1) {
+            ctl.early_accepted = accepted;
+            // bring-up stamps of the resolver (tools/cells_phases.py): the early part is where most of find_matches is resolved
+            ctl.dbg[18] = L.misc[4];
+            ctl.dbg[19] = L.misc[5];
+            ctl.dbg[28] = L.misc[3];
+            for (int k = 0; k < 4; k++) ctl.dbg[24 + k] = L.misc[8 + k];
+            ctl.dbg[29] = L.misc[6];
+            ctl.dbg[30] = L.misc[7];
+            ctl.dbg[31] = tk1 - tk0;
+            ctl.dbg[23] = clock64() - tk0;
+        }
         if (tid == 0 && phase != 1) {
             if (!pass2) {
-                ctl.dbg[18] = L.misc[4];
-                ctl.dbg[19] = L.misc[5];
-                ctl.dbg[28] = L.misc[3];
-                for (int k = 0; k < 4; k++) ctl.dbg[24 + k] = L.misc[8 + k];
-                ctl.dbg[29] = L.misc[6];
-                ctl.dbg[30] = L.misc[7];
-                ctl.dbg[31] = tk1 - tk0;
-                ctl.dbg[23] = clock64() - tk0;
                 ctl.n_pass1 = accepted;
                 ctl.do_pass2 = (accepted < N_MATCHES_TH) ? 1 : 0;  // lvt_local_map.cpp:173
                 L.misc[2] = ctl.do_pass2;

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """usage: python tools/cells_phases.py [kitti|euroc|tum]
 clock64 phase stamps of the single-workgroup kernels (Ctl::dbg, bring-up profiling): k_cells of cell 0 / left eye,
-and k_pnp.  Run on the GPU box:  python tools/cells_phases.py"""
+k_pnp and the early map resolver.  Run on the GPU box:  python tools/cells_phases.py"""
 import os
 import sys
 
@@ -23,3 +23,5 @@ for i in range(4):
     d = vo.debug_stamps()
     print("frame", i, "k_cells cell 0 cycles:", {phases[k]: int(d[k + 1] - d[k]) for k in range(11)}, "total", int(d[11] - d[0]))
     print("   k_pnp cycles: sweeps (incl. reductions)", d[12], "reductions", d[13], "solve", d[14], "decide", d[15], "all", d[16], "solve() calls", d[17])
+    print("   early map resolver (k_early_mid): fixpoint iterations", d[18], "fixpoint cycles", d[19], "kernel cycles", d[23], "| init", d[31], "counts+scan", d[29],
+          "pack", d[30], "longest list", d[28], "end of iterations 1-4", d[24], d[25], d[26], d[27])

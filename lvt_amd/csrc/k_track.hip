@@ -1846,11 +1846,14 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, seq_t 
     __shared__ Pose cam;
     __shared__ int scan[32];
     const int tid = threadIdx.x;
+    const long long tq0 = clock64();
+    long long tq1 = tq0, tq2 = tq0;
     RESOLVE_LDS_DECL
     if (ctl.active && !ctl.lost_now) {  // update_staged_map_points + the triangulation policy (block-uniform condition)
         staged_body(S, ctl, par, L, r_tab);
         __syncthreads();  // need_tri / dont_stage / map_n / staged_n / the marks: written above, read below by other threads
     }
+    tq1 = clock64();
     const bool run = ctl.active && !ctl.lost_now && ctl.need_tri;  // block-uniform
     if (run) {
     int n_pairs = 0;
@@ -1859,6 +1862,7 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, seq_t 
         __syncthreads();
         n_pairs = L.misc[2];
     }
+    tq2 = clock64();
     if (tid == 0) {
         if (ctl.first_frame) {
             cam.q[0] = 1, cam.q[1] = cam.q[2] = cam.q[3] = 0;
@@ -1948,6 +1952,9 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, seq_t 
         ctl.overflow |= S.fb[par].fc->overflow;
         ctl.counts[C_OVERFLOW] = ctl.overflow;
         ctl.dbg[46] = (long long)wall_clock64();
+        if (run) {  // bring-up stamps of a triangulation frame (tools/cells_phases.py): staged update, row resolution, the rest
+            ctl.dbg[20] = tq1 - tq0, ctl.dbg[21] = tq2 - tq1, ctl.dbg[22] = clock64() - tq2;
+        }
         __threadfence();
         atomicExch(&ctl.track_done_seq, seq);  // this frame's feature buffer may be refilled (k_gate_buf polls this)
     }

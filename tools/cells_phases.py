@@ -17,7 +17,7 @@ vo = lvt_amd.LvtSystem.create(prm, sensor)
 # stamp k .. k+1 of k_cells (k_features.hip STAMP(k)); dbg[1] is taken right after the corner gather
 phases = ["gather segments", "(links start)", "links + union-find + component maxima", "replay of tied components", "survivors",
           "std::sort emulation", "rank", "radii", "decision radius", "emit", "done"]
-for i in range(4):
+for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4):
     L, R = w.render_rgbd(i) if sensor == 2 else w.render_stereo(i)
     vo.track(L, R)
     d = vo.debug_stamps()
@@ -25,3 +25,4 @@ for i in range(4):
     print("   k_pnp cycles: sweeps (incl. reductions)", d[12], "reductions", d[13], "solve", d[14], "decide", d[15], "all", d[16], "solve() calls", d[17])
     print("   early map resolver (k_early_mid): fixpoint iterations", d[18], "fixpoint cycles", d[19], "kernel cycles", d[23], "| init", d[31], "counts+scan", d[29],
           "pack", d[30], "longest list", d[28], "end of iterations 1-4", d[24], d[25], d[26], d[27])
+    print("   k_triangulate of the last triangulation frame, cycles: staged update", d[20], "row resolution", d[21], "triangulation + append + epilogue", d[22])

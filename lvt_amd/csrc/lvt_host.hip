@@ -816,11 +816,25 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
         HIPCHK(c, hipHostMalloc((void **)&c->h_stage[par], c->stage_img + second_bytes, hipHostMallocDefault));
         HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_stage_dev[par], c->h_stage[par], 0));
     }
-    // the borrowed buffers are copied into pinned memory by the CPU (they may be reused the moment this call returns) and the
-    // GPU pulls them from there
-    std::memcpy(c->h_stage[par], left, nbytes);
-    std::memcpy(c->h_stage[par] + c->stage_img, second, rgbd ? sizeof(float) * nbytes : nbytes);
-    const uint8_t *s0 = c->h_stage_dev[par], *s1 = c->h_stage_dev[par] + c->stage_img;
+    // the borrowed buffers are copied into pinned memory by the CPU and the GPU pulls them from there -- unless the caller's
+    // buffer already IS pinned host memory (hipHostMalloc / hipHostRegister, 16-byte aligned): then the GPU reads it in place
+    // (this call only returns after the frame has been tracked, so the buffer outlives every read)
+    auto device_view = [](const void *p) -> const uint8_t * {
+        hipPointerAttribute_t a;
+        if (((uintptr_t)p & 15) == 0 && hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost && a.devicePointer)
+            return static_cast<const uint8_t *>(a.devicePointer);
+        (void)hipGetLastError();  // (an ordinary malloc'ed pointer is "invalid value" to the query: not an error of this call)
+        return nullptr;
+    };
+    const uint8_t *s0 = device_view(left), *s1 = device_view(second);
+    if (!s0) {
+        std::memcpy(c->h_stage[par], left, nbytes);
+        s0 = c->h_stage_dev[par];
+    }
+    if (!s1) {
+        std::memcpy(c->h_stage[par] + c->stage_img, second, rgbd ? sizeof(float) * nbytes : nbytes);
+        s1 = c->h_stage_dev[par] + c->stage_img;
+    }
     hipLaunchKernelGGL(k_stage_in, dim3(128, rgbd ? 1 : 2), dim3(256), 0, sf, s0, s1, c->d_img[par][0], c->d_img[par][1], n_cols, n_rows, c->pitch);
     FrameArgs &f = c->h_fargs[(size_t)(c->enq % RING) * c->B];
     f.img[0] = c->d_img[par][0];

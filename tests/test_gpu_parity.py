@@ -368,3 +368,24 @@ def test_lockstep_batch_with_one_sequence_lost(hip_lib):
     for s in range(2):
         assert batch.counts(s) == singles[s].counts()
     assert batch.last_error() == ""
+
+
+def test_pinned_host_buffers_are_read_in_place(hip_lib):
+    """lvt_track with page-locked host images (torch pin_memory = hipHostMalloc) skips the staging copy; same poses as with
+    ordinary numpy buffers, including an unaligned view that has to take the copying path"""
+    import torch
+    world, prm, sensor = make_case("kitti", 17, 0.5)
+    a = hip_lib.LvtSystem.create(prm, 1); b = hip_lib.LvtSystem.create(prm, 1)
+    for i in range(8):
+        L, R = world.render_stereo(i)
+        pl, pr = torch.from_numpy(L).pin_memory(), torch.from_numpy(R).pin_memory()
+        if i == 5:  # an unaligned pinned view: base + 1 byte
+            buf = torch.empty(L.size + 1, dtype=torch.uint8).pin_memory()
+            buf[1:] = torch.from_numpy(L).reshape(-1)
+            Lp = buf[1:].numpy().reshape(L.shape)
+        else:
+            Lp = pl.numpy()
+        Ra, ta = a.track(L, R)
+        Rb, tb = b.track(Lp, pr.numpy())
+        assert np.array_equal(ta, tb) and np.array_equal(Ra, Rb), f"frame {i}"
+    assert a.counts() == b.counts() and b.last_error() == ""

@@ -21,16 +21,20 @@ dev = torch.zeros((n, 2, w.H, pitch), dtype=torch.uint8, device="cuda")
 for i, (L, R) in enumerate(frames):
     dev[i, 0, :, :w.W] = torch.from_numpy(L).cuda(); dev[i, 1, :, :w.W] = torch.from_numpy(R).cuda()
 torch.cuda.synchronize()
-for name in ("host buffers (lvt_track)", "device-resident (lvt_amd_track_device)"):
+pinned = [(torch.from_numpy(L).pin_memory(), torch.from_numpy(R).pin_memory()) for L, R in frames]
+pinned_np = [(a.numpy(), b.numpy()) for a, b in pinned]
+for name in ("host buffers (lvt_track)", "pinned host buffers (lvt_track, read in place)", "device-resident (lvt_amd_track_device)"):
     vo = lvt_amd.LvtSystem.create(prm, 1)
     ts = []
     for i in range(n):
         t0 = time.perf_counter()
         if name.startswith("host"):
             vo.track(frames[i][0], frames[i][1])
+        elif name.startswith("pinned"):
+            vo.track(pinned_np[i][0], pinned_np[i][1])
         else:
             p = dev[i].data_ptr()
             vo.track_device(p, p + w.H * pitch, w.H, w.W, pitch)
         ts.append(time.perf_counter() - t0)
     ts = np.array(ts[10:]) * 1e3
-    print("%-42s median %.3f ms  mean %.3f ms  -> %.0f frames/s   state %d  %s" % (name, np.median(ts), ts.mean(), 1e3 / ts.mean(), vo.get_state(), vo.last_error()))
+    print("%-50s median %.3f ms  mean %.3f ms  -> %.0f frames/s   state %d  %s" % (name, np.median(ts), ts.mean(), 1e3 / ts.mean(), vo.get_state(), vo.last_error()))

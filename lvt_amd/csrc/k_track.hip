@@ -1969,7 +1969,10 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, seq_t 
         __threadfence_system();
         __syncthreads();
         // the completion flag the host polls, behind the record (release at system scope)
-        if (tid == 0) __hip_atomic_store(done_out + blockIdx.z, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        if (tid == 0) {
+            __hip_atomic_store(done_out + blockIdx.z, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            ctl.dbg[43] = (long long)wall_clock64();  // (tools/timeline.py: lands in the NEXT frame's record)
+        }
     }
 }
 

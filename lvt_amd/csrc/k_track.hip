@@ -291,15 +291,19 @@ __device__ __forceinline__ void candidates_body(Seq &S, int pass2, int par, Cand
     }
 }
 
+// need_seq (row mode on the early stream): the lists are only built from COMPLETE features (the stream's gate may have given up
+// waiting for them; then k_row_done does not publish either and k_triangulate reports the frame as lost)
 template <int MODE>
-__global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2, int par) {
+__global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2, int par, seq_t need_seq) {
     Seq &S = seqs[blockIdx.z];
     if (MODE != MODE_ROW) {
         const Ctl &ctl = *S.ctl;
         if (!ctl.active || ctl.first_frame) return;
         if (MODE == MODE_STAGED && (ctl.lost_now || S.prm.staged_th <= 0)) return;
-    } else if (S.prm.sensor != 1)
-        return;
+    } else {
+        if (S.prm.sensor != 1) return;
+        if (need_seq && __hip_atomic_load(&S.fb[par].fc->feat_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < need_seq) return;
+    }
     __shared__ uint32_t lbuf[4 * KC];
     __shared__ float s_tx[NF_MAX], s_ty[NF_MAX];
     __shared__ uint32_t s_tc[NF_MAX];
@@ -372,6 +376,15 @@ __global__ void k_feat_done(Seq *seqs, int par, seq_t seq) {
     seqs[blockIdx.x].ctl->dbg[47] = (long long)wall_clock64();  // (written from the feature stream: the frame it belongs to may differ)
     __threadfence();
     atomicExch(&fc.feat_seq, seq);
+}
+
+// behind k_candidates<ROW>: this frame's row-match candidate lists are complete (k_triangulate's head polls the word)
+__global__ void k_row_done(Seq *seqs, int par, seq_t seq) {
+    if (threadIdx.x != 0) return;
+    FeatCtl &fc = *seqs[blockIdx.x].fb[par].fc;
+    if (__hip_atomic_load(&fc.feat_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) return;  // (see k_candidates)
+    __threadfence();
+    atomicExch(&fc.row_seq, seq);
 }
 
 __global__ __launch_bounds__(64) void k_gate(Seq *seqs, int par, seq_t want, seq_t seq) {
@@ -1839,7 +1852,7 @@ __device__ bool triangulate_pair(const Params &p, const double *cml, const doubl
     return true;
 }
 
-__global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, seq_t seq, Ctl *rec_out, seq_t *done_out) {
+__global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, seq_t seq, Ctl *rec_out, seq_t *done_out, int row_gated) {
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     __shared__ double cml[12], cmr[12], R[9];
@@ -1858,6 +1871,23 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, seq_t 
     if (run) {
     int n_pairs = 0;
     if (S.prm.sensor == 1) {  // row_match (lvt_image_features_handler.cpp:299-326): greedy resolution of the lists k_candidates<ROW> built
+        // (on the early stream behind k_early_mid: normally finished ~70 us ago.  One workgroup polling holds one CU.  2 s without
+        //  the lists: nothing valid to triangulate from -> LOST, reported)
+        if (row_gated) {
+            if (tid == 0) {
+                FeatCtl &fc = *S.fb[par].fc;
+                const unsigned long long t0 = wall_clock64();
+                while (__hip_atomic_load(&fc.row_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+                    __builtin_amdgcn_s_sleep(8);
+                    if (wall_clock64() - t0 > 200000000ull) {
+                        ctl.state = 3;
+                        atomicAdd(&ctl.gate_fatal, 1);
+                        break;
+                    }
+                }
+            }
+            __syncthreads();
+        }
         resolve_body<MODE_ROW>(S, ctl, 0, par, L, r_tab);
         __syncthreads();
         n_pairs = L.misc[2];
@@ -1977,8 +2007,8 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, seq_t 
 }
 
 // explicit instantiations used by the host
-template __global__ void k_candidates<MODE_MAP>(Seq *, int, int);
-template __global__ void k_candidates<MODE_STAGED>(Seq *, int, int);
-template __global__ void k_candidates<MODE_ROW>(Seq *, int, int);
+template __global__ void k_candidates<MODE_MAP>(Seq *, int, int, seq_t);
+template __global__ void k_candidates<MODE_STAGED>(Seq *, int, int, seq_t);
+template __global__ void k_candidates<MODE_ROW>(Seq *, int, int, seq_t);
 
 }  // namespace lvt

@@ -117,6 +117,7 @@ struct FeatCtl {        // per-frame state of the FEATURE stage (own stream, dou
     int n_detected[2];  // corners before BRIEF (for the <200 retry, handler.cpp:161)
     int retry[2];
     int overflow;
+    seq_t row_seq;    // ... of the frame whose row-match candidate lists it holds (k_row_done; polled by k_triangulate)
     seq_t feat_seq;  // sequence number of the frame whose features this buffer holds, published by k_feat_done (polled by k_gate)
 };
 

@@ -38,6 +38,11 @@ namespace lvt {
     } while (0)
 
 constexpr int EXT_MAX = 16384;
+// workgroups of k_candidates<ROW> on the early stream: 256 of them (one per CU, as on the feature stream) cost 6 % of the frame
+// rate -- they share SIMDs and LDS with the single-workgroup kernels of the tracking chain running beside them; 16 make the kernel
+// itself too slow (measured: 24 / 32 / 40 / 48 / 64 / 256 -> 8 180 / 8 330 / 8 320 / 8 270 / 8 240 / 7 840 frames/s)
+constexpr int ROW_BLOCKS = 32;
+constexpr int ROW_BLOCKS_BATCH = 16;  // per sequence of a lock-step batch (16 sequences: 8 / 16 / 32 / 64 / 256 -> 30.8k / 36.9k / 35.8k / 35.0k / 31.1k frames/s)
 constexpr int RING = 8;  // frames that may be in flight / un-collected
 
 // first kernel of the feature stage of a BATCH: publish every sequence's inputs (a single sequence gets them as a kernel
@@ -427,7 +432,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
 static const char *kProfNames[Context::PROF_SLOTS] = {
     "k_feat_begin", "k_gate [early stream: waits for the previous k_pnp]", "k_score", "k_cells(pass0)", "k_cells(retry)", "k_gather", "k_brief", "k_gate_late [waits for the early stream]",
     "k_match_map(begin + new points)", "k_early_map [early stream]", "k_early_mid [early stream]", "", "k_track_mid(resolve+pass2+bookkeep+cull)", "k_pnp(+project staged)", "",
-    "", "k_candidates(staged)", "", "k_candidates(row) [feature stream]", "", "k_triangulate(staged update+row resolve+triangulate+finalize)", "",
+    "", "k_candidates(staged)", "", "k_candidates(row) [early stream]", "", "k_triangulate(staged update+row resolve+triangulate+finalize)", "",
     "", ""};
 
 #define LAUNCH(slot, st, kern, grid, block, lds, ...)                              \
@@ -480,7 +485,7 @@ static void enqueue_frame(Context *c) {
     }
     LAUNCH(5, sf, k_gather, dim3(1, 2, B), dim3(1024), 0, S, par);
     LAUNCH(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, S, par);
-    LAUNCH(18, sf, k_candidates<MODE_ROW>, dim3(256, 1, B), dim3(256), 0, S, 0, par);
+    if (evo) LAUNCH(18, sf, k_candidates<MODE_ROW>, dim3(256, 1, B), dim3(256), 0, S, 0, par, (seq_t)0);  // (normal mode: on the early stream, below)
     hipLaunchKernelGGL(k_feat_done, dim3(B), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));
     if (evo) (void)hipEventRecord(c->ev_feat[par], sf);
     // ---- early stream: projection, candidate lists and greedy resolution of the map points that survived the previous frame,
@@ -491,6 +496,13 @@ static void enqueue_frame(Context *c) {
         LAUNCH(1, se, k_gate, dim3(1, 1, B), dim3(64), 0, S, par, (seq_t)c->enq, seq);  // polls the previous k_pnp and this frame's features
         LAUNCH(9, se, k_early_map, dim3(256, 1, B), dim3(256), 0, S, par, seq);
         LAUNCH(10, se, k_early_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par, seq);
+        if (c->sensor == 1) {
+            // row-match candidate lists of THIS frame (needed by its k_triangulate, ~70 us from here): they need the two feature
+            // sets only, and the feature stream is the longest chain -- here, behind the early part, they lengthen neither it nor
+            // the hand-over to the tracking stream.  Few workgroups: the tracking chain's single-workgroup kernels run meanwhile.
+            LAUNCH(18, se, k_candidates<MODE_ROW>, dim3(B == 1 ? ROW_BLOCKS : ROW_BLOCKS_BATCH, 1, B), dim3(256), 0, S, 0, par, seq);
+            hipLaunchKernelGGL(k_row_done, dim3(B), dim3(64), 0, se, S, par, seq);
+        }
     }
     // ---- tracking chain (stream): strictly ordered frame after frame
     // (no barrier on the features here: k_gate_late returns only after the early stream's gate has seen them complete, and
@@ -503,9 +515,9 @@ static void enqueue_frame(Context *c) {
     LAUNCH(12, st, k_track_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par, seq);
     LAUNCH(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), PNP_DYN_BYTES, S, par, seq);
     if (p.staged_th > 0)  // (a configuration without staging -- EuRoC, TUM -- never has staged points to list)
-        LAUNCH(16, st, k_candidates<MODE_STAGED>, dim3(64, 1, B), dim3(256), 0, S, 0, par);
+        LAUNCH(16, st, k_candidates<MODE_STAGED>, dim3(64, 1, B), dim3(256), 0, S, 0, par, (seq_t)0);
     LAUNCH(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, S, par, seq, c->h_ctl_dev + (size_t)slot * B,
-           c->h_done_dev + (size_t)slot * B);  // writes the result record and the completion flag itself
+           c->h_done_dev + (size_t)slot * B, evo ? 0 : 1);  // writes the result record and the completion flag itself
     if (evo) (void)hipEventRecord(c->ev_done[slot], st);  // (events-only ordering: the feature stream's barrier needs it)
     c->enq++;
 }

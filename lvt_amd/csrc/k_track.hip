@@ -2,7 +2,7 @@
 //
 //   T = tracking stream (the frame period), E = early stream (frame t+1's share of find_matches, behind k_pnp(t)), F = feature stream
 //   k_candidates<ROW|STAGED> : masked Hamming candidate lists, one wavefront per query   (lvt_image_features_struct.cpp:68-148)
-//   k_gate / k_gate_buf / k_gate_late / k_feat_done : the polling hand-over between the streams
+//   k_gate / k_gate_buf / k_gate_late / k_feat_done / k_row_done : the polling hand-over between the streams
 //   E k_early_map  : projection + candidate lists of the map points that survived the previous frame's clean-up
 //   E k_early_mid  : their greedy accept/mark scan (the first part of find_matches' storage-order scan)
 //   T k_match_map  : frame prologue (motion model, state machine; lvt_system.cpp:157-197) + is_point_visible / projection

@@ -1068,10 +1068,30 @@ __global__ __launch_bounds__(RES_THREADS) void k_early_mid(Seq *seqs, int par, s
 // the tracking stream's counterpart of k_gate: returns when the early stream has finished this frame.  A barrier packet waiting
 // on an event would do the same, but a queue parked on a barrier stalls the other queues of its hardware pipe (measured: the
 // feature stream only advanced when the tracking stream's barrier resolved), and the event itself costs ~12 us of latency.
-__global__ __launch_bounds__(64) void k_gate_late(Seq *seqs, int par, seq_t seq) {
+// The frame's result record goes straight into the caller's pinned ring slot (device-visible host memory), then the completion
+// flag the host polls (release at system scope).  An asynchronous copy-engine transfer at the end of the chain cost ~20 us of
+// the inter-frame critical path; doing this at the end of k_triangulate costs ~5 us of it (the system-scope fence is a PCIe
+// round trip) -- so in the asynchronous mode the NEXT frame's k_gate_late delivers it, while it has to wait for the early stream
+// anyway (the per-frame part of Ctl is only reset by the k_match_map behind it).
+__device__ __forceinline__ void deliver_record(const Ctl &ctl, Ctl *rec_out, seq_t *done_out, seq_t seq, int nthreads) {
+    static_assert(sizeof(Ctl) % 8 == 0, "record copy");
+    const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&ctl);
+    unsigned long long *dst = reinterpret_cast<unsigned long long *>(rec_out);
+    for (int i = threadIdx.x; i < (int)(sizeof(Ctl) / 8); i += nthreads) dst[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(done_out, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+// (the last enqueued frame has no successor: the host launches this when it is asked for that frame's result)
+__global__ __launch_bounds__(64) void k_deliver(Seq *seqs, Ctl *rec_out, seq_t *done_out, seq_t seq) {
+    deliver_record(*seqs[blockIdx.z].ctl, rec_out + blockIdx.z, done_out + blockIdx.z, seq, 64);
+}
+
+__global__ __launch_bounds__(64) void k_gate_late(Seq *seqs, int par, seq_t seq, Ctl *prev_rec, seq_t *prev_done) {
     if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[38] = (long long)wall_clock64();
     Ctl &ctl = *seqs[blockIdx.z].ctl;
     FeatCtl &fc = *seqs[blockIdx.z].fb[par].fc;
+    if (prev_rec) deliver_record(ctl, prev_rec + blockIdx.z, prev_done + blockIdx.z, seq - 1, 64);  // the previous frame's result
     if (threadIdx.x != 0) return;
     unsigned long long t0 = wall_clock64();
     for (;;) {
@@ -1852,7 +1872,7 @@ __device__ bool triangulate_pair(const Params &p, const double *cml, const doubl
     return true;
 }
 
-__global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, seq_t seq, Ctl *rec_out, seq_t *done_out, int row_gated) {
+__global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, seq_t seq, Ctl *rec_out, seq_t *done_out, int row_gated, int deliver) {
     Seq &S = seqs[blockIdx.z];
     Ctl &ctl = *S.ctl;
     __shared__ double cml[12], cmr[12], R[9];
@@ -1988,22 +2008,10 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, seq_t 
         __threadfence();
         atomicExch(&ctl.track_done_seq, seq);  // this frame's feature buffer may be refilled (k_gate_buf polls this)
     }
-    // ---- the frame's result record goes straight into the caller's pinned ring slot (device-visible host memory): an
-    //      asynchronous copy engine transfer at this point of the stream cost ~20 us of the inter-frame critical path
+    // ---- the frame's result record (synchronous calls and the events-only ordering: here; otherwise by the next frame's k_gate_late)
     __syncthreads();
-    {
-        static_assert(sizeof(Ctl) % 8 == 0, "record copy");
-        const unsigned long long *src = reinterpret_cast<const unsigned long long *>(&ctl);
-        unsigned long long *dst = reinterpret_cast<unsigned long long *>(rec_out + blockIdx.z);
-        for (int i = tid; i < (int)(sizeof(Ctl) / 8); i += 1024) dst[i] = __hip_atomic_load(&src[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __threadfence_system();
-        __syncthreads();
-        // the completion flag the host polls, behind the record (release at system scope)
-        if (tid == 0) {
-            __hip_atomic_store(done_out + blockIdx.z, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-            ctl.dbg[43] = (long long)wall_clock64();  // (tools/timeline.py: lands in the NEXT frame's record)
-        }
-    }
+    if (deliver) deliver_record(ctl, rec_out + blockIdx.z, done_out + blockIdx.z, seq, 1024);
+    if (tid == 0) ctl.dbg[43] = (long long)wall_clock64();  // (tools/timeline.py: lands in the NEXT frame's record)
 }
 
 // explicit instantiations used by the host

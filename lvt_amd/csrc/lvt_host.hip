@@ -114,6 +114,8 @@ struct Context {
     float *d_ext[NPAR][2] = {};
     int pitch = 0;
     long enq = 0, done = 0;    // frames enqueued / collected
+    long delivered = 0;        // frames whose record delivery has been enqueued (k_triangulate, the next frame's k_gate_late, or k_deliver)
+    bool sync_call = false;    // the frame being enqueued is collected right away: k_triangulate delivers its record itself
     int last_slot = 0, last_par = 0;
     std::string err;
     // optional per-kernel timing with HIP events on the launch streams (lvt_amd_profile_*)
@@ -510,14 +512,24 @@ static void enqueue_frame(Context *c) {
     if (evo)
         (void)hipStreamWaitEvent(st, c->ev_feat[par], 0);  // (the early stream never claims the frame: early_ran_seq stays behind)
     else
-        LAUNCH(7, st, k_gate_late, dim3(1, 1, B), dim3(64), 0, S, par, seq);  // the early stream is done with this frame (polled, no barrier packet)
+    {   // the early stream is done with this frame (polled, no barrier packet); also delivers the previous frame's record if nobody has
+        Ctl *prec = nullptr;
+        seq_t *pdone = nullptr;
+        if (c->delivered < c->enq) {
+            const int pslot = (int)((c->enq - 1) % RING);
+            prec = c->h_ctl_dev + (size_t)pslot * B, pdone = c->h_done_dev + (size_t)pslot * B;
+            c->delivered = c->enq;
+        }
+        LAUNCH(7, st, k_gate_late, dim3(1, 1, B), dim3(64), 0, S, par, seq, prec, pdone);
+    }
     LAUNCH(8, st, k_match_map, dim3(256, 1, B), dim3(256), 0, S, par, seq);
     LAUNCH(12, st, k_track_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par, seq);
     LAUNCH(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), PNP_DYN_BYTES, S, par, seq);
     if (p.staged_th > 0)  // (a configuration without staging -- EuRoC, TUM -- never has staged points to list)
         LAUNCH(16, st, k_candidates<MODE_STAGED>, dim3(64, 1, B), dim3(256), 0, S, 0, par, (seq_t)0);
     LAUNCH(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, S, par, seq, c->h_ctl_dev + (size_t)slot * B,
-           c->h_done_dev + (size_t)slot * B, evo ? 0 : 1);  // writes the result record and the completion flag itself
+           c->h_done_dev + (size_t)slot * B, evo ? 0 : 1, (evo || c->sync_call) ? 1 : 0);
+    if (evo || c->sync_call) c->delivered = c->enq + 1;
     if (evo) (void)hipEventRecord(c->ev_done[slot], st);  // (events-only ordering: the feature stream's barrier needs it)
     c->enq++;
 }
@@ -528,8 +540,13 @@ static void collect_oldest(Context *c) {
     c->host_wait_n++;
     if (c->done >= c->enq) return;
     const int slot = (int)(c->done % RING);
+    if (c->delivered < c->done + 1) {  // the last enqueued frame of an asynchronous run: nobody has been asked to deliver it yet
+        hipLaunchKernelGGL(k_deliver, dim3(1, 1, c->B), dim3(64), 0, c->stream, c->d_seqs, c->h_ctl_dev + (size_t)slot * c->B,
+                           c->h_done_dev + (size_t)slot * c->B, (seq_t)(c->done + 1));
+        c->delivered = c->done + 1;
+    }
     {   // the frame is complete when every sequence's flag carries its number (the flags follow the records: system-scope
-        // release in k_triangulate, acquire here)
+        // release on the device, acquire here)
         const seq_t want = (seq_t)(c->done + 1);
         unsigned spins = 0;
         for (int s = 0; s < c->B; s++) {
@@ -805,7 +822,9 @@ LVT_API void lvt_amd_track_device(lvt_handle h, const void *d_left, const void *
     }
     try {
         drain(c);
+        c->sync_call = true;  // collected right away: k_triangulate delivers the record itself
         lvt_amd_track_device_async(h, d_left, d_right, n_rows, n_cols, pitch_bytes);
+        c->sync_call = false;
         drain(c);
         result_out(c, 0, R, t);
     } catch (...) {
@@ -867,7 +886,9 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
         if (ncl) HIPCHK(c, hipMemcpyAsync(c->d_ext[par][0], cl, sizeof(float) * 2 * (size_t)ncl, hipMemcpyHostToDevice, sf));
         if (ncr) HIPCHK(c, hipMemcpyAsync(c->d_ext[par][1], cr, sizeof(float) * 2 * (size_t)ncr, hipMemcpyHostToDevice, sf));
     }
+    c->sync_call = true;  // collected right away: k_triangulate delivers the record itself
     enqueue_frame(c);
+    c->sync_call = false;
     drain(c);
     result_out(c, 0, R, t);
 }

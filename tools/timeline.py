@@ -51,10 +51,13 @@ def pct(x):
 print("early path of frame k+1 after pnp(k) end, us: gate end [%s]  early_mid end [%s]" % (pct(g1 - r[:, 13]), pct(ed1 - r[:, 13])))
 print("features of frame k+1 seen by its gate, us after pnp(k) end (negative = the feature stream was ahead): [%s]" % pct(np.where(r[:, 3] > r[:, 13] - 1000.0, r[:, 3], nx[:, 3]) - r[:, 13]))
 print("tracking path: triangulate(k) end [%s]  gate_late(k+1) start [%s]  match_map(k+1) start [%s]" % (pct(r[:, 14] - r[:, 13]), pct(nx[:, 6] - r[:, 13]), pct(nx[:, 8] - r[:, 13])))
-print("k_triangulate(k): epilogue stamp -> record + completion flag delivered, us: [%s]   delivered -> gate_late(k+1) start: [%s]" % (pct(nx[:, 11] - r[:, 14]), pct(nx[:, 6] - nx[:, 11])))
-_e, _t, _m = ed1 - r[:, 13], nx[:, 11] - r[:, 13], nx[:, 8] - r[:, 13]
+# end of k_triangulate(k): stamped after the record copy when the kernel delivers it itself (then it is in record k+1), before the
+# copy when the next frame's k_gate_late delivers it (then it is in record k)
+tend = np.where(r[:, 11] > r[:, 14], r[:, 11], nx[:, 11])
+print("k_triangulate(k): epilogue stamp -> kernel end, us: [%s]   kernel end -> gate_late(k+1) start: [%s]" % (pct(tend - r[:, 14]), pct(nx[:, 6] - tend)))
+_e, _t, _m = ed1 - r[:, 13], tend - r[:, 13], nx[:, 8] - r[:, 13]
 _ok = ~np.isnan(_e)
-print("means, us after pnp(k) end: early_mid(k+1) end %.1f, k_triangulate(k) delivered %.1f, later of the two %.1f, match_map(k+1) start %.1f; early stream was the later one in %.0f %% of the frames"
+print("means, us after pnp(k) end: early_mid(k+1) end %.1f, k_triangulate(k) ended %.1f, later of the two %.1f, match_map(k+1) start %.1f; early stream was the later one in %.0f %% of the frames"
       % (np.mean(_e[_ok]), np.mean(_t[_ok]), np.mean(np.maximum(_e, _t)[_ok]), np.mean(_m[_ok]), 100.0 * np.mean((_e > _t)[_ok])))
 print("frame period (pnp start to pnp start)            : %6.1f us" % med(np.diff(tl[:, 12])))
 print("pnp(k) end -> gate(k+1) end                       : %6.1f us   (gate started %.1f us before pnp(k) end)" % (med(g1 - r[:, 13]), med(r[:, 13] - g0)))

@@ -578,7 +578,7 @@ constexpr uint32_t PERM = 0xFFFFFFFFu;
 
 template <class NFn>
 __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint32_t *cand, ResolveLds &L, uint32_t &iter, float ratio,
-                                             float desc_th, int acc[2]) {
+                                             float desc_th, int acc[2], int nq[2] = nullptr) {
     const int tid = threadIdx.x;
     int n[2], off[2];
     const long long ts0 = clock64();
@@ -639,6 +639,7 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
         }
     }
     __syncthreads();
+    if (nq) nq[0] = n[0], nq[1] = n[1];  // (list lengths of this thread's queries: the caller need not fetch them again)
     int prev[2] = {-2, -2};
     acc[0] = acc[1] = -1;
     int dbg_steps = 0;
@@ -756,9 +757,9 @@ __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int pa
     __syncthreads();
     const long long tk1 = clock64();
     for (int b0 = (phase == 2) ? q_split : 0; b0 < M;) {
-        int acc[2];
+        int acc[2], nq[2] = {0, 0};
         const uint8_t *lflag = S.fb[par].feat[0].flag;
-        const int used = resolve_super(b0, M, [&](int q) { return (MODE == MODE_ROW && lflag[q]) ? 0 : ncand[q]; }, cand, L, iter, ratio, desc_th, acc);
+        const int used = resolve_super(b0, M, [&](int q) { return (MODE == MODE_ROW && lflag[q]) ? 0 : ncand[q]; }, cand, L, iter, ratio, desc_th, acc, nq);
         if (used < 0) {  // query b0 overflowed KC: exact scan of all train features by wavefront 0
             if (wave_id() == 0) {
                 float qx, qy;
@@ -801,7 +802,7 @@ __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int pa
             const int lq = tid + u * RES_THREADS, q = b0 + lq;
             if (lq >= used) continue;
             if (MODE == MODE_MAP) {
-                if (ncand[q] > 0) S.match[q] = acc[u];  // invisible / candidate-less points keep -2 / -1 (k_match_map / k_early_map)
+                if (nq[u] > 0) S.match[q] = acc[u];  // invisible / candidate-less points keep -2 / -1 (k_match_map / k_early_map)
             } else if (acc[u] >= 0) {
                 const int slot = accepted + (u ? tot0 + ex1 : ex0);
                 S.pair_l[slot] = q;

@@ -3,7 +3,16 @@
  * existing lvt_c caller).  They expose (a) the reference's C++-only API surface over the C-ABI
  * (lvt_system::create with an in-memory lvt_parameters, reset, RGB-D track), (b) zero-copy tracking on
  * images already resident in HBM, (c) read-back of per-frame intermediate results for stage-by-stage
- * parity tests, (d) the batched Hamming matcher micro-benchmark.
+ * parity tests, (d) the batched Hamming matcher micro-benchmark, (e) the EuRoC rectification pre-step and the odometry
+ * accumulator either side of the path.
+ *
+ * Behaviour worth knowing:
+ *  - lvt_track / lvt_amd_wait block by spinning on a completion flag in pinned host memory (one busy core, no interrupt latency).
+ *  - Host images handed to lvt_track are copied into a pinned staging buffer; page-locked, 16-byte aligned caller buffers
+ *    (hipHostMalloc / hipHostRegister) are read in place.
+ *  - Environment, read by lvt_create: LVT_AMD_ORDERING=events orders the library's three streams with event barriers instead of
+ *    polling gate kernels (needed under tools that serialise kernel dispatches, e.g. rocprofv3 --pmc; ~15 % slower).
+ *  - lvt_amd_last_error reports capacity overflows, gate time-outs and "a stream waited 2 s" failures (which set LOST).
  */
 #ifndef LVT_AMD_EXT_H__
 #define LVT_AMD_EXT_H__

@@ -370,7 +370,7 @@ def hamming_match_batched(q_desc, q_xy, t_desc, t_xy, t_flag, r2: float, mode: i
                                            int(img_rows), int(img_cols), C.c_void_p(out.data_ptr()), C.c_void_p(stream), int(launches))
     if us < 0:
         raise RuntimeError("lvt_amd_hamming_match_batched failed")
-    return us
+    return us  # (0.0 for an empty train set: nothing was timed)
 
 
 class Rectifier:

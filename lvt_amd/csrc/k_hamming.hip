@@ -590,6 +590,12 @@ LVT_RADIUS_BITS(lo, 0, t0)
     if (dbg) dbg[6] = clock64();
 }
 
+// no train features at all: every query gets the "no neighbour" record
+__global__ __launch_bounds__(256) void k_hamming_none(int4 *out, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = make_int4(-1, 0x7FFFFFFF, -1, 0x7FFFFFFF);
+}
+
 static inline size_t hamming_lds_bytes(int N, int M, int nbins) {
     return (size_t)N * 32 + (size_t)N * 8 + (size_t)M * 12 + (size_t)(nbins + 1) * 4 + (size_t)((N + 1) & ~1) * 2 + (size_t)((M + 1) & ~1) * 2 + 16;
 }

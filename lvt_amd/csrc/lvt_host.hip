@@ -1122,6 +1122,11 @@ LVT_API float lvt_amd_hamming_match_batched_n(const void *q_desc, const void *q_
                                               int B, int M, int N, float r2, int mode, int img_rows, int img_cols, void *out,
                                               void *hip_stream, int launches) {
     if (launches < 1) launches = 1;
+    if (B > 0 && M > 0 && M <= HB_MMAX && N == 0) {  // an empty train set: knnMatch returns nothing for every query
+        hipLaunchKernelGGL(k_hamming_none, dim3((unsigned)(((size_t)B * M + 255) / 256)), dim3(256), 0, static_cast<hipStream_t>(hip_stream),
+                           static_cast<int4 *>(out), (size_t)B * M);
+        return hipStreamSynchronize(static_cast<hipStream_t>(hip_stream)) == hipSuccess ? 0.0f : -1.0f;
+    }
     if (B <= 0 || M <= 0 || N <= 0 || N > HB_NMAX || M > HB_MMAX) {
         std::fprintf(stderr, "lvt_amd_hamming_match_batched: bad sizes B=%d M=%d N=%d (N <= %d, M <= %d)\n", B, M, N, HB_NMAX, HB_MMAX);
         return -1.0f;

@@ -117,6 +117,7 @@ def _hamming_ref_np(qd, qxy, td, txy, tf, r2, mode, rows):
             mask = (ty >= s) & (ty <= e)
         mask &= (tf[b] == 0)[None, :]
         key = np.where(mask, d * 65536 + np.arange(N)[None, :], np.int64(1) << 40)
+        key = np.concatenate([key, np.full((M, 2), np.int64(1) << 40)], axis=1)   # (a single train feature still has a "second")
         order = np.argsort(key, axis=1, kind="stable")[:, :2]
         k1 = np.take_along_axis(key, order[:, :1], 1)[:, 0]
         k2 = np.take_along_axis(key, order[:, 1:2], 1)[:, 0]
@@ -155,6 +156,35 @@ def test_hamming_match_batched_large(hip_lib, mode, r2, M, N):
     out = torch.zeros((B, M, 4), dtype=torch.int32, device="cuda")
     us = hip_lib.hamming_match_batched(t(qd), t(qxy), t(td), t(txy), t(tf), r2, mode, rows, cols, out)
     assert us > 0
+    got = out.cpu().numpy()
+    bad = np.argwhere((got != ref).any(axis=2))
+    assert bad.size == 0, f"{len(bad)} queries differ, first {bad[:3]}: got {got[tuple(bad[0])]} ref {ref[tuple(bad[0])]}"
+
+
+@pytest.mark.parametrize("mode,M,N,cols,rows", [(0, 50, 7, 1241, 376), (0, 5, 1, 1241, 376), (0, 40, 60, 60, 45), (0, 64, 200, 74, 376),
+                                                 (1, 30, 9, 1241, 376), (0, 33, 0, 1241, 376), (1, 12, 0, 640, 480)])
+def test_hamming_match_batched_sparse_and_narrow(hip_lib, mode, M, N, cols, rows):
+    """edge shapes: almost empty hash grids (most cells empty, windows whose neighbours in bin order lie rows away), grids of
+    1-3 cell columns (a window covers whole rows), a single train feature, none at all"""
+    import torch
+    rng = np.random.default_rng(100 + M + N + cols)
+    B = 4
+    td = rng.integers(0, 256, (B, max(N, 1), 32), dtype=np.uint8)[:, :N]
+    qd = rng.integers(0, 256, (B, M, 32), dtype=np.uint8)
+    txy = np.floor(rng.uniform(0, 1, (B, N, 2)) * [cols - 1, rows - 1]).astype(np.float32)
+    qxy = (rng.uniform(0, 1, (B, M, 2)) * [cols - 1, rows - 1]).astype(np.float32)
+    if N:
+        # queries on top of / right beside train features, so that windows are not all empty
+        k = min(M, N)
+        qxy[:, :k] = txy[:, rng.integers(0, N, k)] + rng.uniform(-20, 20, (B, k, 2)).astype(np.float32)
+        td[0] = td[0, 0]            # problem 0: all descriptors equal (ties -> lowest index)
+    tf = np.zeros((B, N), np.uint8)
+    if N > 3:
+        tf[1, ::3] = 1
+    ref = _hamming_ref_np(qd, qxy, td, txy, tf, 625.0, mode, rows) if N else np.tile(np.array([-1, 0x7FFFFFFF, -1, 0x7FFFFFFF], np.int32), (B, M, 1))
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    out = torch.full((B, M, 4), 7, dtype=torch.int32, device="cuda")
+    hip_lib.hamming_match_batched(t(qd), t(qxy), t(td.reshape(B, N, 32)), t(txy), t(tf), 625.0, mode, rows, cols, out)
     got = out.cpu().numpy()
     bad = np.argwhere((got != ref).any(axis=2))
     assert bad.size == 0, f"{len(bad)} queries differ, first {bad[:3]}: got {got[tuple(bad[0])]} ref {ref[tuple(bad[0])]}"

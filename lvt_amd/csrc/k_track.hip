@@ -45,8 +45,8 @@ __device__ __forceinline__ void frame_prologue(Seq &S, Ctl &c, int par, const Po
     c.mm_pending = 0;
     const FeatCtl &fc = *S.fb[par].fc;
     c.overflow = fc.overflow;
-    c.counts[C_RETRY_LEFT] = fc.retry[0];
-    c.counts[C_RETRY_RIGHT] = fc.retry[1];
+    c.counts[C_RETRY_LEFT] = active ? fc.retry[0] : 0;  // (LOST: the reference returns before it detects anything; the feature
+    c.counts[C_RETRY_RIGHT] = active ? fc.retry[1] : 0;  //  stream here has run regardless -- its results are not reported)
     if (!active) {  // LOST: return the last pose forever (lvt_system.cpp:161-166)
         pose_to_Rt(c.last_pose, c.out_R, c.out_t);
         c.out_status = 3;
@@ -1996,6 +1996,7 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, seq_t 
             pose_to_Rt(id, ctl.out_R, ctl.out_t);
             ctl.out_status = 2;
         }
+        if (!ctl.active) *S.fb[par].feat[0].n = *S.fb[par].feat[1].n = 0;  // LOST: no features as far as any caller can see
         ctl.counts[C_N_LEFT] = *S.fb[par].feat[0].n;
         ctl.counts[C_N_RIGHT] = *S.fb[par].feat[1].n;
         ctl.counts[C_MAP_SIZE] = *S.map_n;

@@ -1255,9 +1255,17 @@ struct System {
     }
 
     // track -- lvt_system.cpp:157-207
+    // LOST (lvt_system.cpp:161-166): nothing is detected or tracked; the introspection shows no features and the map as it is
+    Pose lost_frame() {
+        L = FeatureStruct();
+        R = FeatureStruct();
+        counts[LVTO_C_MAP_SIZE] = (int)map.size();
+        counts[LVTO_C_STAGED_SIZE] = (int)staged.size();
+        return last_pose;
+    }
     Pose track(const uint8_t *img1, const void *img2, int rows, int cols) {
         begin_frame();
-        if (state == 3) return last_pose;
+        if (state == 3) return lost_frame();
         FeatureStruct ls, rs;
         if (sensor == 1) {
             int r0 = 0, r1 = 0;
@@ -1281,7 +1289,7 @@ struct System {
     // track_with_external_corners -- lvt_system.cpp:209-250
     Pose track_ext(const uint8_t *l, const uint8_t *r, int rows, int cols, const double *cl, int ncl, const double *cr, int ncr) {
         begin_frame();
-        if (state == 3) return last_pose;
+        if (state == 3) return lost_frame();
         FeatureStruct ls, rs;
         compute_descriptors_only_one(l, rows, cols, cl, ncl, &ls);
         compute_descriptors_only_one(r, rows, cols, cr, ncr, &rs);

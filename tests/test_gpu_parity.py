@@ -389,3 +389,35 @@ def test_pinned_host_buffers_are_read_in_place(hip_lib):
         Rb, tb = b.track(Lp, pr.numpy())
         assert np.array_equal(ta, tb) and np.array_equal(Ra, Rb), f"frame {i}"
     assert a.counts() == b.counts() and b.last_error() == ""
+
+
+def test_featureless_and_saturated_frames(hip_lib, oracle_lib):
+    """degenerate inputs through the whole chain, stage by stage against the oracle: a black first frame (no corner, empty map,
+    the <200-corner retry on both eyes) followed by a saturated one (no match -> LOST) and one with a single bright pixel (LOST:
+    nothing is computed or reported); after a reset: a single-pixel first frame, ordinary frames, a black frame in the middle of
+    tracking (LOST again) and an ordinary one behind it"""
+    world, prm, sensor = make_case("kitti", 9, 0.5)
+    hip = hip_lib.LvtSystem.create(prm, 1)
+    orc = oracle_lib.Oracle(prm, 1)
+    H, W = world.H, world.W
+    black = np.zeros((H, W), np.uint8)
+    white = np.full((H, W), 255, np.uint8)
+    dot = black.copy(); dot[H // 2, W // 2] = 255
+
+    def run(seq, tag):
+        states = []
+        for k, (a, b) in enumerate(seq):
+            Ro, to = orc.track(a, b); Rh, th = hip.track(a, b)
+            msgs = diff_frame(hip, orc)
+            assert not msgs, f"{tag} frame {k}: {msgs[:3]}"
+            assert hip.get_state() == orc.status, f"{tag} frame {k}"
+            assert np.allclose(th, to, atol=1e-9) and np.allclose(Rh, Ro, atol=1e-9), f"{tag} frame {k}"
+            states.append(hip.get_state())
+        return states
+
+    assert run([(black, black), (white, white), (dot, dot)], "a") == [2, 3, 3]
+    hip.reset(); orc.reset()
+    st = run([(dot, dot)] + [world.render_stereo(i) for i in range(3)], "b")
+    hip.reset(); orc.reset()
+    st = run([world.render_stereo(i) for i in range(4)] + [(black, black), world.render_stereo(5)], "c")
+    assert st[:4] == [2, 2, 2, 2] and st[4:] == [3, 3]

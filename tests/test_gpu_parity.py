@@ -421,3 +421,47 @@ def test_featureless_and_saturated_frames(hip_lib, oracle_lib):
     hip.reset(); orc.reset()
     st = run([world.render_stereo(i) for i in range(4)] + [(black, black), world.render_stereo(5)], "c")
     assert st[:4] == [2, 2, 2, 2] and st[4:] == [3, 3]
+
+
+def test_handles_are_independent_across_host_threads(hip_lib):
+    """two handles driven concurrently from two host threads (ctypes releases the GIL inside the library) track exactly like the
+    same sequences run one after the other -- the reference's file-scope statics are per instance here (threading)"""
+    import threading
+    cases = [make_case("kitti", 40, 0.5), make_case("kitti", 41, 0.5)]
+    frames = [[w.render_stereo(i) for i in range(14)] for w, _, _ in cases]
+    ref = []
+    for (w, prm, _), fr in zip(cases, frames):
+        vo = hip_lib.LvtSystem.create(prm, 1)
+        ref.append([vo.track(L, R) for L, R in fr])
+    got = [None, None]
+    errs = []
+
+    def work(k):
+        try:
+            vo = hip_lib.LvtSystem.create(cases[k][1], 1)
+            got[k] = [vo.track(L, R) for L, R in frames[k]]
+            if vo.last_error():
+                errs.append(vo.last_error())
+        except Exception as e:  # noqa: BLE001
+            errs.append(repr(e))
+
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    [t.start() for t in ths]; [t.join() for t in ths]
+    assert not errs, errs
+    for k in range(2):
+        for i, ((Ra, ta), (Rb, tb)) in enumerate(zip(ref[k], got[k])):
+            assert np.array_equal(ta, tb) and np.array_equal(Ra, Rb), f"handle {k} frame {i}"
+
+
+def test_wrong_image_size_is_refused_and_reported(hip_lib):
+    """lvt_track with images of another size: outputs untouched (like the reference on an exception), an error string, and the
+    handle keeps working"""
+    world, prm, sensor = make_case("kitti", 42, 0.5)
+    vo = hip_lib.LvtSystem.create(prm, 1)
+    L, R = world.render_stereo(0)
+    R0, t0 = vo.track(L, R)
+    small = np.ascontiguousarray(L[:-2, :-3])
+    R1, t1 = vo.track(small, small)
+    assert "size" in vo.last_error()
+    R2, t2 = vo.track(*world.render_stereo(1))
+    assert vo.get_state() == 2 and np.linalg.norm(t2) > 0

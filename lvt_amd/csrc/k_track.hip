@@ -696,7 +696,12 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
         L.misc[7] = (int)(tj0 - ts1);
     }
     __syncthreads();
-    atomicMax(&L.misc[3], dbg_steps);
+    {   // (bring-up statistic: the longest list of the batch.  One LDS atomic per wavefront -- 1024 of them on one address cost
+        //  ~4k cycles of every resolver call)
+        int m = dbg_steps;
+        for (int d = 32; d >= 1; d >>= 1) m = max(m, __shfl_xor(m, d, 64));
+        if (lane_id() == 0) atomicMax(&L.misc[3], m);
+    }
 #pragma unroll
     for (int u = 0; u < 2; u++)
         if (acc[u] >= 0) {

@@ -262,22 +262,26 @@ __device__ __forceinline__ void candidates_body(Seq &S, int pass2, int par, Cand
                     }
                 }
             }
-            uint32_t key = 0;
-            if (ok) {
-                uint64_t t[4];
-#pragma unroll
-                for (int k = 0; k < 4; k++) t[k] = T.desc[(size_t)j * 4 + k];
-                key = ((uint32_t)hamming256(q.d, t) << 16) | (uint32_t)j;
-            }
+            // pass 1 only collects the indices of the candidates (ascending): fetching each candidate's descriptor inside this
+            // loop made every iteration with a hit wait for its own global round trip (~4 per query)
             const uint64_t m = __ballot(ok);
             if (ok) {
                 const int pos = cnt + __popcll(m & lt_mask);
-                if (pos < KC) buf[pos] = key;
+                if (pos < KC) buf[pos] = (uint32_t)j;
             }
             cnt += __popcll(m);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
         if (cnt <= KC) {
+            // pass 2: all descriptors of the query's candidates in one round trip (KC / 64 per lane), keys = (distance << 16 | index)
+            for (int e = lane; e < cnt; e += 64) {
+                const uint32_t j = buf[e];
+                uint64_t t[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) t[k] = T.desc[(size_t)j * 4 + k];
+                buf[e] = ((uint32_t)hamming256(q.d, t) << 16) | j;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             // rank sort (keys are unique): each lane places up to KC/64 entries
             for (int e = lane; e < cnt; e += 64) {
                 const uint32_t k = buf[e];

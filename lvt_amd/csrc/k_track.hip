@@ -196,10 +196,24 @@ __device__ __forceinline__ void candidates_body(Seq &S, int pass2, int par, Cand
     {   // PROJECT: wavefront 0 arrives late (its thread 0 ran the frame prologue), the other waves stage the train data meanwhile
         const int t0 = PROJECT ? (int)threadIdx.x - 64 : (int)threadIdx.x, tn = PROJECT ? nthreads - 64 : nthreads;
         if (t0 >= 0)
-            for (int j = t0; j < N; j += tn) {
-                s_tx[j] = T.x[j];
-                s_ty[j] = T.y[j];
-                if (MODE != MODE_ROW) s_tc[j] = ((uint32_t)(uint16_t)T.hcy[j] << 16) | (uint32_t)(uint16_t)T.hcx[j];
+            for (int j0 = t0; j0 < N; j0 += 4 * tn) {  // four features per thread and trip: all their loads are in flight together
+                float vx[4], vy[4];
+                int16_t cy[4], cx[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int j = min(j0 + k * tn, N - 1);
+                    vx[k] = T.x[j], vy[k] = T.y[j];
+                    if (MODE != MODE_ROW) cy[k] = T.hcy[j], cx[k] = T.hcx[j];
+                }
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int j = j0 + k * tn;
+                    if (j < N) {
+                        s_tx[j] = vx[k];
+                        s_ty[j] = vy[k];
+                        if (MODE != MODE_ROW) s_tc[j] = ((uint32_t)(uint16_t)cy[k] << 16) | (uint32_t)(uint16_t)cx[k];
+                    }
+                }
             }
     }
     __syncthreads();
@@ -246,18 +260,32 @@ __device__ __forceinline__ void candidates_body(Seq &S, int pass2, int par, Cand
 #pragma unroll
         for (int k = 0; k < 4; k++) q.d[k] = (i == wave0) ? qd0[k] : qdesc[(size_t)i * 4 + k];
         int cnt = 0;
+        // the train data of the NEXT 64 features is read while the current ones are tested: with a dependent LDS read, a
+        // conditional second one and the ballot in every iteration the 16 iterations ran at ~550 cycles each (LDS latency)
+        uint32_t c_n = 0;
+        float x_n = 0.f, y_n = 0.f;
+        {
+            const int j0 = min(lane, NF_MAX - 1);
+            y_n = s_ty[j0];
+            if (MODE != MODE_ROW) c_n = s_tc[j0], x_n = s_tx[j0];
+        }
         for (int base = 0; base < N; base += 64) {
             const int j = base + lane;
+            const uint32_t c = c_n;
+            const float fx = x_n, fy = y_n;
+            {
+                const int jn = min(j + 64, NF_MAX - 1);  // (past N: stale or unwritten entries, never used)
+                y_n = s_ty[jn];
+                if (MODE != MODE_ROW) c_n = s_tc[jn], x_n = s_tx[jn];
+            }
             bool ok = false;
             if (j < N) {
                 if (MODE == MODE_ROW) {
-                    const float fy = s_ty[j];
                     ok = fy >= (float)q.sy && fy <= (float)q.ey;
                 } else {
-                    const uint32_t c = s_tc[j];
                     const int cy = (int)(int16_t)(c >> 16), cx = (int)(int16_t)(c & 0xFFFFu);
                     if (cy >= q.sy && cy < q.ey && cx >= q.sx && cx < q.ex) {
-                        const float dx = s_tx[j] - q.x, dy = s_ty[j] - q.y;
+                        const float dx = fx - q.x, dy = fy - q.y;
                         ok = (dx * dx + dy * dy) < q.r2;
                     }
                 }

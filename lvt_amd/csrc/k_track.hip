@@ -24,11 +24,28 @@ namespace lvt {
 
 enum : int { MODE_MAP = 0, MODE_STAGED = 1, MODE_ROW = 2 };
 
+// A sequence's descriptor reaches the kernels of the early and tracking chains either BY VALUE (single sequence: its fields are
+// kernel arguments, fetched with the kernel's own argument load) or as an element of the device array (lock-step batch: one more
+// dependent memory hop at every kernel head).  These kernels never read the per-frame mutable fields of Seq (FrameBuf::img ...),
+// which only the feature stage writes and reads.
+template <bool BYVAL>
+struct SeqArg;
+template <>
+struct SeqArg<false> {
+    const Seq *p;
+    __device__ __forceinline__ const Seq &get() const { return p[blockIdx.z]; }
+};
+template <>
+struct SeqArg<true> {
+    Seq v;
+    __device__ __forceinline__ const Seq &get() const { return v; }
+};
+
 // =================================================================================================
 // frame prologue (the head of lvt_system::track, lvt_system.cpp:157-167,196-197), evaluated by k_match_map.  The motion
 // model's next state goes to a shadow (mm_next) committed by k_track_mid.
 // =================================================================================================
-__device__ __forceinline__ void frame_prologue(Seq &S, Ctl &c, int par, const Pose &predicted, const double mm_next[14], bool active,
+__device__ __forceinline__ void frame_prologue(const Seq &S, Ctl &c, int par, const Pose &predicted, const double mm_next[14], bool active,
                                                bool first) {
     for (int i = 0; i < N_COUNTS; i++) c.counts[i] = 0;
     c.counts[C_FRAME] = c.frame_number;
@@ -60,7 +77,7 @@ __device__ __forceinline__ void frame_prologue(Seq &S, Ctl &c, int par, const Po
 }
 
 // staged points are projected with the optimised pose in the tail of k_pnp
-__device__ __forceinline__ void project_staged(Seq &S, const Pose &pose, double *w2c_lds) {
+__device__ __forceinline__ void project_staged(const Seq &S, const Pose &pose, double *w2c_lds) {
     if (threadIdx.x == 0) world_to_camera(pose, w2c_lds);
     __syncthreads();
     const int M = *S.staged_n;
@@ -78,7 +95,7 @@ __device__ __forceinline__ void project_staged(Seq &S, const Pose &pose, double 
 }
 
 // map SoA copy helper
-__device__ __forceinline__ void copy_point(const MapSoA &src, int i, MapSoA &dst, int o) {
+__device__ __forceinline__ void copy_point(const MapSoA &src, int i, const MapSoA &dst, int o) {
     dst.pos[3 * o] = src.pos[3 * i];
     dst.pos[3 * o + 1] = src.pos[3 * i + 1];
     dst.pos[3 * o + 2] = src.pos[3 * i + 2];
@@ -151,7 +168,7 @@ struct CandLds {
 // PROJECT (map mode, pass 1): the wavefront first projects its map point with the predicted pose (is_point_visible,
 // lvt_local_map.cpp:62-82,152-156) and records the projection for the rest of the chain.
 template <int MODE, bool PROJECT = false>
-__device__ __forceinline__ void candidates_body(Seq &S, int pass2, int par, CandLds &C, int wave0, int wave_stride, int nthreads, int q_begin = 0,
+__device__ __forceinline__ void candidates_body(const Seq &S, int pass2, int par, CandLds &C, int wave0, int wave_stride, int nthreads, int q_begin = 0,
                                                 int q_end = -1) {
     uint32_t *s_tc = C.tc;
     float *s_tx = C.tx, *s_ty = C.ty;
@@ -222,7 +239,7 @@ __device__ __forceinline__ void candidates_body(Seq &S, int pass2, int par, Cand
     for (int i = wave0; i < M; i += wave_stride) {
         Query q;
         if (MODE == MODE_MAP && PROJECT) {
-            MapSoA &P = S.map[*S.map_cur];
+            const MapSoA &P = S.map[*S.map_cur];
             double X[3] = {X0[0], X0[1], X0[2]};
             if (i != wave0) X[0] = P.pos[3 * i], X[1] = P.pos[3 * i + 1], X[2] = P.pos[3 * i + 2];
             double u, v;
@@ -325,9 +342,9 @@ __device__ __forceinline__ void candidates_body(Seq &S, int pass2, int par, Cand
 
 // need_seq (row mode on the early stream): the lists are only built from COMPLETE features (the stream's gate may have given up
 // waiting for them; then k_row_done does not publish either and k_triangulate reports the frame as lost)
-template <int MODE>
-__global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2, int par, seq_t need_seq) {
-    Seq &S = seqs[blockIdx.z];
+template <int MODE, bool BV>
+__global__ __launch_bounds__(256) void k_candidates(SeqArg<BV> sa, int pass2, int par, seq_t need_seq) {
+    const Seq &S = sa.get();
     if (MODE != MODE_ROW) {
         const Ctl &ctl = *S.ctl;
         if (!ctl.active || ctl.first_frame) return;
@@ -347,9 +364,10 @@ __global__ __launch_bounds__(256) void k_candidates(Seq *seqs, int pass2, int pa
 // k_match_map : frame prologue + projection of the map points + their candidate lists (find_matches pass 1).  Every block
 // derives the per-frame facts it needs (active / first frame / predicted pose) from the PERSISTENT part of Ctl, which
 // nobody writes during this kernel; block 0 additionally publishes them for the rest of the chain.
-__global__ __launch_bounds__(256) void k_match_map(Seq *seqs, int par, seq_t seq) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[40] = (long long)wall_clock64();
-    Seq &S = seqs[blockIdx.z];
+template <bool BV>
+__global__ __launch_bounds__(256) void k_match_map(SeqArg<BV> sa, int par, seq_t seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) sa.get().ctl->dbg[40] = (long long)wall_clock64();
+    const Seq &S = sa.get();
     Ctl &ctl = *S.ctl;
     const int state = ctl.state;  // persistent; not written by this kernel
     const bool active = (state != 3), first = (state == 1);
@@ -419,10 +437,11 @@ __global__ void k_row_done(Seq *seqs, int par, seq_t seq) {
     atomicExch(&fc.row_seq, seq);
 }
 
-__global__ __launch_bounds__(64) void k_gate(Seq *seqs, int par, seq_t want, seq_t seq) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[32] = (long long)wall_clock64();
-    Ctl &ctl = *seqs[blockIdx.z].ctl;
-    FeatCtl &fc = *seqs[blockIdx.z].fb[par].fc;
+template <bool BV>
+__global__ __launch_bounds__(64) void k_gate(SeqArg<BV> sa, int par, seq_t want, seq_t seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) sa.get().ctl->dbg[32] = (long long)wall_clock64();
+    Ctl &ctl = *sa.get().ctl;
+    FeatCtl &fc = *sa.get().fb[par].fc;
     if (threadIdx.x != 0) return;
     bool ok = true;
     {
@@ -469,9 +488,10 @@ __global__ __launch_bounds__(64) void k_gate(Seq *seqs, int par, seq_t want, seq
     ctl.dbg[33] = (long long)wall_clock64();
 }
 
-__global__ __launch_bounds__(256) void k_early_map(Seq *seqs, int par, seq_t seq) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[34] = (long long)wall_clock64();
-    Seq &S = seqs[blockIdx.z];
+template <bool BV>
+__global__ __launch_bounds__(256) void k_early_map(SeqArg<BV> sa, int par, seq_t seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) sa.get().ctl->dbg[34] = (long long)wall_clock64();
+    const Seq &S = sa.get();
     Ctl &ctl = *S.ctl;
     const int n_early = (ctl.gate_ok == seq) ? ctl.early_done : 0;
     if (n_early <= 0) return;  // first frame, LOST, the previous frame did not reach its pose refinement, or the gate timed out
@@ -757,7 +777,7 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
 template <int MODE>
 // phase 0: all queries; phase 1 (map mode, "early"): queries [0, q_split) only, no per-frame bookkeeping; phase 2 ("late"): queries
 // [q_split, M), continuing from the marks and the match count phase 1 left behind
-__device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int par, ResolveLds &L, uint32_t *r_tab, int phase = 0, int q_split = 0) {
+__device__ __forceinline__ void resolve_body(const Seq &S, Ctl &ctl, int pass2, int par, ResolveLds &L, uint32_t *r_tab, int phase = 0, int q_split = 0) {
     const int tid = threadIdx.x;
     const long long tk0 = clock64();
     const Feat &T = (MODE == MODE_ROW) ? S.fb[par].feat[1] : S.fb[par].feat[0];
@@ -889,10 +909,10 @@ __device__ __forceinline__ void resolve_body(Seq &S, Ctl &ctl, int pass2, int pa
 // =================================================================================================
 // bookkeeping of find_matches + LOST decision : lvt_local_map.cpp:201-224 + lvt_system.cpp:266-274
 // =================================================================================================
-__device__ __forceinline__ void bookkeep_body(Seq &S, Ctl &ctl, int par, int *scan) {
+__device__ __forceinline__ void bookkeep_body(const Seq &S, Ctl &ctl, int par, int *scan) {
     const int tid = threadIdx.x;
     const int M = *S.map_n;
-    MapSoA &P = S.map[*S.map_cur];
+    const MapSoA &P = S.map[*S.map_cur];
     const Feat &F = S.fb[par].feat[0];
     int n_out = 0;
     for (int base = 0; base < M; base += RES_THREADS) {
@@ -935,10 +955,10 @@ __device__ __forceinline__ void bookkeep_body(Seq &S, Ctl &ctl, int par, int *sc
 
 // clean_untracked_points (lvt_local_map.cpp:393-413): stable compaction into the other buffer.  It does not depend
 // on the pose, so it runs here, ahead of the pose refinement (the reference runs it right after).
-__device__ __forceinline__ void cull_body(Seq &S, Ctl &ctl, int par, int *scan) {
+__device__ __forceinline__ void cull_body(const Seq &S, Ctl &ctl, int par, int *scan) {
     const int tid = threadIdx.x;
     const int cur = *S.map_cur, M = *S.map_n;
-    MapSoA &A = S.map[cur], &B = S.map[cur ^ 1];
+    const MapSoA &A = S.map[cur], &B = S.map[cur ^ 1];
     const int th = S.prm.untracked_th;
     int n_out = 0;
     for (int base = 0; base < M; base += RES_THREADS) {
@@ -965,10 +985,10 @@ __device__ __forceinline__ void cull_body(Seq &S, Ctl &ctl, int par, int *scan) 
 // KITTI sequence holds ~800): every field of a point is loaded once (independent loads: one memory round trip), both
 // compactions (PnP input = matched points, surviving map = counter < untracked_th) come from one packed scan, and the
 // survivors go straight to the other map buffer.  Returns true when the frame is LOST (block-uniform).
-__device__ __forceinline__ bool bookkeep_cull_small(Seq &S, Ctl &ctl, int par, int *scan) {
+__device__ __forceinline__ bool bookkeep_cull_small(const Seq &S, Ctl &ctl, int par, int *scan) {
     const int tid = threadIdx.x;
     const int cur = *S.map_cur, M = *S.map_n;
-    MapSoA &A = S.map[cur], &B = S.map[cur ^ 1];
+    const MapSoA &A = S.map[cur], &B = S.map[cur ^ 1];
     const Feat &F = S.fb[par].feat[0];
     const int th = S.prm.untracked_th;
     const int i = tid;
@@ -1041,9 +1061,10 @@ __device__ __forceinline__ bool bookkeep_cull_small(Seq &S, Ctl &ctl, int par, i
 // =================================================================================================
 // k_track_mid : find_matches pass 1 [+ second pass, if pass 1 found < 50] + bookkeeping + LOST decision + cull
 // =================================================================================================
-__global__ __launch_bounds__(RES_THREADS) void k_track_mid(Seq *seqs, int par, seq_t seq) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[42] = (long long)wall_clock64();
-    Seq &S = seqs[blockIdx.z];
+template <bool BV>
+__global__ __launch_bounds__(RES_THREADS) void k_track_mid(SeqArg<BV> sa, int par, seq_t seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) sa.get().ctl->dbg[42] = (long long)wall_clock64();
+    const Seq &S = sa.get();
     Ctl &ctl = *S.ctl;
     if (!ctl.active) return;
     if (threadIdx.x == 0 && ctl.mm_pending) {  // commit the motion model state shadowed by the prologue
@@ -1085,9 +1106,10 @@ __global__ __launch_bounds__(RES_THREADS) void k_track_mid(Seq *seqs, int par, s
 
 // k_early_mid : the greedy resolution of find_matches for the map points [0, early_done) (storage order: their decisions do
 // not depend on the points the previous frame is still appending), on the early stream behind k_early_map
-__global__ __launch_bounds__(RES_THREADS) void k_early_mid(Seq *seqs, int par, seq_t seq) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[36] = (long long)wall_clock64();
-    Seq &S = seqs[blockIdx.z];
+template <bool BV>
+__global__ __launch_bounds__(RES_THREADS) void k_early_mid(SeqArg<BV> sa, int par, seq_t seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) sa.get().ctl->dbg[36] = (long long)wall_clock64();
+    const Seq &S = sa.get();
     Ctl &ctl = *S.ctl;
     const int n_early = (ctl.gate_ok == seq) ? ctl.early_done : 0;
     if (n_early > 0) {
@@ -1125,10 +1147,11 @@ __global__ __launch_bounds__(64) void k_deliver(Seq *seqs, Ctl *rec_out, seq_t *
     deliver_record(*seqs[blockIdx.z].ctl, rec_out + blockIdx.z, done_out + blockIdx.z, seq, 64);
 }
 
-__global__ __launch_bounds__(64) void k_gate_late(Seq *seqs, int par, seq_t seq, Ctl *prev_rec, seq_t *prev_done) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[38] = (long long)wall_clock64();
-    Ctl &ctl = *seqs[blockIdx.z].ctl;
-    FeatCtl &fc = *seqs[blockIdx.z].fb[par].fc;
+template <bool BV>
+__global__ __launch_bounds__(64) void k_gate_late(SeqArg<BV> sa, int par, seq_t seq, Ctl *prev_rec, seq_t *prev_done) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) sa.get().ctl->dbg[38] = (long long)wall_clock64();
+    Ctl &ctl = *sa.get().ctl;
+    FeatCtl &fc = *sa.get().fb[par].fc;
     if (prev_rec) deliver_record(ctl, prev_rec + blockIdx.z, prev_done + blockIdx.z, seq - 1, 64);  // the previous frame's result
     if (threadIdx.x != 0) return;
     unsigned long long t0 = wall_clock64();
@@ -1644,9 +1667,10 @@ __device__ __forceinline__ void pnp_solve(const Params &prm, const Pose &prior, 
         pnp_run(prm, prior, X, obs, err, err + 2 * (size_t)n, level, n, sh, red, res, inliers, calls, dbg);  // the caller allocates 2 n + 2 doubles
 }
 
-__global__ __launch_bounds__(PNP_THREADS) void k_pnp(Seq *seqs, int par, seq_t seq) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) seqs[blockIdx.z].ctl->dbg[44] = (long long)wall_clock64();
-    Seq &S = seqs[blockIdx.z];
+template <bool BV>
+__global__ __launch_bounds__(PNP_THREADS) void k_pnp(SeqArg<BV> sa, int par, seq_t seq) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) sa.get().ctl->dbg[44] = (long long)wall_clock64();
+    const Seq &S = sa.get();
     Ctl &ctl = *S.ctl;
     if (!ctl.active || ctl.first_frame || ctl.lost_now) {
         if (threadIdx.x == 0) {  // nothing for the next frame to start on (early_done is 0), but its gate must not wait
@@ -1705,14 +1729,14 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp_standalone(Params prm, Pose
 // destinations come from two prefix sums.
 // =================================================================================================
 // (runs at the head of k_triangulate: both are single-workgroup stages of 1024 threads, a kernel boundary between them bought nothing)
-__device__ __forceinline__ void staged_body(Seq &S, Ctl &ctl, int par, ResolveLds &L, uint32_t *r_tab) {
+__device__ __forceinline__ void staged_body(const Seq &S, Ctl &ctl, int par, ResolveLds &L, uint32_t *r_tab) {
     const int tid = threadIdx.x;
     if (!ctl.first_frame && S.prm.staged_th > 0) {
         const Feat &T = S.fb[par].feat[0];
         const int N = *T.n;
         const int scur = *S.staged_cur, SM = *S.staged_n;
-        MapSoA &A = S.staged[scur], &B = S.staged[scur ^ 1];
-        MapSoA &MP = S.map[*S.map_cur];
+        const MapSoA &A = S.staged[scur], &B = S.staged[scur ^ 1];
+        const MapSoA &MP = S.map[*S.map_cur];
         if (SM > 0) {  // nothing staged (most frames): nothing to match, promote or compact
         for (int j = tid; j < NF_MAX; j += RES_THREADS) {
             const uint8_t f = (j < N) ? T.flag[j] : 0;
@@ -1910,8 +1934,9 @@ __device__ bool triangulate_pair(const Params &p, const double *cml, const doubl
     return true;
 }
 
-__global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, seq_t seq, Ctl *rec_out, seq_t *done_out, int row_gated, int deliver) {
-    Seq &S = seqs[blockIdx.z];
+template <bool BV>
+__global__ __launch_bounds__(1024) void k_triangulate(SeqArg<BV> sa, int par, seq_t seq, Ctl *rec_out, seq_t *done_out, int row_gated, int deliver) {
+    const Seq &S = sa.get();
     Ctl &ctl = *S.ctl;
     __shared__ double cml[12], cmr[12], R[9];
     __shared__ Pose cam;
@@ -1969,7 +1994,7 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, seq_t 
     const int n_in = rgbd ? *FL.n : n_pairs;
     // destination: lvt_local_map.cpp:345 (decided once, before anything is appended)
     const bool to_map = ctl.dont_stage || S.prm.staged_th == 0 || (*S.map_n < N_MAP_POINTS);
-    MapSoA &D = to_map ? S.map[*S.map_cur] : S.staged[*S.staged_cur];
+    const MapSoA &D = to_map ? S.map[*S.map_cur] : S.staged[*S.staged_cur];
     const int d_n0 = to_map ? *S.map_n : *S.staged_n;
     const int d_cap = to_map ? MAP_MAX : STAGED_MAX;
     int n_out = 0;
@@ -2054,8 +2079,5 @@ __global__ __launch_bounds__(1024) void k_triangulate(Seq *seqs, int par, seq_t 
 }
 
 // explicit instantiations used by the host
-template __global__ void k_candidates<MODE_MAP>(Seq *, int, int, seq_t);
-template __global__ void k_candidates<MODE_STAGED>(Seq *, int, int, seq_t);
-template __global__ void k_candidates<MODE_ROW>(Seq *, int, int, seq_t);
 
 }  // namespace lvt

@@ -421,7 +421,8 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
         HIPCHK(c, hipMemcpy(c->d_seqs, c->h_seqs.data(), sizeof(Seq) * B, hipMemcpyHostToDevice));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       CELLS_LDS_BYTES));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pnp), hipFuncAttributeMaxDynamicSharedMemorySize, PNP_DYN_BYTES));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pnp<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PNP_DYN_BYTES));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pnp<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PNP_DYN_BYTES));
         reset_state(c);
     } catch (...) {
         delete c;
@@ -445,6 +446,18 @@ static const char *kProfNames[Context::PROF_SLOTS] = {
             (void)hipEventRecord(c->ev[slot][1], st);                              \
             c->ev_used[slot] = true;                                               \
         }                                                                          \
+    } while (0)
+
+// kernels of the early / tracking chains: a single sequence travels BY VALUE in the kernel arguments (k_track.hip, SeqArg)
+#define LAUNCH_S(slot, st, kern, grid, block, lds, ...)                                                      \
+    do {                                                                                                     \
+        if (B == 1) LAUNCH(slot, st, kern<true>, grid, block, lds, SeqArg<true>{c->h_seqs[0]}, __VA_ARGS__); \
+        else LAUNCH(slot, st, kern<false>, grid, block, lds, SeqArg<false>{S}, __VA_ARGS__);                  \
+    } while (0)
+#define LAUNCH_SM(slot, st, kern, MODE_, grid, block, lds, ...)                                                        \
+    do {                                                                                                               \
+        if (B == 1) LAUNCH(slot, st, (kern<MODE_, true>), grid, block, lds, SeqArg<true>{c->h_seqs[0]}, __VA_ARGS__);   \
+        else LAUNCH(slot, st, (kern<MODE_, false>), grid, block, lds, SeqArg<false>{S}, __VA_ARGS__);                   \
     } while (0)
 
 static void collect_oldest(Context *c);
@@ -487,7 +500,7 @@ static void enqueue_frame(Context *c) {
     }
     LAUNCH(5, sf, k_gather, dim3(1, 2, B), dim3(1024), 0, S, par);
     LAUNCH(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, S, par);
-    if (evo) LAUNCH(18, sf, k_candidates<MODE_ROW>, dim3(256, 1, B), dim3(256), 0, S, 0, par, (seq_t)0);  // (normal mode: on the early stream, below)
+    if (evo) LAUNCH_SM(18, sf, k_candidates, MODE_ROW, dim3(256, 1, B), dim3(256), 0, 0, par, (seq_t)0);  // (normal mode: on the early stream, below)
     hipLaunchKernelGGL(k_feat_done, dim3(B), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));
     if (evo) (void)hipEventRecord(c->ev_feat[par], sf);
     // ---- early stream: projection, candidate lists and greedy resolution of the map points that survived the previous frame,
@@ -495,14 +508,14 @@ static void enqueue_frame(Context *c) {
     const seq_t seq = (seq_t)(c->enq + 1);  // this frame's sequence number; the previous frame's is enq (0: none)
     if (!evo) {
         hipStream_t se = c->stream_e;
-        LAUNCH(1, se, k_gate, dim3(1, 1, B), dim3(64), 0, S, par, (seq_t)c->enq, seq);  // polls the previous k_pnp and this frame's features
-        LAUNCH(9, se, k_early_map, dim3(256, 1, B), dim3(256), 0, S, par, seq);
-        LAUNCH(10, se, k_early_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par, seq);
+        LAUNCH_S(1, se, k_gate, dim3(1, 1, B), dim3(64), 0, par, (seq_t)c->enq, seq);  // polls the previous k_pnp and this frame's features
+        LAUNCH_S(9, se, k_early_map, dim3(256, 1, B), dim3(256), 0, par, seq);
+        LAUNCH_S(10, se, k_early_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, par, seq);
         if (c->sensor == 1) {
             // row-match candidate lists of THIS frame (needed by its k_triangulate, ~70 us from here): they need the two feature
             // sets only, and the feature stream is the longest chain -- here, behind the early part, they lengthen neither it nor
             // the hand-over to the tracking stream.  Few workgroups: the tracking chain's single-workgroup kernels run meanwhile.
-            LAUNCH(18, se, k_candidates<MODE_ROW>, dim3(B == 1 ? ROW_BLOCKS : ROW_BLOCKS_BATCH, 1, B), dim3(256), 0, S, 0, par, seq);
+            LAUNCH_SM(18, se, k_candidates, MODE_ROW, dim3(B == 1 ? ROW_BLOCKS : ROW_BLOCKS_BATCH, 1, B), dim3(256), 0, 0, par, seq);
             hipLaunchKernelGGL(k_row_done, dim3(B), dim3(64), 0, se, S, par, seq);
         }
     }
@@ -520,14 +533,14 @@ static void enqueue_frame(Context *c) {
             prec = c->h_ctl_dev + (size_t)pslot * B, pdone = c->h_done_dev + (size_t)pslot * B;
             c->delivered = c->enq;
         }
-        LAUNCH(7, st, k_gate_late, dim3(1, 1, B), dim3(64), 0, S, par, seq, prec, pdone);
+        LAUNCH_S(7, st, k_gate_late, dim3(1, 1, B), dim3(64), 0, par, seq, prec, pdone);
     }
-    LAUNCH(8, st, k_match_map, dim3(256, 1, B), dim3(256), 0, S, par, seq);
-    LAUNCH(12, st, k_track_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, S, par, seq);
-    LAUNCH(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), PNP_DYN_BYTES, S, par, seq);
+    LAUNCH_S(8, st, k_match_map, dim3(256, 1, B), dim3(256), 0, par, seq);
+    LAUNCH_S(12, st, k_track_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, par, seq);
+    LAUNCH_S(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), PNP_DYN_BYTES, par, seq);
     if (p.staged_th > 0)  // (a configuration without staging -- EuRoC, TUM -- never has staged points to list)
-        LAUNCH(16, st, k_candidates<MODE_STAGED>, dim3(64, 1, B), dim3(256), 0, S, 0, par, (seq_t)0);
-    LAUNCH(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, S, par, seq, c->h_ctl_dev + (size_t)slot * B,
+        LAUNCH_SM(16, st, k_candidates, MODE_STAGED, dim3(64, 1, B), dim3(256), 0, 0, par, (seq_t)0);
+    LAUNCH_S(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, par, seq, c->h_ctl_dev + (size_t)slot * B,
            c->h_done_dev + (size_t)slot * B, evo ? 0 : 1, (evo || c->sync_call) ? 1 : 0);
     if (evo || c->sync_call) c->delivered = c->enq + 1;
     if (evo) (void)hipEventRecord(c->ev_done[slot], st);  // (events-only ordering: the feature stream's barrier needs it)

@@ -361,15 +361,30 @@ __global__ __launch_bounds__(256) void k_candidates(SeqArg<BV> sa, int pass2, in
     candidates_body<MODE>(S, pass2, par, C, blockIdx.x * 4 + wave_id(), gridDim.x * 4, 256);
 }
 
+__device__ __forceinline__ void deliver_record(const Ctl &ctl, Ctl *rec_out, seq_t *done_out, seq_t seq, int nthreads);
+__device__ __forceinline__ void gate_late_poll(Ctl &ctl, FeatCtl &fc, seq_t seq);
 // k_match_map : frame prologue + projection of the map points + their candidate lists (find_matches pass 1).  Every block
 // derives the per-frame facts it needs (active / first frame / predicted pose) from the PERSISTENT part of Ctl, which
 // nobody writes during this kernel; block 0 additionally publishes them for the rest of the chain.
 template <bool BV>
-__global__ __launch_bounds__(256) void k_match_map(SeqArg<BV> sa, int par, seq_t seq) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) sa.get().ctl->dbg[40] = (long long)wall_clock64();
+// gated (single sequence, polling mode: launched with 32 workgroups -- it only has the points appended since the early part to
+// list): the wait for the early stream happens HERE instead of in a k_gate_late launch of its own, and workgroup 0 first delivers
+// the previous frame's record.  32 spinning workgroups leave 224 CUs untouched for whatever they wait for (k_cells needs 20 CUs
+// with free LDS; with 256 workgroups this deadlocked the synchronous mode until the time-out); a lock-step batch, whose grid
+// would cover the chip again, keeps the separate gate kernel.
+__global__ __launch_bounds__(256) void k_match_map(SeqArg<BV> sa, int par, seq_t seq, int gated, Ctl *prev_rec, seq_t *prev_done) {
     const Seq &S = sa.get();
     Ctl &ctl = *S.ctl;
-    const int state = ctl.state;  // persistent; not written by this kernel
+    __shared__ int s_state;
+    if (gated) {
+        if (threadIdx.x == 0 && blockIdx.x == 0) ctl.dbg[38] = (long long)wall_clock64();  // (timeline: the wait starts)
+        if (blockIdx.x == 0 && prev_rec) deliver_record(ctl, prev_rec, prev_done, seq - 1, 256);
+        if (threadIdx.x == 0) gate_late_poll(ctl, *S.fb[par].fc, seq);
+    }
+    if (threadIdx.x == 0 && blockIdx.x == 0) ctl.dbg[40] = (long long)wall_clock64();  // (timeline: the frame's work starts)
+    if (threadIdx.x == 0) s_state = ctl.state;  // persistent; not written by this kernel (but for the gate's "features never arrived")
+    __syncthreads();
+    const int state = s_state;
     const bool active = (state != 3), first = (state == 1);
     __shared__ double w2c[12];
     if (threadIdx.x == 0) {
@@ -1147,13 +1162,8 @@ __global__ __launch_bounds__(64) void k_deliver(Seq *seqs, Ctl *rec_out, seq_t *
     deliver_record(*seqs[blockIdx.z].ctl, rec_out + blockIdx.z, done_out + blockIdx.z, seq, 64);
 }
 
-template <bool BV>
-__global__ __launch_bounds__(64) void k_gate_late(SeqArg<BV> sa, int par, seq_t seq, Ctl *prev_rec, seq_t *prev_done) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) sa.get().ctl->dbg[38] = (long long)wall_clock64();
-    Ctl &ctl = *sa.get().ctl;
-    FeatCtl &fc = *sa.get().fb[par].fc;
-    if (prev_rec) deliver_record(ctl, prev_rec + blockIdx.z, prev_done + blockIdx.z, seq - 1, 64);  // the previous frame's result
-    if (threadIdx.x != 0) return;
+// the tracking stream's wait for the early stream (one thread; see k_gate_late / k_match_map)
+__device__ __forceinline__ void gate_late_poll(Ctl &ctl, FeatCtl &fc, seq_t seq) {
     unsigned long long t0 = wall_clock64();
     for (;;) {
         const seq_t cur = __hip_atomic_load(&ctl.early_state, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
@@ -1176,6 +1186,15 @@ __global__ __launch_bounds__(64) void k_gate_late(SeqArg<BV> sa, int par, seq_t 
             break;
         }
     }
+}
+
+template <bool BV>
+__global__ __launch_bounds__(64) void k_gate_late(SeqArg<BV> sa, int par, seq_t seq, Ctl *prev_rec, seq_t *prev_done) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) sa.get().ctl->dbg[38] = (long long)wall_clock64();
+    Ctl &ctl = *sa.get().ctl;
+    FeatCtl &fc = *sa.get().fb[par].fc;
+    if (prev_rec) deliver_record(ctl, prev_rec + blockIdx.z, prev_done + blockIdx.z, seq - 1, 64);  // the previous frame's result
+    if (threadIdx.x == 0) gate_late_poll(ctl, fc, seq);
 }
 
 // =================================================================================================

@@ -42,6 +42,7 @@ constexpr int EXT_MAX = 16384;
 // rate -- they share SIMDs and LDS with the single-workgroup kernels of the tracking chain running beside them; 16 make the kernel
 // itself too slow (measured: 24 / 32 / 40 / 48 / 64 / 256 -> 8 180 / 8 330 / 8 320 / 8 270 / 8 240 / 7 840 frames/s)
 constexpr int ROW_BLOCKS = 32;
+constexpr int MATCH_BLOCKS_GATED = 32;  // k_match_map when it polls for the early stream itself (single sequence): see k_track.hip
 constexpr int ROW_BLOCKS_BATCH = 16;  // per sequence of a lock-step batch (16 sequences: 8 / 16 / 32 / 64 / 256 -> 30.8k / 36.9k / 35.8k / 35.0k / 31.1k frames/s)
 constexpr int RING = 8;  // frames that may be in flight / un-collected
 
@@ -522,20 +523,26 @@ static void enqueue_frame(Context *c) {
     // ---- tracking chain (stream): strictly ordered frame after frame
     // (no barrier on the features here: k_gate_late returns only after the early stream's gate has seen them complete, and
     //  every barrier / event packet costs this stream 3-4 us per frame)
-    if (evo)
-        (void)hipStreamWaitEvent(st, c->ev_feat[par], 0);  // (the early stream never claims the frame: early_ran_seq stays behind)
-    else
-    {   // the early stream is done with this frame (polled, no barrier packet); also delivers the previous frame's record if nobody has
+    {
+        // the previous frame's record, if nobody has been asked to deliver it yet
         Ctl *prec = nullptr;
         seq_t *pdone = nullptr;
-        if (c->delivered < c->enq) {
+        if (!evo && c->delivered < c->enq) {
             const int pslot = (int)((c->enq - 1) % RING);
             prec = c->h_ctl_dev + (size_t)pslot * B, pdone = c->h_done_dev + (size_t)pslot * B;
             c->delivered = c->enq;
         }
-        LAUNCH_S(7, st, k_gate_late, dim3(1, 1, B), dim3(64), 0, par, seq, prec, pdone);
+        if (evo) {
+            (void)hipStreamWaitEvent(st, c->ev_feat[par], 0);  // (the early stream never claims the frame: early_ran_seq stays behind)
+            LAUNCH_S(8, st, k_match_map, dim3(256, 1, B), dim3(256), 0, par, seq, 0, (Ctl *)nullptr, (seq_t *)nullptr);
+        } else if (B == 1) {
+            // one launch: delivers the record, waits for the early stream (polled, no barrier packet), lists the points appended since
+            LAUNCH_S(8, st, k_match_map, dim3(MATCH_BLOCKS_GATED, 1, 1), dim3(256), 0, par, seq, 1, prec, pdone);
+        } else {
+            LAUNCH_S(7, st, k_gate_late, dim3(1, 1, B), dim3(64), 0, par, seq, prec, pdone);
+            LAUNCH_S(8, st, k_match_map, dim3(256, 1, B), dim3(256), 0, par, seq, 0, (Ctl *)nullptr, (seq_t *)nullptr);
+        }
     }
-    LAUNCH_S(8, st, k_match_map, dim3(256, 1, B), dim3(256), 0, par, seq);
     LAUNCH_S(12, st, k_track_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, par, seq);
     LAUNCH_S(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), PNP_DYN_BYTES, par, seq);
     if (p.staged_th > 0)  // (a configuration without staging -- EuRoC, TUM -- never has staged points to list)

@@ -199,12 +199,12 @@ def main():
                 "k_candidates(staged)": 0.0,
                 "k_pnp": counts["n_matches"] * 32.0 + 56.0,
             }
-            # (the gate kernels only wait for another stream: their event time is waiting, not work)
-            work = [x for x in prof if "k_gate" not in x[0]]
+            # (the gate kernels -- and k_match_map's head for a single sequence -- wait for another stream: their event time is mostly waiting)
+            work = [x for x in prof if "k_gate" not in x[0] and "wait for" not in x[0]]
             tot = sum(ms for _, ms, _ in work)
             for name, ms, calls in prof:
                 if calls:
-                    gate = "k_gate" in name
+                    gate = "k_gate" in name or "wait for" in name
                     kernels.append({"kernel": name, "avg_us": round(1e3 * ms / calls, 3), "share": None if gate else round(ms / tot, 4)})
             # the frame period is the tracking stream's chain (the feature and early streams run beside it): its longest kernel
             chain = [x for x in work if x[0].startswith(("k_match_map", "k_track_mid", "k_pnp", "k_candidates(staged)", "k_triangulate"))]

@@ -5,7 +5,8 @@
 //   k_gate / k_gate_buf / k_gate_late / k_feat_done / k_row_done : the polling hand-over between the streams
 //   E k_early_map  : projection + candidate lists of the map points that survived the previous frame's clean-up
 //   E k_early_mid  : their greedy accept/mark scan (the first part of find_matches' storage-order scan)
-//   T k_match_map  : frame prologue (motion model, state machine; lvt_system.cpp:157-197) + is_point_visible / projection
+//   T k_match_map  : (single sequence: delivers the previous frame's record and waits for the early stream, then) frame prologue
+//                    (motion model, state machine; lvt_system.cpp:157-197) + is_point_visible / projection
 //                    and candidate lists of the points appended since                        (lvt_local_map.cpp:62-82,152)
 //   T k_track_mid  : the rest of the accept/mark scan of find_matches (pass 1, rare pass 2), counters / ages / PnP input,
 //                    LOST decision, clean_untracked_points   (lvt_local_map.cpp:146-224,393-413, lvt_system.cpp:267-274)

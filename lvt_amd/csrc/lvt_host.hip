@@ -435,7 +435,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
 // ---- the per-frame launch chain -------------------------------------------------------------------
 static const char *kProfNames[Context::PROF_SLOTS] = {
     "k_feat_begin", "k_gate [early stream: waits for the previous k_pnp]", "k_score", "k_cells(pass0)", "k_cells(retry)", "k_gather", "k_brief", "k_gate_late [waits for the early stream]",
-    "k_match_map(begin + new points)", "k_early_map [early stream]", "k_early_mid [early stream]", "", "k_track_mid(resolve+pass2+bookkeep+cull)", "k_pnp(+project staged)", "",
+    "k_match_map(wait for the early stream + begin + new points)", "k_early_map [early stream]", "k_early_mid [early stream]", "", "k_track_mid(resolve+pass2+bookkeep+cull)", "k_pnp(+project staged)", "",
     "", "k_candidates(staged)", "", "k_candidates(row) [early stream]", "", "k_triangulate(staged update+row resolve+triangulate+finalize)", "",
     "", ""};
 

@@ -4,11 +4,13 @@
 // (reference lvt/src/lvt_system.cpp) but performs NO tracking arithmetic: the whole state machine
 // runs on the device, the host enqueues the chain and reads back one result record per frame.
 //
-// Two HIP streams form a software pipeline: the FEATURE stage of frame t+1 (k_score .. k_brief, wide kernels)
-// runs on stream_f while the TRACKING chain of frame t (matching, the serial Levenberg-Marquardt pose
-// refinement, map maintenance -- latency-bound, a few workgroups) runs on stream_t.  Feature buffers are
-// double buffered by frame parity; events order the two stages.  Results land in a ring of pinned records,
-// so frames can be enqueued asynchronously (lvt_amd_track_device_async / lvt_amd_wait).
+// Three HIP streams form a software pipeline: the FEATURE stage (k_score .. k_brief, wide kernels) runs up
+// to two frames ahead on stream_f; the TRACKING chain (matching of the newest map points, the serial Levenberg-Marquardt pose
+// refinement, map maintenance -- latency-bound, a few workgroups) runs frame after frame on `stream`; the EARLY stream starts the
+// next frame's map matching the moment a frame's pose exists and builds the row-match candidate lists.  Feature buffers are
+// triple buffered; the streams hand over through sequence numbers polled by one-wave gate kernels (LVT_AMD_ORDERING=events: event
+// barriers instead).  Results land in a ring of pinned records with completion flags the host polls, so frames can be enqueued
+// asynchronously (lvt_amd_track_device_async / lvt_amd_wait).
 #define LVT_EXPORT_FUNCTIONS
 #include "../../include/lvt_amd_ext.h"
 

@@ -111,7 +111,7 @@ struct Ctl {
 // full frame ahead of the tracking stream (with two, the features of frame t+1 only finish when frame t does)
 constexpr int NPAR = 3;
 
-struct FeatCtl {        // per-frame state of the FEATURE stage (own stream, double buffered)
+struct FeatCtl {        // per-frame state of the FEATURE stage (own stream, one per feature buffer)
     int ext_corners;    // track_with_external_corners frame
     int n_ext[2];
     int n_detected[2];  // corners before BRIEF (for the <200 retry, handler.cpp:161)
@@ -137,7 +137,7 @@ struct MapSoA {            // lvt_local_map.h:64-72 as SoA; two copies for stabl
     int *counter, *age, *match_idx;
 };
 
-// everything the feature stage of ONE frame produces / consumes; two copies (frame parity) so that the
+// everything the feature stage of ONE frame produces / consumes; NPAR copies (frame number mod NPAR) so that the
 // feature extraction of frame t+1 overlaps the tracking chain of frame t on a second HIP stream
 struct FrameBuf {
     const uint8_t *img[2];

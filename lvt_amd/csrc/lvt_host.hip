@@ -109,7 +109,7 @@ struct Context {
     // the only dispatch slot while what it waits for cannot start.
     bool events_only = false;
     hipEvent_t ev_feat[NPAR] = {};
-    // owned staging for the host-buffer entry points, per frame parity
+    // owned staging for the host-buffer entry points, per feature buffer
     uint8_t *d_img[NPAR][2] = {};
     uint8_t *h_stage[NPAR] = {}, *h_stage_dev[NPAR] = {};  // pinned staging of host images (lvt_track): [left | right or depth]
     size_t stage_img = 0;                                    // bytes reserved per 8-bit image (16-B multiple)

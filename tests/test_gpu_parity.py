@@ -465,3 +465,37 @@ def test_wrong_image_size_is_refused_and_reported(hip_lib):
     assert "size" in vo.last_error()
     R2, t2 = vo.track(*world.render_stereo(1))
     assert vo.get_state() == 2 and np.linalg.norm(t2) > 0
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3, 7])
+def test_async_depths_and_record_delivery(hip_lib, depth):
+    """every number of frames in flight the ring allows: the result record of a frame is delivered by its successor's gate, by
+    the courier kernel (the last frame of a burst) or by k_triangulate (synchronous calls mixed in) -- always the same poses"""
+    import torch
+    world, prm, sensor = make_case("kitti", 50, 0.5)
+    n = 18
+    pitch = ((world.W + 63) // 64) * 64
+    dev = torch.zeros((n, 2, world.H, pitch), dtype=torch.uint8, device="cuda")
+    for i in range(n):
+        L, R = world.render_stereo(i)
+        dev[i, 0, :, :world.W] = torch.from_numpy(L).cuda(); dev[i, 1, :, :world.W] = torch.from_numpy(R).cuda()
+    torch.cuda.synchronize()
+    a = hip_lib.LvtSystem.create(prm, 1); b = hip_lib.LvtSystem.create(prm, 1)
+    ptr = lambda i: (dev[i].data_ptr(), dev[i].data_ptr() + world.H * pitch)
+    ref = [a.track_device(*ptr(i), world.H, world.W, pitch) for i in range(n)]
+    got, inflight = [], 0
+    for i in range(n):
+        if i in (6, 11):                       # a synchronous call in the middle of the asynchronous stream (drains it first)
+            while inflight:
+                got.append(b.wait()); inflight -= 1
+            got.append(b.track_device(*ptr(i), world.H, world.W, pitch))
+            continue
+        b.track_device_async(*ptr(i), world.H, world.W, pitch); inflight += 1
+        if inflight >= depth:
+            got.append(b.wait()); inflight -= 1
+    while inflight:
+        got.append(b.wait()); inflight -= 1
+    assert len(got) == n
+    for i, ((Ra, ta), (Rb, tb)) in enumerate(zip(ref, got)):
+        assert np.array_equal(ta, tb) and np.array_equal(Ra, Rb), f"frame {i}"
+    assert a.counts() == b.counts() and b.last_error() == ""

@@ -20,6 +20,7 @@
 #include "k_rectify.hip"
 #include "lvt_odometry.h"
 
+#include <atomic>
 #include <cmath>
 #include <chrono>
 #include <cstdio>
@@ -79,6 +80,11 @@ __global__ __launch_bounds__(256) void k_stage_in(const uint8_t *src0, const uin
 __global__ __launch_bounds__(256) void k_stage_copy(const uint4 *src, uint4 *dst, size_t nv) {
     for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (size_t)gridDim.x * blockDim.x) dst[v] = src[v];
 }
+
+// handles alive in this process: a handle whose k_match_map polls for its early stream parks 32 workgroups (50 KB of LDS each)
+// on the GPU; with many handles on one device that would leave no CU with enough free LDS for the 159-KB k_cells workgroups
+// they are waiting for -- beyond 4 handles the separate one-wave gate kernel is used again (enqueue_frame)
+static std::atomic<int> g_live_contexts{0};
 
 struct Context {
     double host_enq_us = 0, host_wait_us = 0;  // host time spent enqueueing / blocking (LVT_AMD_HOST_TIMING=1 prints it at destroy)
@@ -142,7 +148,9 @@ struct Context {
         return static_cast<T *>(p);
     }
 
+    Context() { g_live_contexts.fetch_add(1); }
     ~Context() {
+        g_live_contexts.fetch_sub(1);
         if (stream) (void)hipStreamSynchronize(stream);
         if (stream_f) (void)hipStreamSynchronize(stream_f);
         if (stream_e) (void)hipStreamSynchronize(stream_e);
@@ -537,7 +545,7 @@ static void enqueue_frame(Context *c) {
         if (evo) {
             (void)hipStreamWaitEvent(st, c->ev_feat[par], 0);  // (the early stream never claims the frame: early_ran_seq stays behind)
             LAUNCH_S(8, st, k_match_map, dim3(256, 1, B), dim3(256), 0, par, seq, 0, (Ctl *)nullptr, (seq_t *)nullptr);
-        } else if (B == 1) {
+        } else if (B == 1 && g_live_contexts.load() <= 4) {
             // one launch: delivers the record, waits for the early stream (polled, no barrier packet), lists the points appended since
             LAUNCH_S(8, st, k_match_map, dim3(MATCH_BLOCKS_GATED, 1, 1), dim3(256), 0, par, seq, 1, prec, pdone);
         } else {

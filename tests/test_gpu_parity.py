@@ -499,3 +499,40 @@ def test_async_depths_and_record_delivery(hip_lib, depth):
     for i, ((Ra, ta), (Rb, tb)) in enumerate(zip(ref, got)):
         assert np.array_equal(ta, tb) and np.array_equal(Ra, Rb), f"frame {i}"
     assert a.counts() == b.counts() and b.last_error() == ""
+
+
+def test_many_handles_on_one_gpu(hip_lib):
+    """eight independent handles driven round-robin from one thread, two frames in flight each (several sequences per
+    GPU on separate handles): no gate times out, no handle starves another, every pose equals the stand-alone run"""
+    import torch
+    H = 8
+    n = 10
+    cases = [make_case("kitti", 60 + k, 0.5) for k in range(H)]
+    world0 = cases[0][0]
+    pitch = ((world0.W + 63) // 64) * 64
+    dev = torch.zeros((H, n, 2, world0.H, pitch), dtype=torch.uint8, device="cuda")
+    for k, (w, _, _) in enumerate(cases):
+        for i in range(n):
+            L, R = w.render_stereo(i)
+            dev[k, i, 0, :, :w.W] = torch.from_numpy(L).cuda(); dev[k, i, 1, :, :w.W] = torch.from_numpy(R).cuda()
+    torch.cuda.synchronize()
+    ptr = lambda k, i: (dev[k, i].data_ptr(), dev[k, i].data_ptr() + world0.H * pitch)
+    ref = []
+    for k in range(H):
+        vo = hip_lib.LvtSystem.create(cases[k][1], 1)
+        ref.append([vo.track_device(*ptr(k, i), world0.H, world0.W, pitch) for i in range(n)])
+        del vo
+    vos = [hip_lib.LvtSystem.create(cases[k][1], 1) for k in range(H)]
+    got = [[] for _ in range(H)]
+    for i in range(n):
+        for k in range(H):
+            vos[k].track_device_async(*ptr(k, i), world0.H, world0.W, pitch)
+        if i >= 1:
+            for k in range(H):
+                got[k].append(vos[k].wait())
+    for k in range(H):
+        got[k].append(vos[k].wait())
+    for k in range(H):
+        assert vos[k].last_error() == "", (k, vos[k].last_error())
+        for i, ((Ra, ta), (Rb, tb)) in enumerate(zip(ref[k], got[k])):
+            assert np.array_equal(ta, tb) and np.array_equal(Ra, Rb), f"handle {k} frame {i}"

@@ -368,9 +368,9 @@ __device__ __forceinline__ void gate_late_poll(Ctl &ctl, FeatCtl &fc, seq_t seq)
 // derives the per-frame facts it needs (active / first frame / predicted pose) from the PERSISTENT part of Ctl, which
 // nobody writes during this kernel; block 0 additionally publishes them for the rest of the chain.
 template <bool BV>
-// gated (single sequence, polling mode: launched with 32 workgroups -- it only has the points appended since the early part to
+// gated (single sequence, polling mode: launched with 16 workgroups -- it only has the points appended since the early part to
 // list): the wait for the early stream happens HERE instead of in a k_gate_late launch of its own, and workgroup 0 first delivers
-// the previous frame's record.  32 spinning workgroups leave 224 CUs untouched for whatever they wait for (k_cells needs 20 CUs
+// the previous frame's record.  16 spinning workgroups leave 240 CUs untouched for whatever they wait for (k_cells needs 20 CUs
 // with free LDS; with 256 workgroups this deadlocked the synchronous mode until the time-out); a lock-step batch, whose grid
 // would cover the chip again, keeps the separate gate kernel.
 __global__ __launch_bounds__(256) void k_match_map(SeqArg<BV> sa, int par, seq_t seq, int gated, Ctl *prev_rec, seq_t *prev_done) {

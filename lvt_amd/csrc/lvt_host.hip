@@ -45,7 +45,7 @@ constexpr int EXT_MAX = 16384;
 // rate -- they share SIMDs and LDS with the single-workgroup kernels of the tracking chain running beside them; 16 make the kernel
 // itself too slow (measured: 24 / 32 / 40 / 48 / 64 / 256 -> 8 180 / 8 330 / 8 320 / 8 270 / 8 240 / 7 840 frames/s)
 constexpr int ROW_BLOCKS = 32;
-constexpr int MATCH_BLOCKS_GATED = 32;  // k_match_map when it polls for the early stream itself (single sequence): see k_track.hip
+constexpr int MATCH_BLOCKS_GATED = 16;  // k_match_map when it polls for the early stream itself (single sequence): see k_track.hip (8 / 16 / 32: 8 840 / 8 890 / 8 900 frames/s; fewer parked workgroups leave more CUs to other processes on the GPU)
 constexpr int ROW_BLOCKS_BATCH = 16;  // per sequence of a lock-step batch (16 sequences: 8 / 16 / 32 / 64 / 256 -> 30.8k / 36.9k / 35.8k / 35.0k / 31.1k frames/s)
 constexpr int RING = 8;  // frames that may be in flight / un-collected
 

@@ -89,7 +89,7 @@ LVT_API const char *lvt_amd_last_error(lvt_handle h);
 LVT_API void lvt_amd_profile_enable(lvt_handle h, int enable);
 LVT_API int lvt_amd_profile_read(lvt_handle h, int slot, char *name, int name_cap, double *total_ms, long *calls);
 
-/* ---- per-frame introspection (same slots as the oracle's LVTO_C_*; see oracle/lvt_oracle.h) ---- */
+/* ---- per-frame introspection (counter slots; the test oracle reports the same ones) ---- */
 enum {
     LVT_AMD_C_N_LEFT = 0, LVT_AMD_C_N_RIGHT, LVT_AMD_C_MAP_SIZE, LVT_AMD_C_STAGED_SIZE, LVT_AMD_C_N_MATCHES,
     LVT_AMD_C_SECOND_PASS, LVT_AMD_C_N_ROW_MATCHES, LVT_AMD_C_N_TRIANGULATED, LVT_AMD_C_TRIANGULATED,

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Stage-by-stage differential run: HIP path (through the C-ABI) vs the CPU oracle on a synthetic sequence.
 Prints, per frame, the first stage that diverges.  Used on the GPU box during bring-up:
-    python tools/gpu_parity.py --kind kitti --frames 30
+    python tests/tools/gpu_parity.py --kind kitti --frames 30
 """
 import argparse
 import os
@@ -10,7 +10,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import lvt_amd  # noqa: E402
 from lvt_amd.synth import make_world  # noqa: E402
 from oracle import pyoracle as O  # noqa: E402

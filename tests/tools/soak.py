@@ -1,11 +1,11 @@
 #!/usr/bin/env python3
 """Soak run: N frames of a KITTI-shaped synthetic sequence through the ASYNCHRONOUS pipeline (4 frames in flight), every pose
-compared with the CPU oracle's.  python tools/soak.py [frames] [seed]   (run on the GPU box)"""
+compared with the CPU oracle's.  python tests/tools/soak.py [frames] [seed]   (run on the GPU box)"""
 import os
 import sys
 import time
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import numpy as np
 import torch
 

@@ -1160,7 +1160,9 @@ __device__ __forceinline__ int box_at(const Seq &S, const FrameBuf &FB, int eye,
     return s;
 }
 
-__global__ __launch_bounds__(256) void k_brief(Seq *seqs, int par) {
+// publish_seq != 0: k_brief is the last kernel of the feature stage and its last workgroup publishes the frame's sequence number
+// for the gates of the other streams (a one-thread kernel behind it cost the feature chain a launch and a boundary)
+__global__ __launch_bounds__(256) void k_brief(Seq *seqs, int par, seq_t publish_seq) {
     Seq &S = seqs[blockIdx.z];
     const int eye = blockIdx.y;
     FrameBuf &FB = S.fb[par];
@@ -1188,6 +1190,19 @@ __global__ __launch_bounds__(256) void k_brief(Seq *seqs, int par) {
             word |= (uint64_t)(v & 255u) << (8 * b);
         }
         if ((lane & 15) == 0) F.desc[(size_t)i * 4 + (lane >> 4)] = word;
+    }
+    if (publish_seq) {
+        __syncthreads();  // every wave's descriptors are written ...
+        if (threadIdx.x == 0) {
+            FeatCtl &fc = *FB.fc;
+            __threadfence();  // ... and visible before this workgroup counts itself
+            if (atomicAdd(&fc.done_blocks, 1u) == gridDim.x * gridDim.y - 1) {
+                fc.done_blocks = 0;
+                S.ctl->dbg[47] = (long long)wall_clock64();  // (written from the feature stream: the frame it belongs to may differ)
+                __threadfence();
+                atomicExch(&fc.feat_seq, publish_seq);
+            }
+        }
     }
 }
 

@@ -118,6 +118,7 @@ struct FeatCtl {        // per-frame state of the FEATURE stage (own stream, one
     int retry[2];
     int overflow;
     seq_t row_seq;    // ... of the frame whose row-match candidate lists it holds (k_row_done; polled by k_triangulate)
+    unsigned done_blocks;  // workgroups of the feature stage's last kernel that have finished (the last one publishes feat_seq and resets this)
     seq_t feat_seq;  // sequence number of the frame whose features this buffer holds, published by k_feat_done (polled by k_gate)
 };
 

@@ -510,9 +510,9 @@ static void enqueue_frame(Context *c) {
         LAUNCH(4, sf, k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, S, 1, par);
     }
     LAUNCH(5, sf, k_gather, dim3(1, 2, B), dim3(1024), 0, S, par);
-    LAUNCH(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, S, par);
+    LAUNCH(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, S, par, evo ? (seq_t)0 : (seq_t)(c->enq + 1));  // (its last workgroup publishes feat_seq)
     if (evo) LAUNCH_SM(18, sf, k_candidates, MODE_ROW, dim3(256, 1, B), dim3(256), 0, 0, par, (seq_t)0);  // (normal mode: on the early stream, below)
-    hipLaunchKernelGGL(k_feat_done, dim3(B), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));
+    if (evo) hipLaunchKernelGGL(k_feat_done, dim3(B), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));
     if (evo) (void)hipEventRecord(c->ev_feat[par], sf);
     // ---- early stream: projection, candidate lists and greedy resolution of the map points that survived the previous frame,
     //      as soon as that frame's pose exists (its k_pnp) -- its k_triangulate only appends behind them

@@ -329,7 +329,7 @@ def main():
             "vs_baseline": None, "dtype": "u8/f64", "data": "synthetic",
             "config": {"workload": "KITTI seq 00-shaped synthetic stereo sequence (1241x376, vo_config.yaml), one sequence per GPU, "
                                    "one lvt_track per step, frames resident in HBM",
-                       "sequences_per_gpu": 1, "frames_in_flight": DEPTH, "parallelism": f"{world_size} independent sequences, no collective"},
+                       "sequences_per_gpu": 1, "frames_in_flight": DEPTH, "ordering": vo.ordering(), "parallelism": f"{world_size} independent sequences, no collective"},
             "tracking": {"lost_frames": n_lost, "features_left": counts["n_left"], "map_size": counts["map_size"],
                          "matches": counts["n_matches"], "error": err},
             "roofline": hb, "roofline_pipeline_dominant": roofline_dom,

@@ -12,6 +12,8 @@
  *    (hipHostMalloc / hipHostRegister) are read in place.
  *  - Environment, read by lvt_create: LVT_AMD_ORDERING=events orders the library's three streams with event barriers instead of
  *    polling gate kernels (needed under tools that serialise kernel dispatches, e.g. rocprofv3 --pmc; ~15 % slower).
+ *    Unset, the first live handle of a process polls and single-sequence handles created beside it use events
+ *    (lvt_amd_get_ordering); LVT_AMD_ORDERING=polling forces the gates.
  *  - lvt_amd_last_error reports capacity overflows, gate time-outs and "a stream waited 2 s" failures (which set LOST).
  */
 #ifndef LVT_AMD_EXT_H__
@@ -111,6 +113,11 @@ LVT_API void lvt_amd_get_debug(lvt_handle h, long long out[32]);
 /* wall-clock (100 MHz) start / end stamps of the kernels on the inter-frame critical path, for the frame lvt_amd_wait returned
  * last (tools/timeline.py); does not drain the pipeline */
 LVT_API void lvt_amd_get_timeline(lvt_handle h, long long out[16]);
+/* how the handle's streams hand over: 0 = polling gates + early stream (the fast path of a single handle), 1 = event barriers
+ * only.  LVT_AMD_ORDERING=polling / events fixes it at creation; unset, the first live handle of a process polls and
+ * single-sequence handles created beside it use events (independent handles share the process's hardware queues, and a
+ * polling gate holds up whatever another handle queued behind it) */
+LVT_API int lvt_amd_get_ordering(lvt_handle h);
 /* raw per-pixel intermediates of the last frame: what = 0 score map (u8, rows x pitch),
  * 1 box-sum map (u16, rows x pitch).  returns bytes written, pitch via *pitch_out (in elements). */
 LVT_API int lvt_amd_get_plane(lvt_handle h, int eye, int what, void *dst, int cap_bytes, int *pitch_out);

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "lvt_amd_get_pose", "lvt_amd_get_predicted_pose", "lvt_amd_get_plane", "lvt_amd_pnp",
     "lvt_amd_hamming_match_batched", "lvt_amd_hamming_match_batched_n", "lvt_amd_rectifier_create", "lvt_amd_rectifier_destroy",
     "lvt_amd_rectify_device", "lvt_amd_rectify", "lvt_amd_rectifier_get_maps",
-    "lvt_amd_odometry_create", "lvt_amd_odometry_destroy", "lvt_amd_odometry_reset", "lvt_amd_odometry_push_pose", "lvt_amd_odometry_update", "lvt_amd_profile_enable", "lvt_amd_profile_read", "lvt_amd_get_debug", "lvt_amd_get_timeline",
+    "lvt_amd_odometry_create", "lvt_amd_odometry_destroy", "lvt_amd_odometry_reset", "lvt_amd_odometry_push_pose", "lvt_amd_odometry_update", "lvt_amd_profile_enable", "lvt_amd_profile_read", "lvt_amd_get_debug", "lvt_amd_get_timeline", "lvt_amd_get_ordering",
     "lvt_amd_batch_create", "lvt_amd_batch_size", "lvt_amd_batch_track_device_async", "lvt_amd_batch_wait",
     "lvt_amd_batch_get_counts",
 ]
@@ -95,6 +95,8 @@ def load_library():
     L.lvt_amd_hamming_match_batched.restype = C.c_float
     L.lvt_amd_hamming_match_batched.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp]
     L.lvt_amd_get_timeline.argtypes = [vp, vp]
+    L.lvt_amd_get_ordering.argtypes = [vp]
+    L.lvt_amd_get_ordering.restype = C.c_int
     L.lvt_amd_rectifier_create.restype = vp
     L.lvt_amd_rectifier_create.argtypes = [vp, vp, vp, vp, C.c_int, C.c_int]
     L.lvt_amd_rectifier_destroy.argtypes = [vp]
@@ -281,6 +283,10 @@ class LvtSystem:
                 continue
             out.append((name.value.decode(), ms.value, calls.value))
         return out
+
+    def ordering(self):
+        """'polling' (gates + early stream) or 'events' (barriers only); see lvt_amd_get_ordering"""
+        return "events" if load_library().lvt_amd_get_ordering(self._h) else "polling"
 
     def timeline(self):
         a = np.zeros(16, dtype=np.int64)

@@ -349,8 +349,14 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
         for (auto &e : c->ev_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto &e : c->ev_feat) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         {
+            // "events": barrier-only ordering; "polling": the polling gates + early stream; unset: polling for the first live
+            // handle of the process, events for the ones created beside it -- the gates of several independent handles share
+            // the process's few hardware queues and hold up each other's kernels (4 handles: 5 300 frames/s aggregate with
+            // polling gates, 9 200 with events); several sequences on one GPU belong in one lock-step batch anyway
             const char *o = std::getenv("LVT_AMD_ORDERING");
-            c->events_only = o && std::strcmp(o, "events") == 0;
+            if (o && std::strcmp(o, "events") == 0) c->events_only = true;
+            else if (o && std::strcmp(o, "polling") == 0) c->events_only = false;
+            else c->events_only = B == 1 && g_live_contexts.load() > 1;
         }
         c->pitch = ((prm.W + 63) / 64) * 64;
         HIPCHK(c, hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl) * B * RING, hipHostMallocCoherent));
@@ -1085,6 +1091,9 @@ LVT_API void lvt_amd_get_debug(lvt_handle h, long long out[32]) {
         for (int i = 0; i < 32; i++) out[i] = last_ctl(c).dbg[i];
     } catch (...) {
     }
+}
+LVT_API int lvt_amd_get_ordering(lvt_handle h) {  // 0: polling gates + early stream, 1: event barriers only
+    return h && static_cast<Context *>(h)->events_only ? 1 : 0;
 }
 LVT_API void lvt_amd_get_timeline(lvt_handle h, long long out[16]) {  // of the frame lvt_amd_wait returned last; does not drain
     Context *c = static_cast<Context *>(h);

@@ -508,10 +508,17 @@ def test_async_depths_and_record_delivery(hip_lib, depth):
     assert a.counts() == b.counts() and b.last_error() == ""
 
 
-def test_many_handles_on_one_gpu(hip_lib):
+@pytest.mark.parametrize("ordering", ["auto", "polling"])
+def test_many_handles_on_one_gpu(hip_lib, monkeypatch, ordering):
     """eight independent handles driven round-robin from one thread, two frames in flight each (several sequences per
-    GPU on separate handles): no gate times out, no handle starves another, every pose equals the stand-alone run"""
+    GPU on separate handles): no gate times out, no handle starves another, every pose equals the stand-alone run -- with the
+    default choice (the first live handle polls, the ones created beside it order with events) and with polling gates forced
+    on all eight (more than four handles: separate one-wave k_gate_late instead of the parked k_match_map workgroups)"""
     import torch
+    if ordering == "polling":
+        monkeypatch.setenv("LVT_AMD_ORDERING", "polling")  # read by lvt_create
+    else:
+        monkeypatch.delenv("LVT_AMD_ORDERING", raising=False)
     H = 8
     n = 10
     cases = [make_case("kitti", 60 + k, 0.5) for k in range(H)]
@@ -530,6 +537,8 @@ def test_many_handles_on_one_gpu(hip_lib):
         ref.append([vo.track_device(*ptr(k, i), world0.H, world0.W, pitch) for i in range(n)])
         del vo
     vos = [hip_lib.LvtSystem.create(cases[k][1], 1) for k in range(H)]
+    modes = [v.ordering() for v in vos]
+    assert modes[1:] == (["polling"] * (H - 1) if ordering == "polling" else ["events"] * (H - 1)), modes
     got = [[] for _ in range(H)]
     for i in range(n):
         for k in range(H):

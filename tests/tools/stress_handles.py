@@ -26,11 +26,13 @@ torch.cuda.synchronize()
 base, fs = frames.data_ptr(), 2 * Hh * pitch
 out = [None] * H
 errs = []
+modes = [None] * H
 
 
 def work(k):
     try:
         vo = lvt_amd.LvtSystem.create(prm, 1)
+        modes[k] = vo.ordering()
         poses, inflight = [], 0
         for i in range(n):
             vo.track_device_async(base + i * fs, base + i * fs + Hh * pitch, Hh, W, pitch); inflight += 1
@@ -50,4 +52,5 @@ ths = [threading.Thread(target=work, args=(k,)) for k in range(H)]
 [t.start() for t in ths]; [t.join() for t in ths]
 dt = time.perf_counter() - t0
 same = all(out[k] is not None and np.array_equal(out[0], out[k]) for k in range(H))
-print("STRESS handles=%d frames=%d identical=%s errors=%s aggregate %.0f frames/s" % (H, n, same, errs, H * n / dt))
+print("STRESS handles=%d frames=%d ordering=%s identical=%s errors=%s aggregate %.0f frames/s"
+      % (H, n, ",".join(m[0] for m in modes), same, errs, H * n / dt))

@@ -69,8 +69,11 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     const int N = a.N, M = a.M;
     const int nbins = a.nbx * a.nby;
     // carve: desc [N][2] uint4 | xy [N] float2 | per-query slot [M] 12 B | start [nbins + 1] | idx [N] u16 | order [M] u16
-    uint4 *s_desc = reinterpret_cast<uint4 *>(smem);
-    float2 *s_xy = reinterpret_cast<float2 *>(s_desc + (size_t)N * 2);
+    // descriptor halves as TWO arrays, not one of 32-byte records: a ds_read_b128 serves 16 lanes per LDS cycle over the 16 four-bank
+    // groups, and with 32-byte records every read (all low halves, or all high halves) can only reach 8 of them
+    uint4 *s_dlo = reinterpret_cast<uint4 *>(smem);
+    uint4 *s_dhi = s_dlo + N;
+    float2 *s_xy = reinterpret_cast<float2 *>(s_dhi + N);
     uint2 *s_mask = reinterpret_cast<uint2 *>(s_xy + N);
     uint32_t *s_q = reinterpret_cast<uint32_t *>(s_mask);  // 12 B per query: packed ranges + candidate mask (see stage 4)
     int *s_start = reinterpret_cast<int *>(s_q + 3 * (size_t)M);
@@ -158,8 +161,8 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             const int pos = s_start[tbin[k]] + trank[k];
             s_xy[pos] = tp[k];
             s_idx[pos] = (uint16_t)(tid + k * HB_THREADS);
-            s_desc[2 * pos] = tdlo[k];
-            s_desc[2 * pos + 1] = tdhi[k];
+            s_dlo[pos] = tdlo[k];
+            s_dhi[pos] = tdhi[k];
         }
     }
 
@@ -300,13 +303,13 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         int it;
         LVT_POS_OF(it, 0)
         float2 r = s_xy[it];
-        uint4 a0 = s_desc[2 * it], a1 = s_desc[2 * it + 1];
+        uint4 a0 = s_dlo[it], a1 = s_dhi[it];
         uint32_t id = s_idx[it];
         for (int v = 0; v < total; v++) {  // software-pipelined by one candidate; the last prefetch reads one past (valid LDS)
             int itn;
             LVT_POS_OF(itn, v + 1)
             const float2 rn = s_xy[itn];
-            const uint4 b0 = s_desc[2 * itn], b1 = s_desc[2 * itn + 1];
+            const uint4 b0 = s_dlo[itn], b1 = s_dhi[itn];
             const uint32_t idn = s_idx[itn];
             bool ok;
             if (MODE == 1) ok = (r.y >= fy0) && (r.y <= fy1);
@@ -431,7 +434,7 @@ LVT_RADIUS_BITS(lo, 0, t0)
                         LVT_POS_OF(it, v)
                     }
                     m &= m - 1;
-                    uint4 a0 = s_desc[2 * it], a1 = s_desc[2 * it + 1];
+                    uint4 a0 = s_dlo[it], a1 = s_dhi[it];
                     uint32_t id = s_idx[it];
                     for (;;) {
                         const bool more = m != 0;
@@ -441,7 +444,7 @@ LVT_RADIUS_BITS(lo, 0, t0)
                             LVT_POS_OF(itn, v)
                         }
                         m &= m - 1;
-                        const uint4 b0 = s_desc[2 * itn], b1 = s_desc[2 * itn + 1];
+                        const uint4 b0 = s_dlo[itn], b1 = s_dhi[itn];
                         const uint32_t idn = s_idx[itn];
                         const int d = __popcll(d0 ^ (((uint64_t)a0.y << 32) | a0.x)) + __popcll(d1 ^ (((uint64_t)a0.w << 32) | a0.z)) +
                                       __popcll(d2 ^ (((uint64_t)a1.y << 32) | a1.x)) + __popcll(d3 ^ (((uint64_t)a1.w << 32) | a1.z));
@@ -552,7 +555,7 @@ LVT_RADIUS_BITS(lo, 0, t0)
                         LVT_POS_OF(it, v)
                     }
                     m &= m - 1;
-                    uint4 a0 = s_desc[2 * it], a1 = s_desc[2 * it + 1];
+                    uint4 a0 = s_dlo[it], a1 = s_dhi[it];
                     uint32_t id = s_idx[it];
                     for (;;) {
                         const bool more = m != 0;
@@ -562,7 +565,7 @@ LVT_RADIUS_BITS(lo, 0, t0)
                             LVT_POS_OF(itn, v)
                         }
                         m &= m - 1;
-                        const uint4 b0 = s_desc[2 * itn], b1 = s_desc[2 * itn + 1];
+                        const uint4 b0 = s_dlo[itn], b1 = s_dhi[itn];
                         const uint32_t idn = s_idx[itn];
                         const int d = __popcll(d0 ^ (((uint64_t)a0.y << 32) | a0.x)) + __popcll(d1 ^ (((uint64_t)a0.w << 32) | a0.z)) +
                                       __popcll(d2 ^ (((uint64_t)a1.y << 32) | a1.x)) + __popcll(d3 ^ (((uint64_t)a1.w << 32) | a1.z));

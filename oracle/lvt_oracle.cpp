@@ -1516,7 +1516,7 @@ void lvto_hamming_top2(const uint8_t *query, const uint8_t *train, int n, const 
     out[3] = t.d2;
 }
 int lvto_pnp(const lvto_params *p, const double q_in[4], const double p_in[3], const double *pts, const float *obs, int n,
-             double q_out[4], double p_out[3], int *inlier_marks, double *trace, int trace_cap) {
+             double q_out[4], double p_out[3], int *inlier_marks, double *trace, int trace_cap, int *solve_calls) {
     Pose prior;
     prior.q = Quat{q_in[0], q_in[1], q_in[2], q_in[3]};
     prior.p = V3{p_in[0], p_in[1], p_in[2]};
@@ -1530,6 +1530,7 @@ int lvto_pnp(const lvto_params *p, const double q_in[4], const double p_in[3], c
     p_out[0] = r.pose.p.x, p_out[1] = r.pose.p.y, p_out[2] = r.pose.p.z;
     if (inlier_marks)
         for (int i = 0; i < n; i++) inlier_marks[i] = marks[i];
+    if (solve_calls) *solve_calls = r.solve_calls;
     int rows = (int)tr.size() / 4;
     if (trace)
         for (int i = 0; i < std::min(rows, trace_cap) * 4; i++) trace[i] = tr[i];

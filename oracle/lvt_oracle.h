@@ -119,10 +119,10 @@ int lvto_compute_features(const uint8_t *img, int rows, int cols, const lvto_par
 void lvto_hamming_top2(const uint8_t *query, const uint8_t *train, int n, const uint8_t *mask,
                        int out[4]);
 /* motion-only BA (pnp_solver.cpp:60-128 + A.6).  pose in/out: q_wxyz, p.  pts: n x 3 f64, obs: n x 2 f32
- * trace (optional, cap rows x 4): per LM trial {lambda, chi_cur, chi_tmp, rho} */
+ * trace (optional, cap rows x 4): per LM trial {lambda, chi_cur, chi_tmp, rho}; solve_calls (optional): g2o solve() calls of both passes */
 int lvto_pnp(const lvto_params *p, const double q_in[4], const double p_in[3], const double *pts,
              const float *obs, int n, double q_out[4], double p_out[3], int *inlier_marks,
-             double *trace, int trace_cap);
+             double *trace, int trace_cap, int *solve_calls);
 /* linear-LS stereo triangulation of one pair incl. gates (local_map.cpp:276-319); returns 1 if kept */
 int lvto_triangulate_one(const lvto_params *p, const double q[4], const double pos[3], float ulx,
                          float uly, float urx, float ury, double out_xyz[3]);

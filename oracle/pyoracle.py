@@ -59,7 +59,7 @@ def lib():
         L.lvto_brief.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp, vp]
         L.lvto_compute_features.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp]
         L.lvto_hamming_top2.argtypes = [vp, vp, C.c_int, vp, vp]
-        L.lvto_pnp.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int]
+        L.lvto_pnp.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp]
         L.lvto_triangulate_one.argtypes = [vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]
         L.lvto_motion_predict.argtypes = [vp, vp, vp, vp, vp]
         _lib = L
@@ -238,7 +238,9 @@ def pnp(params, q_in, p_in, pts, obs, trace_cap=256):
     q_in = np.ascontiguousarray(q_in, np.float64); p_in = np.ascontiguousarray(p_in, np.float64)
     pts = np.ascontiguousarray(pts, np.float64); obs = np.ascontiguousarray(obs, np.float32)
     q = np.zeros(4); p = np.zeros(3); marks = np.zeros(len(pts), np.int32); tr = np.zeros((trace_cap, 4))
-    n = lib().lvto_pnp(C.byref(pod), _p(q_in), _p(p_in), _p(pts), _p(obs), len(pts), _p(q), _p(p), _p(marks), _p(tr), trace_cap)
+    calls = C.c_int(0)
+    n = lib().lvto_pnp(C.byref(pod), _p(q_in), _p(p_in), _p(pts), _p(obs), len(pts), _p(q), _p(p), _p(marks), _p(tr), trace_cap, C.byref(calls))
+    pnp.last_solve_calls = calls.value   # optimize() iterations (g2o solve() calls) of both passes
     return q, p, marks, tr[:min(n, trace_cap)].copy()
 
 

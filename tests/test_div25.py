@@ -48,3 +48,16 @@ def test_div_cell_is_exact(tmp_path):
     n, bad = (int(v) for v in out.stdout.split())
     assert out.returncode == 0 and bad == 0, f"{bad} of {n} quotients differ"
     assert n > 60_000_000
+
+
+def test_floor_of_the_float_quotient_is_the_exact_floor():
+    """k_hamming.hip prunes a query's hash rows by their distance to the query: a feature of row ry is taken to lie in the slab
+    25 ry <= y < 25 (ry + 1).  The row is floor(fl(y / 25.0f)); this checks that rounding the quotient never lifts it across an
+    integer: for every k, the largest float below 25 k still divides to something below k (division is monotone, so
+    floor(fl(y / 25)) >= k  <=>  y >= 25 k for every float y >= 0)."""
+    import numpy as np
+    k = np.arange(1, 4001, dtype=np.float32)
+    edge = (k * np.float32(25.0)).astype(np.float32)                # exactly representable
+    below = np.nextafter(edge, np.float32(0))
+    assert (np.floor((below / np.float32(25.0)).astype(np.float32)) == k - 1).all()
+    assert (np.floor((edge / np.float32(25.0)).astype(np.float32)) == k).all()

@@ -15,7 +15,11 @@ CASES = [
     ("kitti_full", "kitti", 1, 1.0, {}, list(range(8))),                       # BASELINE.json configs[1] shape
     ("kitti_dense_anms", "kitti", 2, 1.0, {"agast_threshold": 12, "max_keypoints_per_cell": 60}, list(range(5))),
     ("kitti_low_corner_retry", "kitti", 4, 1.0, {"agast_threshold": 150}, list(range(6))),
-    ("kitti_jump_second_pass", "kitti", 3, 1.0, {}, list(range(8)) + list(range(48, 54))),
+    ("kitti_jump", "kitti", 3, 1.0, {}, list(range(8)) + list(range(48, 54))),      # 40 frames skipped: culling, staging, many re-triangulations
+    # ~70 features per image: the first pass of find_matches stays below 50 matches on EVERY frame, so the doubled-radius
+    # second pass (lvt_local_map.cpp:173-199) runs while tracking continues (asserted below)
+    ("kitti_sparse_second_pass", "kitti", 3, 1.0, {"max_keypoints_per_cell": 8}, list(range(12))),
+    ("kitti_full_long", "kitti", 9, 1.0, {}, list(range(220))),               # staging / promotion / culling at full size over 220 frames
     ("kitti_always_triangulate", "kitti", 5, 0.5, {"triangulation_policy": 2, "staged_threshold": 0}, list(range(10))),
     ("kitti_map_size_policy", "kitti", 6, 0.5, {"triangulation_policy": 3}, list(range(10))),
     ("euroc", "euroc", 0, 1.0, {}, list(range(10))),                           # configs[2] shape
@@ -35,6 +39,10 @@ def test_sequence_parity(hip_lib, oracle_lib, name, kind, seed, scale, overrides
     c = hip.counts()
     if name == "kitti_low_corner_retry":
         assert c["retry_left"] == 1, "the <200-corner retry path was not exercised"
+    if name == "kitti_sparse_second_pass":
+        assert c["second_pass"] == 1 and hip.get_state() == 2, "the second pass of find_matches was not exercised while TRACKING"
+    if name == "kitti_full_long":
+        assert hip.get_state() == 2 and c["frame"] == 219
     if name == "tum_rgbd":
         assert c["n_right"] == 0
 

@@ -53,6 +53,11 @@ LVT_API int lvt_amd_params_from_file(const char *config_file_name, lvt_amd_param
 /* reference lvt_system::create (lvt_system.cpp:70-127): the path the example binaries use, where the
  * intrinsics are filled in after the YAML is read (kitti_example.cpp:98-106) */
 LVT_API lvt_handle lvt_amd_create(const lvt_amd_params *p, int sensor_type);
+/* A handle OWNS the HIP device that was current when it was created (lvt_create, lvt_amd_create, lvt_amd_batch_create) or the one
+ * named here: every entry point makes that device current for the call and restores the caller's, so one process can drive one
+ * handle per GPU from any of its threads.  lvt_amd_get_device: the owning device, -1 for a NULL handle. */
+LVT_API lvt_handle lvt_amd_create_on_device(const lvt_amd_params *p, int sensor_type, int device);
+LVT_API int lvt_amd_get_device(lvt_handle h);
 /* reference lvt_system::reset (lvt_system.cpp:44-68) */
 LVT_API void lvt_amd_reset(lvt_handle h);
 /* reference lvt_system::track, RGB-D branch (lvt_system.cpp:177-183): gray u8 + depth f32 (metres),
@@ -68,6 +73,9 @@ LVT_API void lvt_amd_track_device(lvt_handle h, const void *d_left, const void *
 LVT_API void lvt_amd_track_device_async(lvt_handle h, const void *d_left, const void *d_right, int n_rows,
                                         int n_cols, int pitch_bytes);
 LVT_API void lvt_amd_wait(lvt_handle h, double R[3][3], double t[3]);
+/* the same, returning the tracking state after THAT frame (1 not initialised, 2 tracking, 3 lost; -1 error) -- lvt_get_status would
+ * drain the whole pipeline first */
+LVT_API int lvt_amd_wait_status(lvt_handle h, double R[3][3], double t[3]);
 /* ---- lock-step batch of independent sequences on ONE GPU ----------------------------------------------
  * B sequences (e.g. several KITTI drives) advance frame by frame through a single launch chain (every kernel is
  * launched with gridDim.z = B); the latency-bound serial kernels of the path (pose refinement, greedy resolvers)
@@ -169,7 +177,7 @@ LVT_API int lvt_amd_rectifier_get_maps(lvt_amd_rectifier r, float *map1, float *
 typedef void *lvt_amd_odometry;
 LVT_API lvt_amd_odometry lvt_amd_odometry_create(lvt_handle h, const double base_to_sensor[12] /* 3x4 row-major or NULL */, int reset_pose_on_lost);
 LVT_API void lvt_amd_odometry_destroy(lvt_amd_odometry o);
-LVT_API void lvt_amd_odometry_reset(lvt_amd_odometry o); /* the node's reset_vo service: tracker reset, deltas restart (pose kept) */
+LVT_API void lvt_amd_odometry_reset(lvt_amd_odometry o); /* the node's reset_vo service (lvt_ros.cpp:184-198): tracker reset, deltas restart, accumulated pose back to identity */
 LVT_API int lvt_amd_odometry_push_pose(lvt_amd_odometry o, const double R[3][3], const double t[3], int status, double stamp_sec,
                                        double pose_out[7], double twist_out[6]);
 LVT_API int lvt_amd_odometry_update(lvt_amd_odometry o, unsigned char *left, unsigned char *right, int n_rows, int n_cols, double stamp_sec,

@@ -13,6 +13,13 @@
  *
  * Everything behind this boundary runs as hand-written gfx950 HIP kernels; there is no CPU
  * fallback.  If no HIP device is usable lvt_create() returns NULL.
+ *
+ * Capacities (compile-time, lvt_amd/csrc/lvt_dev.h; the reference's containers grow without
+ * bound): 4096 features per image after BRIEF's border filter, 16384 external corners per
+ * list, 32768 map points, 16384 staged points, 64 detection cells.  Exceeding one never passes
+ * silently: the frame is tracked on what fits and lvt_amd_last_error() / the `overflow` count
+ * (include/lvt_amd_ext.h) say which capacity was hit.  Every shipped configuration of the
+ * reference (KITTI, EuRoC, TUM) stays an order of magnitude below them.
  */
 #ifndef LVT_C_INTERFACE_H__
 #define LVT_C_INTERFACE_H__

@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "lvt_amd_rectify_device", "lvt_amd_rectify", "lvt_amd_rectifier_get_maps",
     "lvt_amd_odometry_create", "lvt_amd_odometry_destroy", "lvt_amd_odometry_reset", "lvt_amd_odometry_push_pose", "lvt_amd_odometry_update", "lvt_amd_profile_enable", "lvt_amd_profile_read", "lvt_amd_get_debug", "lvt_amd_get_timeline", "lvt_amd_get_ordering",
     "lvt_amd_batch_create", "lvt_amd_batch_size", "lvt_amd_batch_track_device_async", "lvt_amd_batch_wait",
-    "lvt_amd_batch_get_counts",
+    "lvt_amd_batch_get_counts", "lvt_amd_create_on_device", "lvt_amd_get_device", "lvt_amd_wait_status",
 ]
 
 N_COUNTS = 32
@@ -68,6 +68,9 @@ def load_library():
     L.lvt_create.argtypes = [C.c_char_p, C.c_int]
     L.lvt_amd_create.restype = vp
     L.lvt_amd_create.argtypes = [vp, C.c_int]
+    L.lvt_amd_create_on_device.restype = vp
+    L.lvt_amd_create_on_device.argtypes = [vp, C.c_int, C.c_int]
+    L.lvt_amd_get_device.argtypes = [vp]
     L.lvt_destroy.argtypes = [vp]
     L.lvt_amd_reset.argtypes = [vp]
     L.lvt_track.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
@@ -79,6 +82,8 @@ def load_library():
     L.lvt_amd_track_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.lvt_amd_track_device_async.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int]
     L.lvt_amd_wait.argtypes = [vp, vp, vp]
+    L.lvt_amd_wait_status.argtypes = [vp, vp, vp]
+    L.lvt_amd_wait_status.restype = C.c_int
     L.lvt_amd_set_stream.argtypes = [vp, vp]
     L.lvt_amd_last_error.restype = C.c_char_p
     L.lvt_amd_last_error.argtypes = [vp]
@@ -145,10 +150,11 @@ class LvtSystem:
 
     # lvt_system::create(const lvt_parameters&, eSensor)  -- lvt_system.cpp:70-127
     @classmethod
-    def create(cls, params: LvtParameters, sensor_type: int = eSensor_STEREO) -> "LvtSystem":
+    def create(cls, params: LvtParameters, sensor_type: int = eSensor_STEREO, device: int = -1) -> "LvtSystem":
+        """device >= 0: the handle owns that HIP device whatever the calling thread's current device is (lvt_amd_create_on_device)"""
         L = load_library()
         pod = params.to_pod()
-        h = L.lvt_amd_create(C.byref(pod), sensor_type)
+        h = L.lvt_amd_create_on_device(C.byref(pod), sensor_type, device) if device >= 0 else L.lvt_amd_create(C.byref(pod), sensor_type)
         if not h:
             raise RuntimeError("lvt_amd_create failed (bad parameters, or no usable HIP device -- no CPU fallback)")
         return cls(h, sensor_type)
@@ -182,6 +188,9 @@ class LvtSystem:
 
     def get_sensor_type(self):
         return self._sensor
+
+    def device(self) -> int:
+        return load_library().lvt_amd_get_device(self._h)
 
     def get_state(self):
         return load_library().lvt_get_status(self._h)
@@ -224,6 +233,12 @@ class LvtSystem:
         R = np.zeros((3, 3)); t = np.zeros(3)
         load_library().lvt_amd_wait(self._h, _p(R), _p(t))
         return R, t
+
+    def wait_status(self):
+        """(R, t, state after that frame) of the oldest un-collected frame"""
+        R = np.zeros((3, 3)); t = np.zeros(3)
+        st = load_library().lvt_amd_wait_status(self._h, _p(R), _p(t))
+        return R, t, st
 
     def set_stream(self, hip_stream: int):
         load_library().lvt_amd_set_stream(self._h, C.c_void_p(hip_stream))

@@ -74,6 +74,7 @@ __device__ __forceinline__ void feat_begin(Seq &S, const FrameArgs &f, int par) 
     FB.img_pitch = f.img_pitch;
     FB.depth_pitch = f.depth_pitch;
     FeatCtl &c = *FB.fc;
+    if (c.poison) return;  // (k_gate_buf: the buffer still belongs to an older frame)
     c.ext_corners = f.ext_corners;
     c.n_ext[0] = f.n_ext[0];
     c.n_ext[1] = f.n_ext[1];
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par)
     const int seq = blockIdx.z >> 1, eye = blockIdx.z & 1;
     Seq &S = seqs[seq];
     FrameBuf &FB = S.fb[par];
+    if (FB.fc->poison) return;
     if (BEGIN && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) feat_begin(S, fa, par);
     if (eye == 1 && S.prm.sensor == 2) return;
     const int W = S.prm.W, H = S.prm.H;
@@ -990,7 +992,7 @@ __global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass, int par) {
     const int eye = blockIdx.y, cell = blockIdx.x;
     FrameBuf &FB = S.fb[par];
     FeatCtl &ctl = *FB.fc;
-    if (ctl.ext_corners) return;
+    if (ctl.poison || ctl.ext_corners) return;
     if (eye == 1 && S.prm.sensor == 2) return;
     if (cell >= S.prm.n_cells) return;
     CellGeom g;
@@ -1076,6 +1078,7 @@ __global__ __launch_bounds__(1024) void k_gather(Seq *seqs, int par) {
     __shared__ int scan[32];
     const int tid = threadIdx.x;
     Feat &F = FB.feat[eye];
+    if (ctl.poison) return;
     if (eye == 1 && S.prm.sensor == 2) {
         if (tid == 0) *F.n = 0;
         return;
@@ -1167,7 +1170,8 @@ __global__ __launch_bounds__(256) void k_brief(Seq *seqs, int par, seq_t publish
     const int eye = blockIdx.y;
     FrameBuf &FB = S.fb[par];
     Feat &F = FB.feat[eye];
-    const int n = *F.n;
+    const bool poison = FB.fc->poison != 0;  // (block-uniform; reset by the publishing workgroup below, after every workgroup has read it)
+    const int n = poison ? 0 : *F.n;
     const int lane = lane_id();
     const int wpb = blockDim.x >> 6;
     for (int i = blockIdx.x * wpb + wave_id(); i < n; i += gridDim.x * wpb) {
@@ -1198,6 +1202,10 @@ __global__ __launch_bounds__(256) void k_brief(Seq *seqs, int par, seq_t publish
             __threadfence();  // ... and visible before this workgroup counts itself
             if (atomicAdd(&fc.done_blocks, 1u) == gridDim.x * gridDim.y - 1) {
                 fc.done_blocks = 0;
+                if (poison) {  // the frame has no features: say so to the gates of the other streams, then release the flag
+                    fc.skip_seq = publish_seq;
+                    fc.poison = 0;
+                }
                 S.ctl->dbg[47] = (long long)wall_clock64();  // (written from the feature stream: the frame it belongs to may differ)
                 __threadfence();
                 atomicExch(&fc.feat_seq, publish_seq);

@@ -47,7 +47,7 @@ struct SeqArg<true> {
 // model's next state goes to a shadow (mm_next) committed by k_track_mid.
 // =================================================================================================
 __device__ __forceinline__ void frame_prologue(const Seq &S, Ctl &c, int par, const Pose &predicted, const double mm_next[14], bool active,
-                                               bool first) {
+                                               bool first, bool skipped) {
     for (int i = 0; i < N_COUNTS; i++) c.counts[i] = 0;
     c.counts[C_FRAME] = c.frame_number;
     c.frame_number++;
@@ -65,9 +65,10 @@ __device__ __forceinline__ void frame_prologue(const Seq &S, Ctl &c, int par, co
     c.overflow = fc.overflow;
     c.counts[C_RETRY_LEFT] = active ? fc.retry[0] : 0;  // (LOST: the reference returns before it detects anything; the feature
     c.counts[C_RETRY_RIGHT] = active ? fc.retry[1] : 0;  //  stream here has run regardless -- its results are not reported)
-    if (!active) {  // LOST: return the last pose forever (lvt_system.cpp:161-166)
+    if (!active) {  // LOST: return the last pose forever (lvt_system.cpp:161-166).  A SKIPPED frame (its features never arrived: a gate
+                    // timed out, reported through lvt_amd_last_error) also returns the last pose, but the state stays what it was
         pose_to_Rt(c.last_pose, c.out_R, c.out_t);
-        c.out_status = 3;
+        c.out_status = skipped ? c.state : 3;
         return;
     }
     if (!first) {  // lvt_system.cpp:197 -> lvt_motion_model.cpp:42-65
@@ -383,10 +384,12 @@ __global__ __launch_bounds__(256) void k_match_map(SeqArg<BV> sa, int par, seq_t
         if (threadIdx.x == 0) gate_late_poll(ctl, *S.fb[par].fc, seq);
     }
     if (threadIdx.x == 0 && blockIdx.x == 0) ctl.dbg[40] = (long long)wall_clock64();  // (timeline: the frame's work starts)
-    if (threadIdx.x == 0) s_state = ctl.state;  // persistent; not written by this kernel (but for the gate's "features never arrived")
+    __shared__ int s_skip;
+    if (threadIdx.x == 0) s_state = ctl.state, s_skip = ctl.skip;  // state: persistent, not written by this kernel; skip: set by this frame's gate (above / k_gate_late)
     __syncthreads();
     const int state = s_state;
-    const bool active = (state != 3), first = (state == 1);
+    const bool skipped = s_skip != 0;
+    const bool active = (state != 3) && !skipped, first = (state == 1);
     __shared__ double w2c[12];
     if (threadIdx.x == 0) {
         Pose predicted;
@@ -396,7 +399,7 @@ __global__ __launch_bounds__(256) void k_match_map(SeqArg<BV> sa, int par, seq_t
             world_to_camera(predicted, w2c);
         }
         if (blockIdx.x == 0) {
-            frame_prologue(S, ctl, par, predicted, mmn, active, first);
+            frame_prologue(S, ctl, par, predicted, mmn, active, first, skipped);
             if (active && !first) ctl.counts[C_MAP_SIZE_AT_MATCH] = *S.map_n;
         }
     }
@@ -421,15 +424,20 @@ __global__ __launch_bounds__(256) void k_match_map(SeqArg<BV> sa, int par, seq_t
 // is finished.  Polled: a feature stream parked on an event barrier stalls the queues that share its hardware pipe -- with
 // the barrier, SHORTENING the feature chain made the whole pipeline slower -- and the event record costs the tracking stream
 // 3-4 us per frame.  (LVT_AMD_ORDERING=events uses the barrier instead of this kernel.)
-__global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, seq_t want) {
+__global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, seq_t want, int par) {
     Ctl &ctl = *seqs[blockIdx.z].ctl;
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(&ctl.track_done_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
         __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > 200000000ull) {  // 2 s: the tracking stream is wedged (or a tool serialises the dispatches and
-            ctl.state = 3;                          // this kernel holds the slot): the buffer is about to be overwritten under a
-            atomicAdd(&ctl.gate_fatal, 1);  // frame that still needs it -- LOST, reported through lvt_amd_last_error
+        if (wall_clock64() - t0 > 200000000ull) {  // 2 s: the tracking stream is wedged, or a tool serialises the dispatches and this
+            // kernel holds the slot.  The buffer still belongs to an older frame: this frame's feature kernels leave it alone
+            // (FeatCtl::poison), k_brief publishes "no features" (skip_seq) and the tracking chain SKIPS the frame -- last pose
+            // returned, state kept, reported through lvt_amd_last_error.  Never LOST: that state is sticky and, in the reference,
+            // a matter of match counts only.
+            seqs[blockIdx.z].fb[par].fc->poison = 1;
+            atomicAdd(&ctl.gate_fatal, 1);
+            __threadfence();
             break;
         }
     }
@@ -476,6 +484,7 @@ __global__ __launch_bounds__(64) void k_gate(SeqArg<BV> sa, int par, seq_t want,
                 break;
             }
         }
+        if (ok && __hip_atomic_load(&fc.skip_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == seq) ok = false;  // published, but empty (k_gate_buf)
         // (b) the previous frame's k_pnp
         const unsigned long long t1 = wall_clock64();
         ctl.dbg[35] = (long long)t1;  // (tools/timeline.py: when this frame's features were seen)
@@ -1181,12 +1190,13 @@ __device__ __forceinline__ void gate_late_poll(Ctl &ctl, FeatCtl &fc, seq_t seq)
     t0 = wall_clock64();
     while (__hip_atomic_load(&fc.feat_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
         __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > 200000000ull) {  // 2 s: the feature stream is wedged -- nothing valid to track on.  LOST is the
-            ctl.state = 3;                          // reference's "cannot continue" state; reported through lvt_amd_last_error
+        if (wall_clock64() - t0 > 200000000ull) {  // 2 s: the feature stream is wedged -- nothing valid to track on: the frame is
+            ctl.skip = 1;                           // skipped (last pose, state kept), reported through lvt_amd_last_error
             atomicAdd(&ctl.gate_fatal, 1);
             break;
         }
     }
+    if (__hip_atomic_load(&fc.skip_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == seq) ctl.skip = 1;  // published without features (k_gate_buf gave up)
 }
 
 template <bool BV>
@@ -1977,19 +1987,35 @@ __global__ __launch_bounds__(1024) void k_triangulate(SeqArg<BV> sa, int par, se
         // (on the early stream behind k_early_mid: normally finished ~70 us ago.  One workgroup polling holds one CU.  2 s without
         //  the lists: nothing valid to triangulate from -> LOST, reported)
         if (row_gated) {
+            // (the lists are normally ~70 us old by now.  5 ms without them -- the early stream's gate stood down, or the stream is
+            //  held up -- and this workgroup builds them itself: the features are complete (this frame's gate has seen them), the lists
+            //  are a function of the two feature sets only, so a late k_candidates<ROW> writing the same words is harmless.  A
+            //  time-out costs time, never the track.)
+            __shared__ int s_row_fallback;
             if (tid == 0) {
                 FeatCtl &fc = *S.fb[par].fc;
                 const unsigned long long t0 = wall_clock64();
+                int fb = 0;
                 while (__hip_atomic_load(&fc.row_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
                     __builtin_amdgcn_s_sleep(8);
-                    if (wall_clock64() - t0 > 200000000ull) {
-                        ctl.state = 3;
-                        atomicAdd(&ctl.gate_fatal, 1);
+                    if (wall_clock64() - t0 > 500000ull) {
+                        atomicAdd(&ctl.gate_timeouts, 1);
+                        fb = 1;
                         break;
                     }
                 }
+                s_row_fallback = fb;
             }
             __syncthreads();
+            if (s_row_fallback) {
+                CandLds C;  // carve the (not yet used) list area of the resolver, as k_track_mid's second pass does
+                C.lbuf = r_lists;
+                C.tx = reinterpret_cast<float *>(r_lists + 16 * KC);
+                C.ty = C.tx + NF_MAX;
+                C.tc = reinterpret_cast<uint32_t *>(C.ty + NF_MAX);
+                candidates_body<MODE_ROW>(S, 0, par, C, wave_id(), RES_THREADS / 64, RES_THREADS);
+                __syncthreads();
+            }
         }
         resolve_body<MODE_ROW>(S, ctl, 0, par, L, r_tab);
         __syncthreads();
@@ -2085,6 +2111,7 @@ __global__ __launch_bounds__(1024) void k_triangulate(SeqArg<BV> sa, int par, se
         ctl.counts[C_STAGED_SIZE] = *S.staged_n;
         ctl.overflow |= S.fb[par].fc->overflow;
         ctl.counts[C_OVERFLOW] = ctl.overflow;
+        ctl.skip = 0;  // (a skipped frame ends here: every workgroup of k_match_map has read the flag long ago)
         ctl.dbg[46] = (long long)wall_clock64();
         if (run) {  // bring-up stamps of a triangulation frame (tools/cells_phases.py): staged update, row resolution, the rest
             ctl.dbg[20] = tq1 - tq0, ctl.dbg[21] = tq2 - tq1, ctl.dbg[22] = clock64() - tq2;

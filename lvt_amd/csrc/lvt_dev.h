@@ -86,7 +86,10 @@ struct Ctl {
     seq_t early_state;
     seq_t track_done_seq;  // last frame whose tracking chain has finished with its feature buffer (polled by k_gate_buf)
     int gate_timeouts;  // a gate gave up waiting and its stream stood down / cancelled (results unaffected)
-    int gate_fatal;     // a stream waited 2 s for data it cannot do without: the sequence was set LOST
+    int gate_fatal;     // a stream waited 2 s for data it cannot do without: the frame was SKIPPED (last pose returned, state kept)
+    int skip;           // set by the tracking stream's gate for the frame it is about to start: its features never arrived; consumed
+                        // (and cleared) by the frame prologue.  A time-out never turns into LOST: in the reference LOST depends on
+                        // match counts only (lvt_system.cpp:267-272), and it is sticky.
     // per-frame control, written by k_begin / later kernels
     int active;         // 0: LOST at frame start -> every kernel exits
     int first_frame;    // state was NOT_INITIALIZED at frame start
@@ -119,6 +122,8 @@ struct FeatCtl {        // per-frame state of the FEATURE stage (own stream, one
     int overflow;
     seq_t row_seq;    // ... of the frame whose row-match candidate lists it holds (k_row_done; polled by k_triangulate)
     unsigned done_blocks;  // workgroups of the feature stage's last kernel that have finished (the last one publishes feat_seq and resets this)
+    int poison;         // k_gate_buf gave up waiting for this buffer's previous user: the feature kernels of this frame must not touch it
+    seq_t skip_seq;     // ... and this frame (sequence number) has no features: the tracking chain skips it
     seq_t feat_seq;  // sequence number of the frame whose features this buffer holds, published by k_feat_done (polled by k_gate)
 };
 

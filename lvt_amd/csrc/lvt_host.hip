@@ -48,6 +48,9 @@ constexpr int ROW_BLOCKS = 32;
 constexpr int MATCH_BLOCKS_GATED = 16;  // k_match_map when it polls for the early stream itself (single sequence): see k_track.hip (8 / 16 / 32: 8 840 / 8 890 / 8 900 frames/s; fewer parked workgroups leave more CUs to other processes on the GPU)
 constexpr int ROW_BLOCKS_BATCH = 16;  // per sequence of a lock-step batch (16 sequences: 8 / 16 / 32 / 64 / 256 -> 30.8k / 36.9k / 35.8k / 35.0k / 31.1k frames/s)
 constexpr int RING = 8;  // frames that may be in flight / un-collected
+// handles per DEVICE whose k_match_map may poll for the early stream itself: each parks MATCH_BLOCKS_GATED workgroups with 50 KB of LDS;
+// 4 x 16 of them still leave most CUs with the 159 KB a k_cells workgroup needs, more handles use the separate one-wave gate kernel
+constexpr int MAX_FOLDED_GATES = 4;
 
 // first kernel of the feature stage of a BATCH: publish every sequence's inputs (a single sequence gets them as a kernel
 // argument of k_score)
@@ -84,12 +87,15 @@ __global__ __launch_bounds__(256) void k_stage_copy(const uint4 *src, uint4 *dst
 // handles alive in this process: a handle whose k_match_map polls for its early stream parks 32 workgroups (50 KB of LDS each)
 // on the GPU; with many handles on one device that would leave no CU with enough free LDS for the 159-KB k_cells workgroups
 // they are waiting for -- beyond 4 handles the separate one-wave gate kernel is used again (enqueue_frame)
-static std::atomic<int> g_live_contexts{0};
+// Counted PER DEVICE: handles on different GPUs of one process share no hardware queue and no CU.
+constexpr int MAX_DEVICES = 64;
+static std::atomic<int> g_live_contexts[MAX_DEVICES];
 
 struct Context {
     double host_enq_us = 0, host_wait_us = 0;  // host time spent enqueueing / blocking (LVT_AMD_HOST_TIMING=1 prints it at destroy)
     long host_enq_n = 0, host_wait_n = 0;
     int gate_timeouts_seen = 0, gate_fatal_seen = 0;
+    int device = 0;            // the HIP device that owns every allocation, stream and event of this handle (recorded at creation)
     int B = 1;                 // sequences advanced in lock-step by one launch chain
     int sensor = 1;
     Params prm{};
@@ -148,9 +154,16 @@ struct Context {
         return static_cast<T *>(p);
     }
 
-    Context() { g_live_contexts.fetch_add(1); }
+    bool counted = false;
+    void count_in(int dev) {
+        device = dev;
+        g_live_contexts[dev % MAX_DEVICES].fetch_add(1);
+        counted = true;
+    }
+    int live_on_device() const { return g_live_contexts[device % MAX_DEVICES].load(); }
+    Context() {}
     ~Context() {
-        g_live_contexts.fetch_sub(1);
+        if (counted) g_live_contexts[device % MAX_DEVICES].fetch_sub(1);
         if (stream) (void)hipStreamSynchronize(stream);
         if (stream_f) (void)hipStreamSynchronize(stream_f);
         if (stream_e) (void)hipStreamSynchronize(stream_e);
@@ -167,6 +180,20 @@ struct Context {
         if (stream && own_stream) (void)hipStreamDestroy(stream);
         if (stream_f) (void)hipStreamDestroy(stream_f);
         if (stream_e) (void)hipStreamDestroy(stream_e);
+    }
+};
+
+// A handle belongs to the device that was current when it was created (or the one named to lvt_amd_create_on_device).  Every entry
+// point makes that device current for the duration of the call and restores the caller's: a thread-per-GPU process can
+// drive its handles from any thread without calling hipSetDevice itself.
+struct DeviceGuard {
+    int prev = -1;
+    explicit DeviceGuard(const Context *c) {
+        int cur = -1;
+        if (c && hipGetDevice(&cur) == hipSuccess && cur != c->device && hipSetDevice(c->device) == hipSuccess) prev = cur;
+    }
+    ~DeviceGuard() {
+        if (prev >= 0) (void)hipSetDevice(prev);
     }
 };
 
@@ -331,14 +358,21 @@ static void reset_state(Context *c) {  // lvt_system::reset (lvt_system.cpp:44-6
     HIPCHK(c, hipStreamSynchronize(c->stream));
 }
 
-static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
+static Context *create_context(const lvt_amd_params &in, int sensor, int B, int device = -1) {
     if (sensor != 1 && sensor != 2) return nullptr;
     Params prm;
     if (!derive_params(in, sensor, prm)) return nullptr;
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return nullptr;  // no CPU fallback, by design
+    int cur = 0;
+    if (hipGetDevice(&cur) != hipSuccess) return nullptr;
+    if (device < 0) device = cur;
+    if (device >= ndev) return nullptr;
     Context *c = new Context();
+    c->device = device;
+    DeviceGuard guard(c);
     try {
+        c->count_in(device);
         c->B = B;
         c->sensor = sensor;
         c->prm = prm;
@@ -356,7 +390,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B) {
             const char *o = std::getenv("LVT_AMD_ORDERING");
             if (o && std::strcmp(o, "events") == 0) c->events_only = true;
             else if (o && std::strcmp(o, "polling") == 0) c->events_only = false;
-            else c->events_only = B == 1 && g_live_contexts.load() > 1;
+            else c->events_only = B == 1 && c->live_on_device() > 1;
         }
         c->pitch = ((prm.W + 63) / 64) * 64;
         HIPCHK(c, hipHostMalloc((void **)&c->h_ctl, sizeof(Ctl) * B * RING, hipHostMallocCoherent));
@@ -501,7 +535,7 @@ static void enqueue_frame(Context *c) {
     const bool evo = c->events_only;
     if (c->enq >= NPAR) {
         if (!evo)
-            hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, B), dim3(64), 0, sf, S, (seq_t)(c->enq + 1 - NPAR));  // polls; see k_gate_buf
+            hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, B), dim3(64), 0, sf, S, (seq_t)(c->enq + 1 - NPAR), par);  // polls; see k_gate_buf
         else
             (void)hipStreamWaitEvent(sf, c->ev_done[(int)((c->enq - NPAR) % RING)], 0);
     }
@@ -551,7 +585,7 @@ static void enqueue_frame(Context *c) {
         if (evo) {
             (void)hipStreamWaitEvent(st, c->ev_feat[par], 0);  // (the early stream never claims the frame: early_ran_seq stays behind)
             LAUNCH_S(8, st, k_match_map, dim3(256, 1, B), dim3(256), 0, par, seq, 0, (Ctl *)nullptr, (seq_t *)nullptr);
-        } else if (B == 1 && g_live_contexts.load() <= 4) {
+        } else if (B == 1 && c->live_on_device() <= MAX_FOLDED_GATES) {
             // one launch: delivers the record, waits for the early stream (polled, no barrier packet), lists the points appended since
             LAUNCH_S(8, st, k_match_map, dim3(MATCH_BLOCKS_GATED, 1, 1), dim3(256), 0, par, seq, 1, prec, pdone);
         } else {
@@ -632,13 +666,13 @@ static void collect_oldest(Context *c) {
         const Ctl &r = c->h_ctl[(size_t)slot * c->B + s];
         if (r.gate_fatal != c->gate_fatal_seen) {
             c->gate_fatal_seen = r.gate_fatal;
-            c->set_error("a stream waited 2 s for another one (features / buffer hand-over): the frame could not be tracked (state LOST); under a tool that "
-                         "serialises kernel dispatches (rocprofv3 --pmc) set LVT_AMD_ORDERING=events");
+            c->set_error("a stream waited 2 s for another one (features / buffer hand-over): a frame was SKIPPED (its pose is the previous frame's, the "
+                         "tracking state is unchanged); under a tool that serialises kernel dispatches (rocprofv3 --pmc) set LVT_AMD_ORDERING=events");
         } else if (r.gate_timeouts != c->gate_timeouts_seen) {
             c->gate_timeouts_seen = r.gate_timeouts;
-            // not a wrong result (the frame was tracked without the early stream), but >= 20 ms were lost: the streams do
-            // not run concurrently (shared hardware queue, or a tool that serialises the dispatches)
-            c->set_error("early-stream gate timed out (results unaffected; the streams do not run concurrently: LVT_AMD_ORDERING=events avoids the waits)");
+            // not a wrong result (the frame was tracked without the early stream / with row lists built on the tracking stream), but
+            // milliseconds were lost: the streams do not run concurrently (shared hardware queue, or a tool that serialises the dispatches)
+            c->set_error("a stream gate timed out (results unaffected; the streams do not run concurrently: LVT_AMD_ORDERING=events avoids the waits)");
         }
     }
 }
@@ -691,6 +725,15 @@ LVT_API lvt_handle lvt_amd_create(const lvt_amd_params *p, int sensor_type) {
     return nullptr;
 }
 
+LVT_API lvt_handle lvt_amd_create_on_device(const lvt_amd_params *p, int sensor_type, int device) {
+    try {
+        return static_cast<lvt_handle>(create_context(*p, sensor_type, 1, device));
+    } catch (...) {
+    }
+    return nullptr;
+}
+LVT_API int lvt_amd_get_device(lvt_handle h) { return h ? static_cast<Context *>(h)->device : -1; }
+
 LVT_API lvt_handle lvt_create(const char *config_file_name, int sensor_type) {
     try {
         lvt_amd_params p;
@@ -710,6 +753,7 @@ LVT_API void lvt_destroy(lvt_handle h) {
                          c->host_enq_us / c->host_enq_n, c->host_wait_n, c->host_wait_us / std::max(c->host_wait_n, 1L));
     }
     try {
+        DeviceGuard guard(static_cast<Context *>(h));
         delete static_cast<Context *>(h);
     } catch (...) {
     }
@@ -717,6 +761,7 @@ LVT_API void lvt_destroy(lvt_handle h) {
 
 LVT_API void lvt_amd_reset(lvt_handle h) {
     try {
+        DeviceGuard guard(static_cast<Context *>(h));
         reset_state(static_cast<Context *>(h));
     } catch (...) {
     }
@@ -724,6 +769,7 @@ LVT_API void lvt_amd_reset(lvt_handle h) {
 
 LVT_API void lvt_amd_set_stream(lvt_handle h, void *hip_stream) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         drain(c);
         if (c->own_stream && c->stream) (void)hipStreamDestroy(c->stream);
@@ -740,6 +786,7 @@ LVT_API const char *lvt_amd_last_error(lvt_handle h) {
 
 LVT_API void lvt_amd_profile_enable(lvt_handle h, int enable) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         drain(c);
         if (enable) {
@@ -754,6 +801,7 @@ LVT_API void lvt_amd_profile_enable(lvt_handle h, int enable) {
 }
 LVT_API int lvt_amd_profile_read(lvt_handle h, int slot, char *name, int name_cap, double *total_ms, long *calls) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     if (slot < 0 || slot >= Context::PROF_SLOTS || !kProfNames[slot][0]) return 0;
     std::snprintf(name, name_cap, "%s", kProfNames[slot]);
     *total_ms = c->prof_ms[slot];
@@ -763,6 +811,7 @@ LVT_API int lvt_amd_profile_read(lvt_handle h, int slot, char *name, int name_ca
 
 LVT_API void lvt_amd_track_device_async(lvt_handle h, const void *d_left, const void *d_right, int n_rows, int n_cols, int pitch_bytes) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         if (!size_ok(c, n_rows, n_cols) || (pitch_bytes & 15)) {
             c->set_error("lvt_amd_track_device: image size / pitch mismatch");
@@ -796,6 +845,7 @@ LVT_API int lvt_amd_batch_size(lvt_handle h) { return static_cast<Context *>(h)-
 LVT_API void lvt_amd_batch_track_device_async(lvt_handle h, const void *const *d_left, const void *const *d_right, int n_rows, int n_cols,
                                               int pitch_bytes) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         if (!size_ok(c, n_rows, n_cols) || (pitch_bytes & 15)) {
             c->set_error("lvt_amd_batch_track_device: image size / pitch mismatch");
@@ -819,6 +869,7 @@ LVT_API void lvt_amd_batch_track_device_async(lvt_handle h, const void *const *d
 // poses of the oldest un-collected batch frame: R = B x 9 doubles (row-major 3x3 each), t = B x 3, status = B ints
 LVT_API void lvt_amd_batch_wait(lvt_handle h, double *R, double *t, int *status) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         if (c->done < c->enq) collect_oldest(c);
         for (int s = 0; s < c->B; s++) {
@@ -832,6 +883,7 @@ LVT_API void lvt_amd_batch_wait(lvt_handle h, double *R, double *t, int *status)
 }
 LVT_API void lvt_amd_batch_get_counts(lvt_handle h, int seq, int out[LVT_AMD_C__COUNT]) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         drain(c);
         if (seq < 0 || seq >= c->B) return;
@@ -842,6 +894,7 @@ LVT_API void lvt_amd_batch_get_counts(lvt_handle h, int seq, int out[LVT_AMD_C__
 
 LVT_API void lvt_amd_wait(lvt_handle h, double R[3][3], double t[3]) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         if (c->done < c->enq) collect_oldest(c);  // FIFO: the oldest frame not yet collected
         result_out(c, 0, R, t);
@@ -849,9 +902,22 @@ LVT_API void lvt_amd_wait(lvt_handle h, double R[3][3], double t[3]) {
     }
 }
 
+LVT_API int lvt_amd_wait_status(lvt_handle h, double R[3][3], double t[3]) {  // lvt_amd_wait + the tracking state AFTER that frame (1 / 2 / 3; -1: error)
+    Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
+    try {
+        if (c->done < c->enq) collect_oldest(c);
+        result_out(c, 0, R, t);
+        return last_ctl(c).state;
+    } catch (...) {
+    }
+    return -1;
+}
+
 LVT_API void lvt_amd_track_device(lvt_handle h, const void *d_left, const void *d_right, int n_rows, int n_cols, int pitch_bytes,
                                   double R[3][3], double t[3]) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     if (!size_ok(c, n_rows, n_cols) || (pitch_bytes & 15)) {
         c->set_error("lvt_amd_track_device: image size / pitch mismatch");
         return;  // outputs untouched, like the reference on an exception
@@ -886,14 +952,16 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
     // the borrowed buffers are copied into pinned memory by the CPU and the GPU pulls them from there -- unless the caller's
     // buffer already IS pinned host memory (hipHostMalloc / hipHostRegister, 16-byte aligned): then the GPU reads it in place
     // (this call only returns after the frame has been tracked, so the buffer outlives every read)
-    auto device_view = [](const void *p) -> const uint8_t * {
+    // (k_stage_in / k_stage_copy read whole 16-byte vectors: a borrowed buffer is only read in place when its byte count is a
+    //  multiple of 16 -- otherwise the last vector would reach up to 15 bytes past its end, possibly past a registered page)
+    auto device_view = [](const void *p, size_t bytes) -> const uint8_t * {
         hipPointerAttribute_t a;
-        if (((uintptr_t)p & 15) == 0 && hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost && a.devicePointer)
+        if (((uintptr_t)p & 15) == 0 && (bytes & 15) == 0 && hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost && a.devicePointer)
             return static_cast<const uint8_t *>(a.devicePointer);
         (void)hipGetLastError();  // (an ordinary malloc'ed pointer is "invalid value" to the query: not an error of this call)
         return nullptr;
     };
-    const uint8_t *s0 = device_view(left), *s1 = device_view(second);
+    const uint8_t *s0 = device_view(left, nbytes), *s1 = device_view(second, rgbd ? sizeof(float) * nbytes : nbytes);
     if (!s0) {
         std::memcpy(c->h_stage[par], left, nbytes);
         s0 = c->h_stage_dev[par];
@@ -931,6 +999,7 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
 
 LVT_API void lvt_track(lvt_handle h, unsigned char *left, unsigned char *right, int n_rows, int n_cols, double R[3][3], double t[3]) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         if (c->sensor != 1) return;  // the reference cannot run RGB-D through this entry either
         upload_and_track(c, left, right, false, n_rows, n_cols, 0, nullptr, 0, nullptr, 0, R, t);
@@ -941,6 +1010,7 @@ LVT_API void lvt_track(lvt_handle h, unsigned char *left, unsigned char *right, 
 LVT_API void lvt_amd_track_rgbd(lvt_handle h, const unsigned char *gray, const float *depth, int n_rows, int n_cols, double R[3][3],
                                 double t[3]) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         if (c->sensor != 2) return;
         upload_and_track(c, gray, depth, true, n_rows, n_cols, 0, nullptr, 0, nullptr, 0, R, t);
@@ -952,8 +1022,16 @@ LVT_API void lvt_track_with_external_corners(lvt_handle h, unsigned char *left, 
                                              double corners_left[][2], int n_corners_left, double corners_right[][2],
                                              int n_corners_right, double R[3][3], double t[3]) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         if (c->sensor != 1) return;
+        if (n_corners_left < 0 || n_corners_right < 0) return;
+        if (n_corners_left > EXT_MAX || n_corners_right > EXT_MAX) {  // (the reference takes any number; here the lists are cut -- never silently)
+            char buf[160];
+            std::snprintf(buf, sizeof(buf), "lvt_track_with_external_corners: %d / %d corners, only the first %d of a list are used", n_corners_left,
+                          n_corners_right, EXT_MAX);
+            c->set_error(buf);
+        }
         const int ncl = std::min(n_corners_left, EXT_MAX), ncr = std::min(n_corners_right, EXT_MAX);
         std::vector<float> cl(2 * (size_t)ncl + 2), cr(2 * (size_t)ncr + 2);
         for (int i = 0; i < ncl; i++) {  // doubles narrowed to float (lvt_c.cpp:104-117)
@@ -972,6 +1050,7 @@ LVT_API void lvt_track_with_external_corners(lvt_handle h, unsigned char *left, 
 LVT_API int lvt_get_status(lvt_handle h) {
     try {
         Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
         drain(c);
         return last_ctl(c).state;
     } catch (...) {
@@ -982,6 +1061,7 @@ LVT_API int lvt_get_status(lvt_handle h) {
 // ---- introspection (of the most recently COLLECTED frame; drains the pipeline first) -----------------
 LVT_API void lvt_amd_get_counts(lvt_handle h, int out[LVT_AMD_C__COUNT]) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         drain(c);
         for (int i = 0; i < LVT_AMD_C__COUNT; i++) out[i] = last_ctl(c).counts[i];
@@ -991,6 +1071,7 @@ LVT_API void lvt_amd_get_counts(lvt_handle h, int out[LVT_AMD_C__COUNT]) {
 
 LVT_API int lvt_amd_get_features(lvt_handle h, int eye, float *xy, float *resp, uint8_t *desc, int cap) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         drain(c);
         const Feat &F = c->h_seqs[0].fb[c->last_par].feat[eye ? 1 : 0];
@@ -1010,6 +1091,7 @@ LVT_API int lvt_amd_get_features(lvt_handle h, int eye, float *xy, float *resp, 
 
 LVT_API int lvt_amd_get_matches(lvt_handle h, int *feat_idx, double *xyz, int cap) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         drain(c);
         const int n = last_ctl(c).n_matches, m = std::min(n, cap);
@@ -1023,6 +1105,7 @@ LVT_API int lvt_amd_get_matches(lvt_handle h, int *feat_idx, double *xyz, int ca
 
 LVT_API int lvt_amd_get_row_matches(lvt_handle h, int *pairs, int cap) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         drain(c);
         const int n = last_ctl(c).counts[C_N_ROW_MATCHES], m = std::min(n, cap);
@@ -1048,6 +1131,7 @@ static int get_points(Context *c, const MapSoA *bufs, const int *d_cur, const in
 }
 LVT_API int lvt_amd_get_map(lvt_handle h, double *xyz, int *counter, int *age, uint8_t *desc, int cap) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         drain(c);
         const Seq &S = c->h_seqs[0];
@@ -1058,6 +1142,7 @@ LVT_API int lvt_amd_get_map(lvt_handle h, double *xyz, int *counter, int *age, u
 }
 LVT_API int lvt_amd_get_staged(lvt_handle h, double *xyz, int *counter, uint8_t *desc, int cap) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         drain(c);
         const Seq &S = c->h_seqs[0];
@@ -1068,6 +1153,7 @@ LVT_API int lvt_amd_get_staged(lvt_handle h, double *xyz, int *counter, uint8_t 
 }
 LVT_API void lvt_amd_get_pose(lvt_handle h, double q[4], double p[3]) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         drain(c);
         for (int k = 0; k < 4; k++) q[k] = last_ctl(c).last_pose.q[k];
@@ -1077,6 +1163,7 @@ LVT_API void lvt_amd_get_pose(lvt_handle h, double q[4], double p[3]) {
 }
 LVT_API void lvt_amd_get_predicted_pose(lvt_handle h, double q[4], double p[3]) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         drain(c);
         for (int k = 0; k < 4; k++) q[k] = last_ctl(c).predicted.q[k];
@@ -1086,6 +1173,7 @@ LVT_API void lvt_amd_get_predicted_pose(lvt_handle h, double q[4], double p[3]) 
 }
 LVT_API void lvt_amd_get_debug(lvt_handle h, long long out[32]) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         drain(c);
         for (int i = 0; i < 32; i++) out[i] = last_ctl(c).dbg[i];
@@ -1097,10 +1185,12 @@ LVT_API int lvt_amd_get_ordering(lvt_handle h) {  // 0: polling gates + early st
 }
 LVT_API void lvt_amd_get_timeline(lvt_handle h, long long out[16]) {  // of the frame lvt_amd_wait returned last; does not drain
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     for (int i = 0; i < 16; i++) out[i] = last_ctl(c).dbg[32 + i];
 }
 LVT_API int lvt_amd_get_plane(lvt_handle h, int eye, int what, void *dst, int cap_bytes, int *pitch_out) {
     Context *c = static_cast<Context *>(h);
+    DeviceGuard guard(c);
     try {
         drain(c);
         const FrameBuf &FB = c->h_seqs[0].fb[c->last_par];

@@ -1,8 +1,24 @@
-"""Multi-GPU sharding of independent sequences: sequence s -> rank s mod G, no data-path collective.
-The only cross-rank traffic is the barrier + MAX-reduce that brackets the timed region of bench.py."""
+"""Multi-GPU sharding of independent sequences: sequence s -> rank s mod G, one process per GPU, NO data-path
+collective ("replicas only": frame k of a sequence depends on the map after frame k-1, sequences share nothing).  The only
+cross-rank traffic is the barrier + MAX-reduce that brackets the timed region and a SUM of the lost-frame counts.
+bench.py's rank body is built from these helpers; tests/test_shard_gloo.py runs that same rank body on gloo, world size 2."""
 from __future__ import annotations
 
+import os
 import time
+from dataclasses import dataclass
+
+
+@dataclass
+class RankEnv:
+    rank: int
+    local_rank: int
+    world_size: int
+
+
+def rank_env() -> RankEnv:
+    """what torch.distributed.run exports for one-process-per-GPU launches (absent: a single process)"""
+    return RankEnv(int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")), int(os.environ.get("WORLD_SIZE", "1")))
 
 
 def assign_sequences(n_sequences: int, world_size: int, rank: int):
@@ -25,6 +41,15 @@ def timed_region(fn, dist=None, sync=None, device=None):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     return dt, out
+
+
+def sum_over_ranks(value: int, dist=None, device=None) -> int:
+    import torch
+    if dist is None:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return int(t.item())
 
 
 def aggregate_fps(frames_per_rank: int, world_size: int, elapsed_max: float) -> float:

@@ -316,8 +316,9 @@ print("RESULT " + json.dumps(out))
 
 def test_serialised_dispatches_are_reported_not_silently_wrong(hip_lib, tmp_path):
     """rocprofv3 --pmc serialises the dispatches of all queues: a polling gate then holds the only dispatch slot.  In the default
-    ordering the library must say so (error string; LOST when a frame's features never arrived) -- and every pose it does return
-    must be the right one; with LVT_AMD_ORDERING=events the same run is clean."""
+    ordering the library must say so (error string) and must never turn a time-out into LOST (sticky; in the reference a matter of
+    match counts only): a frame whose features never arrived is SKIPPED -- last pose, state kept.  Until the first reported problem
+    every pose is the right one; with LVT_AMD_ORDERING=events the same run is clean."""
     import json, os, shutil, subprocess, sys
     if not shutil.which("rocprofv3"):
         pytest.skip("rocprofv3 not on PATH")
@@ -346,9 +347,9 @@ def test_serialised_dispatches_are_reported_not_silently_wrong(hip_lib, tmp_path
     saw_report = False
     for f, g in zip(runs["pmc_default"], ref):
         saw_report |= f["err"] != ""
-        assert f["state"] == 3 or f["t"] == g["t"]      # a returned TRACKING pose is the right pose
-        if f["state"] == 3:
-            assert f["err"] != ""                        # LOST is never silent
+        assert f["state"] != 3, "a time-out must never cost the track"
+        if not saw_report:
+            assert f["t"] == g["t"]                      # nothing reported so far: the pose is the right pose
     assert saw_report
 
 
@@ -466,6 +467,45 @@ def test_handles_are_independent_across_host_threads(hip_lib):
     for k in range(2):
         for i, ((Ra, ta), (Rb, tb)) in enumerate(zip(ref[k], got[k])):
             assert np.array_equal(ta, tb) and np.array_equal(Ra, Rb), f"handle {k} frame {i}"
+
+
+def test_a_handle_owns_its_device(hip_lib):
+    """a handle records the HIP device it was created on and makes it current inside every entry point (one process may
+    drive one handle per GPU from any thread).  On a multi-GPU box: two handles on two devices, each driven by a thread whose
+    current device is the OTHER one, both equal to a plain run; each is the first live handle of ITS device (polling gates)."""
+    import threading
+    import torch
+    n = torch.cuda.device_count()
+    world, prm, sensor = make_case("kitti", 40, 0.5)
+    frames = [world.render_stereo(i) for i in range(6)]
+    ref = hip_lib.LvtSystem.create(prm, 1)
+    assert ref.device() == torch.cuda.current_device()
+    want = [ref.track(a, b)[1].copy() for a, b in frames]
+    ref.close()
+    with pytest.raises(RuntimeError):
+        hip_lib.LvtSystem.create(prm, 1, device=n)              # no such device: NULL, no fallback
+    devs = [0, 1] if n >= 2 else [0]
+    got, errs = {}, {}
+
+    def drive(d):
+        if n >= 2:
+            torch.cuda.set_device(1 - d)                         # the calling thread's current device is NOT the handle's
+        vo = hip_lib.LvtSystem.create(prm, 1, device=d)
+        got[d] = [vo.track(a, b)[1].copy() for a, b in frames]
+        errs[d] = (vo.device(), vo.ordering(), vo.last_error(), vo.get_state())
+        if n >= 2:
+            assert torch.cuda.current_device() == 1 - d          # restored after every call
+        vo.close()
+    ths = [threading.Thread(target=drive, args=(d,)) for d in devs]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    for d in devs:
+        assert errs[d] == (d, "polling", "", 2), errs[d]
+        assert all(np.array_equal(x, y) for x, y in zip(got[d], want))
+    if n < 2:
+        pytest.skip("one GPU: the two-device half needs a multi-GPU box (the owning-device bookkeeping above ran)")
 
 
 def test_wrong_image_size_is_refused_and_reported(hip_lib):

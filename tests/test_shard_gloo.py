@@ -1,51 +1,88 @@
-"""CPU tier: the N > 1 path of bench.py (sequence -> rank sharding, barrier + MAX-over-ranks timing) with
-world_size 2 on gloo.  No data-path collective exists: ranks only meet at the barrier / timing reduce."""
+"""CPU tier: the N > 1 path that bench.py really runs -- its own rank body (`bench.run_rank`: warm-up, the timed region between
+barriers, MAX-over-ranks time, SUM of the lost-frame counts, whole-job frames/s, the JSON skeleton) on gloo with world size 2.
+Only the per-step work is a stand-in (no GPU here): a backend with the same five methods as bench.HipBackend whose "frames" take a
+known time.  No data-path collective exists: the ranks meet at the barrier and at two scalar reductions."""
 import os
 import socket
+import sys
+import time
 
-import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from lvt_amd.shard import assign_sequences, aggregate_fps, timed_region
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+from lvt_amd.shard import RankEnv, assign_sequences  # noqa: E402
 
 
 def _free_port():
     s = socket.socket(); s.bind(("127.0.0.1", 0)); p = s.getsockname()[1]; s.close(); return p
 
 
-def _worker(rank, world, port, ret):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
-    dist.init_process_group("gloo", rank=rank, world_size=world)
-    import numpy as np
-    import sys
-    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from parity_util import make_case
-    from oracle import pyoracle as O
-    seqs = assign_sequences(8, world, rank)
-    world_, prm, _ = make_case("kitti", seed=seqs[0], scale=0.25)
-    orc = O.Oracle(prm, 1, threads=1)       # stand-in step function on CPU (tests may use the oracle)
-    frames = [world_.render_stereo(i) for i in range(3)]
+class StandInBackend:
+    """what bench.HipBackend offers to run_rank, with sleeps for steps: rank r's step takes (1 + r) * 5 ms, rank 1 loses one frame"""
+    device = None                       # gloo: the reductions run on CPU tensors
+    sequences_per_gpu = 1
+    workload = "stand-in"
 
-    def body():
-        import time
-        if rank == 1:
-            time.sleep(0.25)                # the slow rank must set the reported time
-        return [orc.track(a, b)[1] for a, b in frames]
-    dt, poses = timed_region(body, dist=dist)
-    ret[rank] = (seqs, dt, float(np.abs(poses[-1]).sum()), aggregate_fps(len(frames), world, dt))
+    def __init__(self, env):
+        self.env = env
+        self.log = []
+
+    def sync(self):
+        self.log.append("sync")
+
+    def prepare(self, n_frames):
+        self.seqs = assign_sequences(8, self.env.world_size, self.env.rank)
+        self.n_frames = n_frames
+
+    def warmup(self, Wm):
+        self.log.append(("warmup", Wm))
+        return [None] * Wm
+
+    def timed(self, first, K, depth):
+        assert first + K == self.n_frames
+        for _ in range(K):
+            time.sleep(0.005 * (1 + self.env.rank))
+        return [(None, None)] * K, (1 if self.env.rank == 1 else 0)
+
+    def extras(self, args, env, warm, poses):
+        assert env.rank == 0 and len(poses) == args.steps and len(warm) == args.warmup
+        return {"roofline": None, "cpu_baseline": None}
+
+
+def _worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import bench
+    from lvt_amd.shard import rank_env
+    env = rank_env()
+    assert env == RankEnv(rank, rank, world)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    args = bench.parse_args(["--gpus", str(world), "--steps", "12", "--warmup", "3"])
+    be = StandInBackend(env)
+    res = bench.run_rank(args, env, dist, be)
+    ret[rank] = (res, be.seqs, be.log)
+    dist.barrier()
     dist.destroy_process_group()
 
 
-def test_world_size_2_sharding_and_timing():
+def test_bench_rank_body_on_gloo_world_size_2():
     mgr = mp.Manager(); ret = mgr.dict()
-    port = _free_port()
-    mp.spawn(_worker, args=(2, port, ret), nprocs=2, join=True)
-    (s0, t0, p0, f0), (s1, t1, p1, f1) = ret[0], ret[1]
+    mp.spawn(_worker, args=(2, _free_port(), ret), nprocs=2, join=True)
+    (r0, s0, log0), (r1, s1, log1) = ret[0], ret[1]
     assert s0 == [0, 2, 4, 6] and s1 == [1, 3, 5, 7]           # s mod G, disjoint, covers all 8 sequences
-    assert abs(t0 - t1) < 1e-9 and t0 >= 0.25                    # MAX over ranks, identical on every rank
-    assert p0 != p1                                              # different sequences were processed
-    assert abs(f0 - 2 * 3 / t0) < 1e-9 and f0 == f1
+    assert r1 is None and r0 is not None                        # rank 0 alone reports
+    assert r0["n_gpus"] == 2 and r0["steps"] == 12 and r0["warmup"] == 3 and r0["scaling"] == "weak" and r0["higher_is_better"] is True
+    # the slow rank (10 ms per step) sets the time: MAX over ranks, and value = frames of ALL ranks / that time
+    assert r0["ms_per_step"] >= 10.0 and r0["ms_per_step"] < 40.0
+    assert abs(r0["value"] - 2 * 12 / (r0["ms_per_step"] * 12e-3)) < 0.05 * r0["value"]
+    assert r0["tracking"]["frames_not_tracking"] == 1           # SUM over ranks: rank 1's lost frame shows up in rank 0's line
+    for log in (log0, log1):                                    # device sync on both sides of the timed region, warm-up first
+        assert log[0] == ("warmup", 3) and log.count("sync") == 2
+    for k in ("metric", "value", "unit", "config", "vs_baseline", "dtype", "data", "roofline", "cpu_baseline"):
+        assert k in r0
 
 
 def test_assignment_covers_every_gpu_count():

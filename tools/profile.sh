@@ -2,19 +2,19 @@
 # rocprofv3 evidence for bench.py (run on the GPU box through gpurun).  Raw traces stay in /tmp; compact per-kernel
 # summaries of OUR kernels (lvt::*) go to gpurun_out/prof_<tag>/ and from there into profiles/.
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
-TAG=${1:-r01}
+TAG=${1:-r02}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_*
-BENCH="python $ROOT/bench.py --steps 400 --warmup 20 --no-cpu --profile-steps 0"
+BENCH="python $ROOT/bench.py --steps 400 --warmup 20 --skip kernels,sync,batch,configs,cpu"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_trace -o bench -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_batch -o bench -- python $ROOT/bench.py --steps 100 --warmup 10 --seqs-per-gpu 16 --depth 2 > $OUT/bench_batch16_under_rocprof.json 2> /dev/null
 # PMC: separate passes, counters only (no trace domains) -- FETCH_SIZE and WRITE_SIZE cannot share a pass
 # (counter collection serialises the dispatches of all queues: the pipeline must not use its polling gates -> LVT_AMD_ORDERING=events;
 #  the timeout only guards the box)
-LVT_AMD_ORDERING=events timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -o bench -- python $ROOT/bench.py --steps 60 --warmup 5 --no-cpu --profile-steps 0 > $OUT/bench_under_pmc.json 2>&1
-LVT_AMD_ORDERING=events timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -o bench -- python $ROOT/bench.py --steps 60 --warmup 5 --no-cpu --profile-steps 0 > /dev/null 2>&1
+LVT_AMD_ORDERING=events timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -o bench -- python $ROOT/bench.py --steps 60 --warmup 5 --skip kernels,sync,batch,configs,cpu > $OUT/bench_under_pmc.json 2>&1
+LVT_AMD_ORDERING=events timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -o bench -- python $ROOT/bench.py --steps 60 --warmup 5 --skip kernels,sync,batch,configs,cpu > /dev/null 2>&1
 python - "$OUT" <<'PY'
 import csv, sys, glob, collections
 out = sys.argv[1]
@@ -26,11 +26,12 @@ def stats(src, dst):
     csv.writer(open(dst, "w")).writerows(keep)
     print("==", dst); [print(",".join(r[:4])) for r in keep]
 stats("/tmp/prof_trace", out + "/kernel_stats_single.csv")
-# per-dispatch durations of the matcher (bench.py: 80 warm-up launches while the clocks ramp up, then 35 timed ones)
+# per-dispatch durations of the radius-mode matcher instance (bench.py warms the clocks up with 80 launches of the ROW-mode instance, so this
+# instance's --stats row holds 3 untimed + the 35 reported launches)
 f = glob.glob("/tmp/prof_trace/**/*kernel_trace.csv", recursive=True)
 if f:
     rd = csv.DictReader(open(f[0]))
-    d = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rd if "k_hamming_batched" in r["Kernel_Name"]]
+    d = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rd if "k_hamming_batched<0" in r["Kernel_Name"]]
     d.sort()
     w = csv.writer(open(out + "/hamming_dispatch_durations.csv", "w")); w.writerow(["dispatch", "duration_ns"])
     for i, (_, ns) in enumerate(d): w.writerow([i, ns])

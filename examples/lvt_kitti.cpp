@@ -1,4 +1,6 @@
-// lvt_kitti -- KITTI-odometry command line harness over the lvt_c C-ABI.
+// lvt_kitti -- KITTI-odometry command line harness, written against the header-compatible C++ layer
+// include/lvt_system.h -- the calls below are the reference example's own (kitti_example.cpp:82-131: lvt_parameters,
+// lvt_system::create, vo->track, lvt_pose::get_position / get_orientation_matrix), with lvt_image_view where it has cv::Mat.
 //
 // Same argv, inputs and outputs as the reference's example binary (examples/kitti/kitti_example.cpp:49-152 there):
 //     lvt_kitti <sequences_dir> <seq_number> [--config vo_config.yaml] [--calib calib/NN.yml] [--max-frames N] [--out NN.txt]
@@ -7,8 +9,7 @@
 // 3x4 row format with the reference's precision (fixed, 9 digits) and prints the mean per-frame track() time.
 // No OpenCV: the PNG reader below handles what KITTI ships (8-bit gray / RGB / RGBA / gray+alpha, non-interlaced), colour
 // is reduced to gray with cv::cvtColor's fixed-point weights, and PGM (P5) is accepted for pre-converted data.
-#include "../include/lvt_amd_ext.h"
-#include "../include/lvt_c.h"
+#include "../include/lvt_system.h"
 
 #include "image_io.h"
 
@@ -76,8 +77,8 @@ int main(int argc, char **argv) {
         std::cout << "failed to open camera matrix yml file" << std::endl;
         return -1;
     }
-    lvt_amd_params params;
-    if (!lvt_amd_params_from_file(config.c_str(), &params)) {
+    lvt_parameters params;
+    if (!params.init_from_file(config.c_str())) {
         std::cout << "failed to initialize from vo_config.yml file." << std::endl;
         return -1;
     }
@@ -95,7 +96,7 @@ int main(int argc, char **argv) {
     params.fx = (float)K[0], params.fy = (float)K[4], params.cx = (float)K[2], params.cy = (float)K[5];
     params.baseline = (float)baseline;
     params.img_width = left.w, params.img_height = left.h;
-    lvt_handle vo = lvt_amd_create(&params, 1 /* STEREO */);
+    lvt_system *vo = lvt_system::create(params, lvt_system::eSensor_STEREO);
     if (!vo) {
         std::cout << "failed to create the tracker: " << lvt_amd_last_error(nullptr) << std::endl;
         return -1;
@@ -117,16 +118,17 @@ int main(int argc, char **argv) {
             break;
         }
         std::cout << "Frame number: " << i << "\r" << std::flush;
-        double R[3][3] = {{1, 0, 0}, {0, 1, 0}, {0, 0, 1}}, t[3] = {0, 0, 0};
         const auto t0 = std::chrono::steady_clock::now();
-        lvt_track(vo, left.px.data(), right.px.data(), left.h, left.w, R, t);
+        const lvt_pose pose = vo->track(lvt_image_view(left.px.data(), left.h, left.w), lvt_image_view(right.px.data(), right.h, right.w));
         total_time += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const lvt_vector3 pos = pose.get_position();  // kitti_example.cpp:40-47
+        const lvt_matrix33 R = pose.get_orientation_matrix();
         for (int r = 0; r < 3; r++) {
-            rows.push_back(R[r][0]), rows.push_back(R[r][1]), rows.push_back(R[r][2]);
-            rows.push_back(t[r]);
+            rows.push_back(R(r, 0)), rows.push_back(R(r, 1)), rows.push_back(R(r, 2));
+            rows.push_back(pos(r));
         }
         n++;
-        if (lvt_get_status(vo) == 3) break;  // LOST
+        if (vo->get_state() == lvt_system::eState_LOST) break;
     }
     std::ofstream file(out_name.c_str());
     file << std::fixed;
@@ -137,7 +139,7 @@ int main(int argc, char **argv) {
         file << std::endl;
     }
     file.close();
-    lvt_destroy(vo);
+    lvt_system::destroy(vo);
     std::cout << std::endl << "Frames: " << n << "/" << frame_count << "  Average frame processing time: " << (frame_count ? total_time / (double)frame_count : 0.0) << std::endl;
     return 0;
 }

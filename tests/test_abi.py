@@ -54,3 +54,36 @@ def test_product_does_not_reference_the_oracle():
                 if f.endswith((".py", ".hip", ".h", ".cpp", ".sh", ".inc")):
                     txt = open(os.path.join(base, f), errors="ignore").read()
                     assert "pyoracle" not in txt and "lvt_oracle" not in txt and "liblvt_oracle" not in txt and "from oracle" not in txt, (top, f)
+
+
+def test_lvt_system_facade_compiles_without_opencv_and_eigen(tmp_path):
+    """include/lvt_system.h (the reference's C++ API names over the C-ABI) is self-contained: a caller written
+    like the reference's examples compiles with neither OpenCV nor Eigen installed, and links against liblvt_c.so"""
+    import subprocess
+    src = tmp_path / "caller.cpp"
+    src.write_text(r'''
+#include "lvt_system.h"
+#include <cstdio>
+int main(int argc, char **argv) {
+    lvt_parameters params;                      // defaults of lvt_parameters.cpp:29-52
+    if (argc > 1 && !params.init_from_file(argv[1])) return 2;
+    params.fx = params.fy = 718.856f; params.cx = 607.19f; params.cy = 185.2f; params.baseline = 0.537f;
+    params.img_width = 1241; params.img_height = 376;
+    if (params.tracking_radius != 25 || params.staged_threshold != 2 || params.triangulation_policy != lvt_parameters::etriangulation_policy_decreasing_matches) return 3;
+    lvt_system *vo = lvt_system::create(params, lvt_system::eSensor_STEREO);   // NULL without a GPU: no CPU fallback
+    if (!vo) { std::printf("no device\n"); return 0; }
+    std::vector<unsigned char> l(1241 * 376, 7), r(1241 * 376, 7);
+    lvt_pose pose = vo->track(lvt_image_view(l.data(), 376, 1241), lvt_image_view(r.data(), 376, 1241));
+    lvt_vector3 p = pose.get_position(); lvt_matrix33 R = pose.get_orientation_matrix(); lvt_quaternion q = pose.get_orientation_quaternion();
+    lvt_pose_array poses(1); poses[0] = pose;
+    std::printf("%g %g %g %d %d\n", p.x() + p(1) + p.z(), R(0, 0), q.w(), (int)vo->get_state(), (int)vo->should_quit());
+    lvt_system::destroy(vo);
+    return 0;
+}
+''')
+    exe = tmp_path / "caller"
+    libdir = os.path.dirname(lvt_amd.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++11", "-Wall", "-Werror", "-DLVT_SYSTEM_NO_OPENCV", "-DLVT_SYSTEM_NO_EIGEN", "-I", os.path.join(ROOT, "include"), "-o", str(exe),
+                           str(src), "-L", libdir, "-llvt_c", "-Wl,-rpath," + libdir])
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr

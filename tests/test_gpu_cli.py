@@ -1,5 +1,7 @@
-"""examples/lvt_kitti (the dataset command line harness over the C-ABI) on a synthetic KITTI-layout
-directory: PNG / PGM decoding, calibration + config parsing and the trajectory file, against the Python binding."""
+"""examples/lvt_kitti / lvt_tum / lvt_euroc (the dataset command line harnesses over the C-ABI) on synthetic
+dataset-layout directories: PNG / PGM decoding, calibration + config parsing and the trajectory files.  Every trajectory is held
+FIRST against the CPU oracle's trajectory on the same decoded frames (per-frame SE3 within 1e-4, the tolerance of BASELINE.json),
+and then -- tighter, as a plumbing check -- against the Python binding of the same library."""
 import os
 import struct
 import subprocess
@@ -11,6 +13,20 @@ import pytest
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 EXE = os.path.join(ROOT, "examples", "lvt_kitti")
+POSE_TOL = 1e-4
+
+
+def _se3_close(R_cli, t_cli, R_orc, t_orc, what):
+    from parity_util import pose_errors
+    e_t, e_R = pose_errors(np.asarray(R_cli), np.asarray(t_cli), np.asarray(R_orc), np.asarray(t_orc))
+    assert e_t <= POSE_TOL and e_R <= POSE_TOL, f"{what}: e_t={e_t:.3e} e_R={e_R:.3e} against the oracle"
+
+
+def _quat_xyzw_to_R(q):
+    x, y, z, w = q
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
 
 
 def _png(path, img, color=False, filt=0):
@@ -47,7 +63,7 @@ def _png(path, img, color=False, filt=0):
 
 
 @pytest.mark.gpu
-def test_kitti_cli_matches_the_binding(tmp_path):
+def test_kitti_cli_matches_the_oracle_and_the_binding(tmp_path):
     import lvt_amd
     from lvt_amd.synth import make_world
     if not os.path.exists(EXE):
@@ -76,6 +92,15 @@ def test_kitti_cli_matches_the_binding(tmp_path):
     traj = np.loadtxt(tmp_path / "07.txt").reshape(-1, 3, 4)
     assert traj.shape[0] == n
 
+    # the oracle on the same frames, parameters as the harness builds them (YAML floats; calibration narrowed to float, which the
+    # parameter record holds as float anyway)
+    from oracle import pyoracle as O
+    orc = O.Oracle(lvt_amd.LvtParameters.from_file(str(tmp_path / "vo_config.yaml")), 1)
+    for i, (L, R) in enumerate(frames):
+        Ro, to = orc.track(L, R)
+        assert orc.status == 2
+        _se3_close(traj[i, :, :3], traj[i, :, 3], Ro, to, f"lvt_kitti frame {i}")
+
     # the binding, with the parameters exactly as the harness builds them (YAML floats, calibration narrowed to float)
     ref = lvt_amd.LvtSystem.create_from_file(str(tmp_path / "vo_config.yaml"), lvt_amd.eSensor_STEREO)
     for i, (L, R) in enumerate(frames):
@@ -99,7 +124,7 @@ def _png16(path, img16):
 
 
 @pytest.mark.gpu
-def test_tum_cli_matches_the_binding(tmp_path):
+def test_tum_cli_matches_the_oracle_and_the_binding(tmp_path):
     import lvt_amd
     from lvt_amd.synth import make_world
     exe = os.path.join(ROOT, "examples", "lvt_tum")
@@ -128,6 +153,13 @@ def test_tum_cli_matches_the_binding(tmp_path):
     traj = np.loadtxt(tmp_path / "fr1_synth.txt").reshape(-1, 8)
     assert traj.shape[0] == n
 
+    from oracle import pyoracle as O
+    orc = O.Oracle(lvt_amd.LvtParameters.from_file(str(tmp_path / "config.yaml")), 2)
+    for i, (gray, depth) in enumerate(frames):
+        Ro, to = orc.track_rgbd(gray, depth)
+        assert orc.status == 2
+        _se3_close(_quat_xyzw_to_R(traj[i, 4:8]), traj[i, 1:4], Ro, to, f"lvt_tum frame {i}")
+
     import ctypes as C
     L = lvt_amd.load_library()
     pod = lvt_amd.ParamsPOD()
@@ -141,7 +173,7 @@ def test_tum_cli_matches_the_binding(tmp_path):
 
 
 @pytest.mark.gpu
-def test_euroc_cli_matches_the_binding(tmp_path):
+def test_euroc_cli_matches_the_oracle_and_the_binding(tmp_path):
     """lvt_euroc = PNG read + GPU rectification (both cameras) + track + body-frame TUM trajectory, against the same steps
     done through the Python binding (Rectifier.rectify, LvtSystem.track) and numpy for T_BS / the quaternion"""
     import lvt_amd
@@ -189,6 +221,25 @@ def test_euroc_cli_matches_the_binding(tmp_path):
     ref = lvt_amd.LvtSystem(Lib.lvt_amd_create(C.byref(pod), 1), 1)
     Tbs = np.array([[0.0148655429818, -0.999880929698, 0.00414029679422, -0.0216401454975], [0.999557249008, 0.0149672133247, 0.025715529948, -0.064676986768],
                     [-0.0257744366974, 0.00375618835797, 0.999660727178, 0.00981073058949], [0, 0, 0, 1.0]])
+    # the oracle chain: its own rectification maps + bilinear remap, then its tracker, with the parameters the harness derives
+    from oracle import pyoracle as O
+    oprm = lvt_amd.LvtParameters.from_file(str(tmp_path / "config.yaml"))
+    oprm.fx = oprm.fy = float(np.float32(435.2046959714599))
+    oprm.cx, oprm.cy, oprm.baseline = float(np.float32(367.4517211914062)), float(np.float32(252.2008514404297)), float(np.float32(0.110077842))
+    oprm.img_width, oprm.img_height = 752, 480
+    orc = O.Oracle(oprm, 1)
+    maps = [O.init_undistort_rectify_map(c["K"], c["D"], c["R"], c["P"], 752, 480) for c in (EUROC_L, cam1)]
+    for i, (stamp, Lm, Rm) in enumerate(frames):
+        Ro, to = orc.track(O.remap_bilinear(Lm, *maps[0]), O.remap_bilinear(Rm, *maps[1]))
+        if orc.status != 2:
+            break
+        To = np.eye(4); To[:3, :3] = Ro; To[:3, 3] = to
+        Bo = Tbs @ To
+        _se3_close(_quat_xyzw_to_R(traj[i, 4:8]), traj[i, 1:4], Bo[:3, :3], Bo[:3, 3], f"lvt_euroc frame {i}")
+    else:
+        i = n
+    assert i >= 3, "the synthetic EuRoC sequence lost tracking too early to compare anything"
+
     lost = False
     for i, (stamp, Lm, Rm) in enumerate(frames):
         if lost:

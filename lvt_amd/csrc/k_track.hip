@@ -1697,8 +1697,14 @@ __device__ __forceinline__ void pnp_solve(const Params &prm, const Pose &prior, 
         pnp_run(prm, prior, X, obs, err, err + 2 * (size_t)n, level, n, sh, red, res, inliers, calls, dbg);  // the caller allocates 2 n + 2 doubles
 }
 
+// the pose of a synchronous call, delivered the moment it exists (pinned host memory): lvt_track returns on it while the frame's
+// tail (staged update, triangulation: ~30 us that change the map, not the pose) finishes behind the caller's next upload
+struct PoseRec {
+    double R[9], t[3];
+    int status, pad;
+};
 template <bool BV>
-__global__ __launch_bounds__(PNP_THREADS) void k_pnp(SeqArg<BV> sa, int par, seq_t seq) {
+__global__ __launch_bounds__(PNP_THREADS) void k_pnp(SeqArg<BV> sa, int par, seq_t seq, PoseRec *pose_out, seq_t *pose_done) {
     if (threadIdx.x == 0 && blockIdx.x == 0) sa.get().ctl->dbg[44] = (long long)wall_clock64();
     const Seq &S = sa.get();
     Ctl &ctl = *S.ctl;
@@ -1728,6 +1734,14 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(SeqArg<BV> sa, int par, seq
         ctl.dbg[45] = (long long)wall_clock64();
         __threadfence();
         atomicExch(&ctl.pnp_seq, seq);  // release: everything the next frame's early kernels read is final
+        if (pose_out) {  // synchronous call: hand the pose to the waiting host now (no later kernel of this frame changes it or the state)
+            PoseRec &o = pose_out[blockIdx.z];
+            for (int k = 0; k < 9; k++) o.R[k] = ctl.out_R[k];
+            for (int k = 0; k < 3; k++) o.t[k] = ctl.out_t[k];
+            o.status = 2;
+            __threadfence_system();
+            __hip_atomic_store(&pose_done[blockIdx.z], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
     // update_staged_map_points projects the staged points with the optimised pose (lvt_local_map.cpp:357-368)
     if (S.prm.staged_th > 0) project_staged(S, res, red);

@@ -113,6 +113,12 @@ struct Context {
     // host polls it -- an event record on the tracking stream costs that stream 3-4 us per frame (measured), and nothing else
     // on the device needs the event in the normal mode
     seq_t *h_done = nullptr, *h_done_dev = nullptr;
+    // synchronous calls: k_pnp hands the pose over as soon as it exists (PoseRec + flag, same pinned scheme), the call returns on it
+    // and the frame's tail finishes behind the caller's next upload; the frame is collected (full record) by the next entry point
+    PoseRec *h_pose = nullptr, *h_pose_dev = nullptr;
+    seq_t *h_pose_done = nullptr, *h_pose_done_dev = nullptr;
+    bool early_pose = true;    // LVT_AMD_SYNC_TAIL=wait: synchronous calls return only when the whole frame is done
+    bool early_pending = false;  // the last synchronous call returned on its early pose: its frame is still un-collected (and is nobody's to wait for)
     FrameArgs *h_fargs = nullptr;  // pinned, RING x B
     hipEvent_t ev_done[RING] = {};  // the only events of the normal mode: the streams hand over through polling gates (k_gate*)
     // LVT_AMD_ORDERING=events: the streams are ordered by event barriers only and the early stream is not used (the tracking chain
@@ -176,6 +182,8 @@ struct Context {
         for (auto &x : h_stage) if (x) (void)hipHostFree(x);
         if (h_ctl) (void)hipHostFree(h_ctl);
         if (h_done) (void)hipHostFree(h_done);
+        if (h_pose) (void)hipHostFree(h_pose);
+        if (h_pose_done) (void)hipHostFree(h_pose_done);
         if (h_fargs) (void)hipHostFree(h_fargs);
         if (stream && own_stream) (void)hipStreamDestroy(stream);
         if (stream_f) (void)hipStreamDestroy(stream_f);
@@ -398,6 +406,12 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         HIPCHK(c, hipHostMalloc((void **)&c->h_done, sizeof(seq_t) * B * RING, hipHostMallocCoherent));
         HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_done_dev, c->h_done, 0));
         std::memset(c->h_done, 0, sizeof(seq_t) * B * RING);
+        HIPCHK(c, hipHostMalloc((void **)&c->h_pose, sizeof(PoseRec) * B * RING, hipHostMallocCoherent));
+        HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_pose_dev, c->h_pose, 0));
+        HIPCHK(c, hipHostMalloc((void **)&c->h_pose_done, sizeof(seq_t) * B * RING, hipHostMallocCoherent));
+        HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_pose_done_dev, c->h_pose_done, 0));
+        std::memset(c->h_pose_done, 0, sizeof(seq_t) * B * RING);
+        if (const char *e = std::getenv("LVT_AMD_SYNC_TAIL")) c->early_pose = std::strcmp(e, "wait") != 0;
         HIPCHK(c, hipHostMalloc((void **)&c->h_fargs, sizeof(FrameArgs) * B * RING, hipHostMallocDefault));
         c->h_seqs.resize(B);
         c->d_ctl.resize(B);
@@ -594,7 +608,11 @@ static void enqueue_frame(Context *c) {
         }
     }
     LAUNCH_S(12, st, k_track_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, par, seq);
-    LAUNCH_S(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), PNP_DYN_BYTES, par, seq);
+    {
+        const bool ep = c->sync_call && c->early_pose && !c->prof && B == 1;
+        LAUNCH_S(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), PNP_DYN_BYTES, par, seq, ep ? c->h_pose_dev + (size_t)slot * B : (PoseRec *)nullptr,
+                 ep ? c->h_pose_done_dev + (size_t)slot * B : (seq_t *)nullptr);
+    }
     if (p.staged_th > 0)  // (a configuration without staging -- EuRoC, TUM -- never has staged points to list)
         LAUNCH_SM(16, st, k_candidates, MODE_STAGED, dim3(64, 1, B), dim3(256), 0, 0, par, (seq_t)0);
     LAUNCH_S(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, par, seq, c->h_ctl_dev + (size_t)slot * B,
@@ -678,6 +696,41 @@ static void collect_oldest(Context *c) {
 }
 static void drain(Context *c) {
     while (c->done < c->enq) collect_oldest(c);
+    c->early_pending = false;
+}
+// synchronous calls: wait for the frame just enqueued -- its pose (k_pnp) or, when the frame has none of its own (first frame, LOST,
+// skipped), its full record.  Returns true when R / t were taken from the early pose; the frame then stays un-collected until the next
+// entry point drains (by then its tail has long finished).
+static bool wait_pose_or_frame(Context *c, double R[3][3], double t[3]) {
+    HostTimer ht(&c->host_wait_us);
+    const int slot = (int)((c->enq - 1) % RING);
+    const seq_t want = (seq_t)c->enq;
+    volatile seq_t *fp = c->h_pose_done + (size_t)slot * c->B, *fd = c->h_done + (size_t)slot * c->B;
+    if (!c->early_pose || c->prof || c->B != 1) {
+        drain(c);
+        return false;
+    }
+    unsigned spins = 0;
+    for (;;) {
+        if (__atomic_load_n(fp, __ATOMIC_ACQUIRE) == want) {
+            const PoseRec &p = c->h_pose[(size_t)slot * c->B];
+            if (R)
+                for (int i = 0; i < 3; i++)
+                    for (int j = 0; j < 3; j++) R[i][j] = p.R[3 * i + j];
+            if (t)
+                for (int i = 0; i < 3; i++) t[i] = p.t[i];
+            c->early_pending = true;
+            return true;
+        }
+        if (__atomic_load_n(fd, __ATOMIC_ACQUIRE) == want) break;
+        __builtin_ia32_pause();
+        if ((++spins & 0xFFFFF) == 0) {  // a dead stream must not hang the caller: collect_oldest diagnoses it
+            const hipError_t q = hipStreamQuery(c->stream);
+            if (q != hipErrorNotReady) break;
+        }
+    }
+    drain(c);
+    return false;
 }
 static void make_room(Context *c) {  // at most RING-1 frames un-collected before a new one is enqueued
     while (c->enq - c->done >= RING - 1) collect_oldest(c);
@@ -817,6 +870,7 @@ LVT_API void lvt_amd_track_device_async(lvt_handle h, const void *d_left, const 
             c->set_error("lvt_amd_track_device: image size / pitch mismatch");
             return;
         }
+        if (c->early_pending) drain(c);  // (a synchronous call's frame whose pose has already been returned: not this caller's to collect)
         make_room(c);
         FrameArgs &f = c->h_fargs[(size_t)(c->enq % RING) * c->B];
         f.img[0] = static_cast<const uint8_t *>(d_left);
@@ -896,6 +950,7 @@ LVT_API void lvt_amd_wait(lvt_handle h, double R[3][3], double t[3]) {
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
     try {
+        if (c->early_pending) drain(c);
         if (c->done < c->enq) collect_oldest(c);  // FIFO: the oldest frame not yet collected
         result_out(c, 0, R, t);
     } catch (...) {
@@ -906,6 +961,7 @@ LVT_API int lvt_amd_wait_status(lvt_handle h, double R[3][3], double t[3]) {  //
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
     try {
+        if (c->early_pending) drain(c);
         if (c->done < c->enq) collect_oldest(c);
         result_out(c, 0, R, t);
         return last_ctl(c).state;
@@ -927,8 +983,7 @@ LVT_API void lvt_amd_track_device(lvt_handle h, const void *d_left, const void *
         c->sync_call = true;  // collected right away: k_triangulate delivers the record itself
         lvt_amd_track_device_async(h, d_left, d_right, n_rows, n_cols, pitch_bytes);
         c->sync_call = false;
-        drain(c);
-        result_out(c, 0, R, t);
+        if (!wait_pose_or_frame(c, R, t)) result_out(c, 0, R, t);
     } catch (...) {
     }
 }
@@ -939,7 +994,8 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
         c->set_error("lvt_track: image size differs from the configured img_width/img_height");
         return;
     }
-    drain(c);
+    // (the previous synchronous call may have returned on its early pose: its frame's tail -- staged update, triangulation -- runs
+    //  while this call copies the new images into the staging buffer of THIS frame's feature buffer; the drain comes after)
     const int par = (int)(c->enq % NPAR);
     hipStream_t sf = c->stream_f;
     const size_t nbytes = (size_t)n_rows * n_cols;
@@ -970,6 +1026,7 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
         std::memcpy(c->h_stage[par] + c->stage_img, second, rgbd ? sizeof(float) * nbytes : nbytes);
         s1 = c->h_stage_dev[par] + c->stage_img;
     }
+    drain(c);
     hipLaunchKernelGGL(k_stage_in, dim3(128, rgbd ? 1 : 2), dim3(256), 0, sf, s0, s1, c->d_img[par][0], c->d_img[par][1], n_cols, n_rows, c->pitch);
     FrameArgs &f = c->h_fargs[(size_t)(c->enq % RING) * c->B];
     f.img[0] = c->d_img[par][0];
@@ -993,8 +1050,7 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
     c->sync_call = true;  // collected right away: k_triangulate delivers the record itself
     enqueue_frame(c);
     c->sync_call = false;
-    drain(c);
-    result_out(c, 0, R, t);
+    if (!wait_pose_or_frame(c, R, t)) result_out(c, 0, R, t);
 }
 
 LVT_API void lvt_track(lvt_handle h, unsigned char *left, unsigned char *right, int n_rows, int n_cols, double R[3][3], double t[3]) {

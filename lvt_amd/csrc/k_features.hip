@@ -406,7 +406,7 @@ struct CellGeom {
 // compared at once (s >= th  <=>  bit 7 of (s & 0x7F) + (0x80 - th), or bit 7 of s itself), so a 16-pixel chunk costs ~25
 // instructions to count and a find-first-set walk over its corners to emit, instead of ~100 + ~160 for the scalar loops
 // -- one CU runs all 16 wavefronts of the cell, so this phase is VALU-bound.
-__device__ __forceinline__ int cell_compact(const CellGeom &g, uint32_t *keys, int cap, int *scan, long long *dbg = nullptr) {
+__device__ __forceinline__ int cell_compact(const CellGeom &g, uint32_t *keys, int cap, int *scan, long long *dbg = nullptr, int ly_off = 0) {
     const int tid = threadIdx.x;
     const int xa = g.X0 + 3, xb = g.X0 + g.cw - 4;  // inclusive pixel range
     const int c0 = xa >> 4, c1 = xb >> 4;
@@ -480,7 +480,7 @@ __device__ __forceinline__ int cell_compact(const CellGeom &g, uint32_t *keys, i
                     const int b = (__ffs((int)m) - 1) >> 3;
                     m &= m - 1;
                     const int s = (w[k] >> (8 * b)) & 255;
-                    if (off < cap) keys[off] = mk_key(ly, gx0 + 4 * k + b - g.X0, s);
+                    if (off < cap) keys[off] = mk_key(ly + ly_off, gx0 + 4 * k + b - g.X0, s);
                     off++;
                 }
             }
@@ -491,7 +491,7 @@ __device__ __forceinline__ int cell_compact(const CellGeom &g, uint32_t *keys, i
             const int s = (w[b >> 2] >> (8 * (b & 3))) & 255;
             const int gx = gx0 + b;
             if (s >= g.threshold && gx >= xa && gx <= xb) {
-                if (off < cap) keys[off] = mk_key(ly, gx - g.X0, s);
+                if (off < cap) keys[off] = mk_key(ly + ly_off, gx - g.X0, s);
                 off++;
             }
         }
@@ -560,10 +560,12 @@ __device__ __forceinline__ int cell_gather_segments(const FrameBuf &FB, int eye,
 
 // AGAST NMS + LVT ANMS of one cell on arrays that live either in LDS (I = u16) or in global scratch
 // (I = u32).  Writes the cell's key points to `out` and returns how many.
-template <typename I>
-__device__ __forceinline__ int cell_nms_anms(const Seq &S, const CellGeom &g, uint32_t *keys, uint32_t *uf, I *root, I *abv, I *nms, uint8_t *tie,
-                                             int n_raw, int n_cap, int *row_first, int *row_end, int *scan, int *stack, int *misc, float *out, long long *dbg) {
 #define STAMP(k) do { if (dbg && threadIdx.x == 0) dbg[k] = clock64(); } while (0)
+// first half: AGAST's NMS.  keys[0..n_raw) = raw corners in raster order; on return uf[0..n_kp) (= `arr`) holds the survivors in raster
+// order, keys / root are intact (root[i] = representative of corner i's 4-connected component).
+template <typename I>
+__device__ __forceinline__ int cell_nms(uint32_t *keys, uint32_t *uf, I *root, I *abv, I *nms, uint8_t *tie, int n_raw, int *row_first, int *row_end, int *scan,
+                                        long long *dbg) {
     constexpr uint32_t NONE = IdxT<I>::NONE, LEFT = IdxT<I>::LEFT, MAXF = IdxT<I>::MAXF;
     const int tid = threadIdx.x;
     STAMP(2);
@@ -745,6 +747,19 @@ __device__ __forceinline__ int cell_nms_anms(const Seq &S, const CellGeom &g, ui
     __syncthreads();
 
     STAMP(5);
+    return n_kp;
+}
+
+// second half: LVT's ANMS when the cell is too dense (handler.cpp:140-143, 34-83), else the survivors as they are.  arr = uf[0..n_kp) in
+// raster order; keys / root / abv / nms are scratch of n_cap elements each.
+template <typename I>
+__device__ __forceinline__ int cell_anms(const Seq &S, const CellGeom &g, uint32_t *keys, uint32_t *uf, I *root, I *abv, I *nms, int n_kp, int n_cap, int *row_first,
+                                         int *row_end, int *scan, int *misc, float *out, long long *dbg, int n_raw_dbg) {
+    constexpr uint32_t NONE = IdxT<I>::NONE, LEFT = IdxT<I>::LEFT, MAXF = IdxT<I>::MAXF;
+    (void)NONE, (void)LEFT, (void)MAXF;
+    const int tid = threadIdx.x;
+    uint32_t *arr = uf;
+    const int n_raw = n_raw_dbg;
     // ---------------- ANMS when the cell is too dense (handler.cpp:140-143, 34-83)
     const int max_kp = S.prm.max_kp_cell;
     const float fX0 = (float)g.X0, fY0 = (float)g.Y0;
@@ -983,8 +998,84 @@ __device__ __forceinline__ int cell_nms_anms(const Seq &S, const CellGeom &g, ui
     }
     STAMP(10);
     if (dbg && threadIdx.x == 0) { dbg[20] = n_raw; dbg[21] = n_kp; dbg[22] = n_out; }
-#undef STAMP
     return n_out;
+}
+#undef STAMP
+
+// AGAST NMS + LVT ANMS of one cell on arrays that live either in LDS (I = u16) or in global scratch (I = u32).
+template <typename I>
+__device__ __forceinline__ int cell_nms_anms(const Seq &S, const CellGeom &g, uint32_t *keys, uint32_t *uf, I *root, I *abv, I *nms, uint8_t *tie,
+                                             int n_raw, int n_cap, int *row_first, int *row_end, int *scan, int *stack, int *misc, float *out, long long *dbg) {
+    (void)stack;
+    const int n_kp = cell_nms<I>(keys, uf, root, abv, nms, tie, n_raw, row_first, row_end, scan, dbg);
+    return cell_anms<I>(S, g, keys, uf, root, abv, nms, n_kp, n_cap, row_first, row_end, scan, misc, out, dbg, n_raw);
+}
+
+// the LDS image of one cell's workgroup
+struct CellLds {
+    uint32_t *keys, *uf;
+    uint16_t *root16, *abv16, *nms16;
+    int *row_first, *row_end, *scan, *stack, *misc;
+    uint8_t *tie8;
+};
+__device__ __forceinline__ CellLds carve_cell_lds(uint8_t *smem) {
+    CellLds L;
+    L.keys = reinterpret_cast<uint32_t *>(smem);
+    L.uf = L.keys + RAW_CAP;
+    L.root16 = reinterpret_cast<uint16_t *>(L.uf + RAW_CAP);
+    L.abv16 = L.root16 + RAW_CAP;
+    L.nms16 = L.abv16 + RAW_CAP;
+    L.row_first = reinterpret_cast<int *>(L.nms16 + RAW_CAP);  // [1024]
+    L.row_end = L.row_first + 1024;                            // [1024]
+    L.scan = L.row_end + 1024;                                 // [64]
+    L.stack = L.scan + 64;                                     // [192]
+    L.misc = L.stack + 192;                                    // [16]
+    L.tie8 = reinterpret_cast<uint8_t *>(L.misc + 16);          // [RAW_CAP]
+    return L;
+}
+// shared prologue of the three cell kernels: false = nothing to do for this (cell, eye, pass)
+__device__ __forceinline__ bool cell_begin(const Seq &S, const FrameBuf &FB, int eye, int cell, int pass, CellGeom &g, int &cxi) {
+    const FeatCtl &ctl = *FB.fc;
+    if (ctl.poison || ctl.ext_corners) return false;
+    if (eye == 1 && S.prm.sensor == 2) return false;
+    if (cell >= S.prm.n_cells) return false;
+    g.threshold = S.prm.agast_th;
+    if (pass == 1) {
+        if (ctl.n_detected[eye] >= CORNERS_LOW_TH) return false;  // handler.cpp:161
+        g.threshold = S.prm.agast_th_low;
+    }
+    const int cs = S.prm.cell_size;
+    cxi = cell % S.prm.cells_x;
+    const int cyi = cell / S.prm.cells_x;
+    g.X0 = cxi * cs;
+    g.Y0 = cyi * cs;
+    g.cw = min(cs, S.prm.W - g.X0);
+    g.ch = min(cs, S.prm.H - g.Y0);
+    g.score = FB.score[eye];
+    g.pp = S.plane_pitch;
+    return true;
+}
+__device__ __forceinline__ void cell_finish(FrameBuf &FB, int eye, int cell, int pass, int n_out) {
+    FeatCtl &ctl = *FB.fc;
+    if (threadIdx.x == 0) {
+        if (n_out > CELL_OUT_CAP) {
+            atomicOr(&ctl.overflow, OVF_CELL_OUT);
+            n_out = CELL_OUT_CAP;
+        }
+        FB.cell_n[eye][cell] = n_out;
+        if (pass == 0) atomicAdd(&ctl.n_detected[eye], n_out);
+        else if (cell == 0) ctl.retry[eye] = 1;
+    }
+}
+// dense / very large cell on ONE workgroup: the same algorithm on global scratch sized for every pixel of the cell
+__device__ __forceinline__ int cell_global_path(const Seq &S, const FrameBuf &FB, int eye, int cell, int cxi, bool segs, const CellGeom &g, const CellLds &L, float *out,
+                                                long long *dbg) {
+    const size_t cap = (size_t)g.cw * g.ch;
+    uint32_t *gk = S.cell_scratch[eye] + S.cell_scratch_off[cell];
+    uint32_t *guf = gk + cap, *groot = guf + cap, *gabv = groot + cap, *gnms = gabv + cap;
+    const int n_raw = segs ? cell_gather_segments(FB, eye, g, S.prm.cell_size, cxi, (S.prm.W + TS_W - 1) / TS_W, gk, (int)cap, L.scan) : cell_compact(g, gk, (int)cap, L.scan);
+    return cell_nms_anms<uint32_t>(S, g, gk, guf, groot, gabv, gnms, reinterpret_cast<uint8_t *>(gnms + cap), n_raw, (int)cap, L.row_first, L.row_end, L.scan, L.stack, L.misc, out,
+                                   dbg);
 }
 
 __global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass, int par) {
@@ -992,37 +1083,14 @@ __global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass, int par) {
     const int eye = blockIdx.y, cell = blockIdx.x;
     FrameBuf &FB = S.fb[par];
     FeatCtl &ctl = *FB.fc;
-    if (ctl.poison || ctl.ext_corners) return;
-    if (eye == 1 && S.prm.sensor == 2) return;
-    if (cell >= S.prm.n_cells) return;
-    CellGeom g;
-    g.threshold = S.prm.agast_th;
-    if (pass == 1) {
-        if (ctl.n_detected[eye] >= CORNERS_LOW_TH) return;  // handler.cpp:161
-        g.threshold = S.prm.agast_th_low;
-    }
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    uint32_t *keys = reinterpret_cast<uint32_t *>(smem);
-    uint32_t *uf = keys + RAW_CAP;
-    uint16_t *root16 = reinterpret_cast<uint16_t *>(uf + RAW_CAP);
-    uint16_t *abv16 = root16 + RAW_CAP;
-    uint16_t *nms16 = abv16 + RAW_CAP;
-    int *row_first = reinterpret_cast<int *>(nms16 + RAW_CAP);  // [1024]
-    int *row_end = row_first + 1024;                            // [1024]
-    int *scan = row_end + 1024;                                 // [64]
-    int *stack = scan + 64;                                     // [192]
-    int *misc = stack + 192;                                    // [16]
-    uint8_t *tie8 = reinterpret_cast<uint8_t *>(misc + 16);      // [RAW_CAP]
-
     const int tid = threadIdx.x;
+    if (tid == 0 && cell < CELLS_MAX) S.cell_big[eye][cell] = 0;  // (nobody reads it before this launch is over)
+    CellGeom g;
+    int cxi;
+    if (!cell_begin(S, FB, eye, cell, pass, g, cxi)) return;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const CellLds L = carve_cell_lds(smem);
     const int cs = S.prm.cell_size;
-    const int cxi = cell % S.prm.cells_x, cyi = cell / S.prm.cells_x;
-    g.X0 = cxi * cs;
-    g.Y0 = cyi * cs;
-    g.cw = min(cs, S.prm.W - g.X0);
-    g.ch = min(cs, S.prm.H - g.Y0);
-    g.score = FB.score[eye];
-    g.pp = S.plane_pitch;
     float *out = FB.cell_kp[eye] + (size_t)cell * CELL_OUT_CAP * 3;
 
     long long *dbg = (cell == 0 && eye == 0 && pass == 0) ? S.ctl->dbg : nullptr;
@@ -1033,30 +1101,130 @@ __global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass, int par) {
     } else if (g.cw >= 7 && g.ch >= 7) {
         // pass 0 with cells of at least one tile width: gather k_score's segments; otherwise compact the score map here
         const bool segs = (pass == 0) && (cs >= TS_W);
-        int n_raw = segs ? cell_gather_segments(FB, eye, g, cs, cxi, (S.prm.W + TS_W - 1) / TS_W, keys, RAW_CAP, scan)
-                         : cell_compact(g, keys, RAW_CAP, scan, dbg);
+        const int n_raw = segs ? cell_gather_segments(FB, eye, g, cs, cxi, (S.prm.W + TS_W - 1) / TS_W, L.keys, RAW_CAP, L.scan)
+                               : cell_compact(g, L.keys, RAW_CAP, L.scan, dbg);
         if (dbg && tid == 0) dbg[1] = clock64();
         if (n_raw <= RAW_CAP) {
-            n_out = cell_nms_anms<uint16_t>(S, g, keys, uf, root16, abv16, nms16, tie8, n_raw, RAW_CAP, row_first, row_end, scan, stack, misc, out, dbg);
+            n_out = cell_nms_anms<uint16_t>(S, g, L.keys, L.uf, L.root16, L.abv16, L.nms16, L.tie8, n_raw, RAW_CAP, L.row_first, L.row_end, L.scan, L.stack, L.misc, out, dbg);
+        } else if (S.prm.big_cell_strips) {
+            // more raw corners than this workgroup's LDS holds, in a cell tall enough to cut: k_cells_strip (NMS of row strips on several
+            // CUs) and k_cells_big (ANMS of the merged survivors) take over; they also write cell_n / n_detected
+            if (tid == 0) S.cell_big[eye][cell] = 1;
+            return;
         } else {
-            // dense / very large cell: same algorithm on global scratch sized for every pixel of the cell
-            const size_t cap = (size_t)g.cw * g.ch;
-            uint32_t *gk = S.cell_scratch[eye] + S.cell_scratch_off[cell];
-            uint32_t *guf = gk + cap, *groot = guf + cap, *gabv = groot + cap, *gnms = gabv + cap;
-            n_raw = segs ? cell_gather_segments(FB, eye, g, cs, cxi, (S.prm.W + TS_W - 1) / TS_W, gk, (int)cap, scan) : cell_compact(g, gk, (int)cap, scan);
-            n_out = cell_nms_anms<uint32_t>(S, g, gk, guf, groot, gabv, gnms, reinterpret_cast<uint8_t *>(gnms + cap), n_raw, (int)cap, row_first, row_end, scan, stack, misc, out, dbg);
+            n_out = cell_global_path(S, FB, eye, cell, cxi, segs, g, L, out, dbg);
         }
     }
     if (dbg && tid == 0) dbg[11] = clock64();
-    if (tid == 0) {
-        if (n_out > CELL_OUT_CAP) {
-            atomicOr(&ctl.overflow, OVF_CELL_OUT);
-            n_out = CELL_OUT_CAP;
-        }
-        FB.cell_n[eye][cell] = n_out;
-        if (pass == 0) atomicAdd(&ctl.n_detected[eye], n_out);
-        else if (cell == 0) ctl.retry[eye] = 1;
+    cell_finish(FB, eye, cell, pass, n_out);
+}
+
+// ---- an oversized cell as row strips --------------------------------------------------------------------------------------------
+// AGAST's NMS keeps one corner per 4-connected blob of corner pixels, decided by the blob's pixels alone, so the rows
+// of a cell can be cut: strip s decides the corners of its CORE rows from the raw corners of core + STRIP_HALO rows on either side
+// (the fast LDS path of k_cells, one CU per strip), and every decision is exact as long as no blob reaches from a core row to the
+// outermost halo row of the extended strip -- such a blob might continue outside.  That is checked per blob; a strip that cannot
+// vouch (or whose extended rows overflow the LDS) reports -1 and k_cells_big runs the whole cell on the single-workgroup global path
+// instead, as before.  Survivors of the strips, concatenated in strip order, ARE the cell's survivors in raster order.
+constexpr int STRIPS = 8, STRIP_HALO = 16;
+__global__ __launch_bounds__(1024) void k_cells_strip(Seq *seqs, int pass, int par) {
+    Seq &S = seqs[blockIdx.z];
+    const int eye = blockIdx.y, cell = blockIdx.x / STRIPS, strip = blockIdx.x % STRIPS;
+    FrameBuf &FB = S.fb[par];
+    CellGeom g;
+    int cxi;
+    if (!cell_begin(S, FB, eye, cell, pass, g, cxi)) return;
+    if (S.cell_big[eye][cell] != 1) return;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const CellLds L = carve_cell_lds(smem);
+    const int tid = threadIdx.x, cs = S.prm.cell_size;
+    int *cnt = S.strip_n[eye] + cell * STRIPS + strip;
+    uint32_t *dst = S.strip_kp[eye] + ((size_t)cell * STRIPS + strip) * RAW_CAP;
+    // interior rows of the cell: ly in [3, ch - 3)
+    const int per = (g.ch - 6 + STRIPS - 1) / STRIPS;
+    const int c0 = 3 + strip * per, c1 = min(c0 + per, g.ch - 3);
+    if (c0 >= c1) {
+        if (tid == 0) *cnt = 0;
+        return;
     }
+    const int e0 = max(3, c0 - STRIP_HALO), e1 = min(g.ch - 3, c1 + STRIP_HALO);
+    CellGeom g2 = g;  // the extended strip as a "cell" whose interior rows are [e0, e1)
+    g2.Y0 = g.Y0 + e0 - 3;
+    g2.ch = (e1 - e0) + 6;
+    const bool segs = (pass == 0) && (cs >= TS_W);
+    const int n_raw = segs ? cell_gather_segments(FB, eye, g2, cs, cxi, (S.prm.W + TS_W - 1) / TS_W, L.keys, RAW_CAP, L.scan)
+                           : cell_compact(g2, L.keys, RAW_CAP, L.scan, nullptr, e0 - 3);
+    if (n_raw > RAW_CAP) {
+        if (tid == 0) *cnt = -1;
+        return;
+    }
+    const int n_kp = cell_nms<uint16_t>(L.keys, L.uf, L.root16, L.abv16, L.nms16, L.tie8, n_raw, L.row_first, L.row_end, L.scan, nullptr);
+    // a blob with a pixel in an outermost extended row (that is not the cell's own first / last interior row) AND one in a core row?
+    for (int i = tid; i < n_raw; i += 1024) L.tie8[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < n_raw; i += 1024) {
+        const int y = key_y(L.keys[i]);
+        if ((e0 > 3 && y == e0) || (e1 < g.ch - 3 && y == e1 - 1)) L.tie8[L.root16[i]] = 1;
+    }
+    __syncthreads();
+    int unsafe = 0;
+    for (int i = tid; i < n_raw; i += 1024) {
+        const int y = key_y(L.keys[i]);
+        if (y >= c0 && y < c1 && L.tie8[L.root16[i]]) unsafe = 1;
+    }
+    if (__syncthreads_or(unsafe)) {
+        if (tid == 0) *cnt = -1;
+        return;
+    }
+    // survivors of the core rows, raster order
+    int n_out = 0;
+    for (int base = 0; base < n_kp; base += 1024) {
+        const int i = base + tid;
+        const uint32_t k = (i < n_kp) ? L.uf[i] : 0u;
+        const bool keep = (i < n_kp) && key_y(k) >= c0 && key_y(k) < c1;
+        int total;
+        const int off = n_out + block_excl_scan(keep ? 1 : 0, L.scan, &total);
+        if (keep) dst[off] = k;  // (at most n_raw <= RAW_CAP)
+        n_out += total;
+    }
+    if (tid == 0) *cnt = n_out;
+}
+
+// the oversized cell's second half: its strips' survivors, merged in LDS, through LVT's ANMS (or the whole cell on the old path)
+__global__ __launch_bounds__(1024) void k_cells_big(Seq *seqs, int pass, int par) {
+    Seq &S = seqs[blockIdx.z];
+    const int eye = blockIdx.y, cell = blockIdx.x;
+    FrameBuf &FB = S.fb[par];
+    CellGeom g;
+    int cxi;
+    if (!cell_begin(S, FB, eye, cell, pass, g, cxi)) return;
+    if (S.cell_big[eye][cell] != 1) return;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const CellLds L = carve_cell_lds(smem);
+    const int tid = threadIdx.x;
+    float *out = FB.cell_kp[eye] + (size_t)cell * CELL_OUT_CAP * 3;
+    const int *cnt = S.strip_n[eye] + cell * STRIPS;
+    int total = 0;
+    bool bad = false;
+    for (int s = 0; s < STRIPS; s++) {  // (block-uniform: every thread reads the same eight words)
+        const int n = cnt[s];
+        bad = bad || n < 0;
+        total += max(n, 0);
+    }
+    int n_out;
+    if (bad || total > RAW_CAP) {
+        n_out = cell_global_path(S, FB, eye, cell, cxi, (pass == 0) && (S.prm.cell_size >= TS_W), g, L, out, nullptr);
+    } else {
+        int off = 0;
+        for (int s = 0; s < STRIPS; s++) {
+            const uint32_t *src = S.strip_kp[eye] + ((size_t)cell * STRIPS + s) * RAW_CAP;
+            for (int i = tid; i < cnt[s]; i += 1024) L.uf[off + i] = src[i];
+            off += cnt[s];
+        }
+        __syncthreads();
+        n_out = cell_anms<uint16_t>(S, g, L.keys, L.uf, L.root16, L.abv16, L.nms16, total, RAW_CAP, L.row_first, L.row_end, L.scan, L.misc, out, nullptr, total);
+    }
+    cell_finish(FB, eye, cell, pass, n_out);
 }
 
 // =================================================================================================

@@ -52,6 +52,7 @@ struct Params {  // lvt_parameters.h:29-64 + derived values
     int hash_ccx, hash_ccy, cell_search_radius;  // lvt_image_features_struct.cpp:48-53
     int sensor;                             // 1 stereo, 2 rgbd
     int undistort;                          // |k1| > 1e-5 (handler.cpp:268)
+    int big_cell_strips;                    // detection cells taller than 256 px: an oversized cell's NMS runs as row strips on several CUs (k_cells_strip)
 };
 
 struct Pose {  // camera-to-world, quaternion (w,x,y,z) + position
@@ -167,6 +168,11 @@ struct Seq {
     int plane_pitch;            // elements, multiple of 64
     uint32_t *cell_scratch[2];  // global-memory arrays for cells whose raw corners exceed RAW_CAP (6 words / pixel)
     size_t cell_scratch_off[CELLS_MAX];
+    // oversized cells (more raw corners than one workgroup's LDS holds) whose NMS runs as STRIPS row strips: per (cell, strip) the survivors
+    // of the strip's core rows (raw-corner keys, raster order) and their count (-1: the strip could not decide exactly -> single-workgroup path)
+    uint32_t *strip_kp[2];
+    int *strip_n[2];
+    int *cell_big[2];           // [CELLS_MAX] 1: this pass's k_cells left the cell to k_cells_strip / k_cells_big
     // map + staged, ping-pong
     MapSoA map[2], staged[2];
     int *map_cur, *map_n, *staged_cur, *staged_n;   // device scalars

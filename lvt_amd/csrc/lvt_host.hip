@@ -253,6 +253,7 @@ static bool derive_params(const lvt_amd_params &in, int sensor, Params &p) {
         p.max_y = std::max(y[2], y[3]);
     }
     p.undistort = (std::fabs(p.k1) > 1e-5) ? 1 : 0;
+    p.big_cell_strips = (p.cell_size > 256) ? 1 : 0;  // (TUM's single 2000-px cell; the 250-px cells of KITTI / EuRoC keep the two-launch feature chain)
     return true;
 }
 
@@ -432,6 +433,11 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
                 }
             }
             for (int e = 0; e < 2; e++) S.cell_scratch[e] = c->dalloc<uint32_t>((size_t)prm.W * prm.H * 6 + 64);
+            for (int e = 0; e < 2; e++) {
+                S.strip_kp[e] = c->dalloc<uint32_t>(prm.big_cell_strips ? (size_t)prm.n_cells * STRIPS * RAW_CAP : 64);
+                S.strip_n[e] = c->dalloc<int>((size_t)CELLS_MAX * STRIPS);
+                S.cell_big[e] = c->dalloc<int>(CELLS_MAX);
+            }
             for (int par = 0; par < NPAR; par++) {
                 FrameBuf &FB = S.fb[par];
                 FB.fc = c->dalloc<FeatCtl>(1);
@@ -486,6 +492,8 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         HIPCHK(c, hipMemcpy(c->d_seqs, c->h_seqs.data(), sizeof(Seq) * B, hipMemcpyHostToDevice));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       CELLS_LDS_BYTES));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_strip), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_big), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pnp<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PNP_DYN_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pnp<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PNP_DYN_BYTES));
         reset_state(c);
@@ -560,8 +568,14 @@ static void enqueue_frame(Context *c) {
         LAUNCH(2, sf, k_score<false>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2 * B), dim3(256), 0, S, FrameArgs{}, par);
     }
     if (!ext) {
-        LAUNCH(3, sf, k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, S, 0, par);
-        LAUNCH(4, sf, k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, S, 1, par);
+        for (int pass = 0; pass < 2; pass++) {
+            LAUNCH(3 + pass, sf, k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, S, pass, par);
+            if (p.big_cell_strips) {  // oversized cells: NMS as row strips on several CUs, then ANMS of the merged survivors
+                hipLaunchKernelGGL(k_cells_strip, dim3(p.n_cells * STRIPS, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
+                hipLaunchKernelGGL(k_cells_big, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
+                if (c->prof) (void)hipEventRecord(c->ev[3 + pass][1], sf);  // (the slot's time covers the three launches)
+            }
+        }
     }
     LAUNCH(5, sf, k_gather, dim3(1, 2, B), dim3(1024), 0, S, par);
     LAUNCH(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, S, par, evo ? (seq_t)0 : (seq_t)(c->enq + 1));  // (its last workgroup publishes feat_seq)

@@ -344,9 +344,11 @@ __device__ __forceinline__ void candidates_body(const Seq &S, int pass2, int par
 
 // need_seq (row mode on the early stream): the lists are only built from COMPLETE features (the stream's gate may have given up
 // waiting for them; then k_row_done does not publish either and k_triangulate reports the frame as lost)
+// only_fb: the binned list kernel (k_lists.hip) ran in front of this one -- build the lists only where it stood down
 template <int MODE, bool BV>
-__global__ __launch_bounds__(256) void k_candidates(SeqArg<BV> sa, int pass2, int par, seq_t need_seq) {
+__global__ __launch_bounds__(256) void k_candidates(SeqArg<BV> sa, int pass2, int par, seq_t need_seq, int only_fb) {
     const Seq &S = sa.get();
+    if (only_fb && !S.lists_fb[MODE == MODE_ROW ? 1 : 0]) return;
     if (MODE != MODE_ROW) {
         const Ctl &ctl = *S.ctl;
         if (!ctl.active || ctl.first_frame) return;
@@ -514,9 +516,10 @@ __global__ __launch_bounds__(64) void k_gate(SeqArg<BV> sa, int par, seq_t want,
 }
 
 template <bool BV>
-__global__ __launch_bounds__(256) void k_early_map(SeqArg<BV> sa, int par, seq_t seq) {
+__global__ __launch_bounds__(256) void k_early_map(SeqArg<BV> sa, int par, seq_t seq, int only_fb) {
     if (threadIdx.x == 0 && blockIdx.x == 0) sa.get().ctl->dbg[34] = (long long)wall_clock64();
     const Seq &S = sa.get();
+    if (only_fb && !S.lists_fb[0]) return;  // (k_hamming_batched_lists<MODE_MAP> has projected and listed these points)
     Ctl &ctl = *S.ctl;
     const int n_early = (ctl.gate_ok == seq) ? ctl.early_done : 0;
     if (n_early <= 0) return;  // first frame, LOST, the previous frame did not reach its pose refinement, or the gate timed out

@@ -173,6 +173,7 @@ struct Seq {
     uint32_t *strip_kp[2];
     int *strip_n[2];
     int *cell_big[2];           // [CELLS_MAX] 1: this pass's k_cells left the cell to k_cells_strip / k_cells_big
+    int *lists_fb;              // [2] k_hamming_batched_lists (map / row) stood down: the wave-per-query kernel behind it builds the lists
     // map + staged, ping-pong
     MapSoA map[2], staged[2];
     int *map_cur, *map_n, *staged_cur, *staged_n;   // device scalars

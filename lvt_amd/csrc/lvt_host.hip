@@ -17,6 +17,7 @@
 #include "k_features.hip"
 #include "k_track.hip"
 #include "k_hamming.hip"
+#include "k_lists.hip"
 #include "k_rectify.hip"
 #include "lvt_odometry.h"
 
@@ -117,6 +118,7 @@ struct Context {
     // and the frame's tail finishes behind the caller's next upload; the frame is collected (full record) by the next entry point
     PoseRec *h_pose = nullptr, *h_pose_dev = nullptr;
     seq_t *h_pose_done = nullptr, *h_pose_done_dev = nullptr;
+    bool binned_lists = false; // lock-step batches: k_hamming_batched_lists builds the early map lists and the row lists (LVT_AMD_BINNED_LISTS=0 / 1)
     bool early_pose = true;    // LVT_AMD_SYNC_TAIL=wait: synchronous calls return only when the whole frame is done
     bool early_pending = false;  // the last synchronous call returned on its early pose: its frame is still un-collected (and is nobody's to wait for)
     FrameArgs *h_fargs = nullptr;  // pinned, RING x B
@@ -413,6 +415,8 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_pose_done_dev, c->h_pose_done, 0));
         std::memset(c->h_pose_done, 0, sizeof(seq_t) * B * RING);
         if (const char *e = std::getenv("LVT_AMD_SYNC_TAIL")) c->early_pose = std::strcmp(e, "wait") != 0;
+        c->binned_lists = B > 1;
+        if (const char *e = std::getenv("LVT_AMD_BINNED_LISTS")) c->binned_lists = std::atoi(e) != 0;
         HIPCHK(c, hipHostMalloc((void **)&c->h_fargs, sizeof(FrameArgs) * B * RING, hipHostMallocDefault));
         c->h_seqs.resize(B);
         c->d_ctl.resize(B);
@@ -438,6 +442,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
                 S.strip_n[e] = c->dalloc<int>((size_t)CELLS_MAX * STRIPS);
                 S.cell_big[e] = c->dalloc<int>(CELLS_MAX);
             }
+            S.lists_fb = c->dalloc<int>(2);
             for (int par = 0; par < NPAR; par++) {
                 FrameBuf &FB = S.fb[par];
                 FB.fc = c->dalloc<FeatCtl>(1);
@@ -492,6 +497,10 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         HIPCHK(c, hipMemcpy(c->d_seqs, c->h_seqs.data(), sizeof(Seq) * B, hipMemcpyHostToDevice));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells), hipFuncAttributeMaxDynamicSharedMemorySize,
                                       CELLS_LDS_BYTES));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hamming_batched_lists<MODE_MAP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LS_LDS_BYTES));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hamming_batched_lists<MODE_MAP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LS_LDS_BYTES));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hamming_batched_lists<MODE_ROW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LS_LDS_BYTES));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hamming_batched_lists<MODE_ROW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_strip), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_big), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pnp<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PNP_DYN_BYTES));
@@ -507,8 +516,8 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
 // ---- the per-frame launch chain -------------------------------------------------------------------
 static const char *kProfNames[Context::PROF_SLOTS] = {
     "k_feat_begin", "k_gate [early stream: waits for the previous k_pnp]", "k_score", "k_cells(pass0)", "k_cells(retry)", "k_gather", "k_brief", "k_gate_late [waits for the early stream]",
-    "k_match_map(wait for the early stream + begin + new points)", "k_early_map [early stream]", "k_early_mid [early stream]", "", "k_track_mid(resolve+pass2+bookkeep+cull)", "k_pnp(+project staged)", "",
-    "", "k_candidates(staged)", "", "k_candidates(row) [early stream]", "", "k_triangulate(staged update+row resolve+triangulate+finalize)", "",
+    "k_match_map(wait for the early stream + begin + new points)", "k_early_map [early stream]", "k_early_mid [early stream]", "k_hamming_batched_lists(map) [early stream]", "k_track_mid(resolve+pass2+bookkeep+cull)", "k_pnp(+project staged)", "",
+    "", "k_candidates(staged)", "", "k_candidates(row) [early stream]", "k_hamming_batched_lists(row)", "k_triangulate(staged update+row resolve+triangulate+finalize)", "",
     "", ""};
 
 #define LAUNCH(slot, st, kern, grid, block, lds, ...)                              \
@@ -579,7 +588,9 @@ static void enqueue_frame(Context *c) {
     }
     LAUNCH(5, sf, k_gather, dim3(1, 2, B), dim3(1024), 0, S, par);
     LAUNCH(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, S, par, evo ? (seq_t)0 : (seq_t)(c->enq + 1));  // (its last workgroup publishes feat_seq)
-    if (evo) LAUNCH_SM(18, sf, k_candidates, MODE_ROW, dim3(256, 1, B), dim3(256), 0, 0, par, (seq_t)0);  // (normal mode: on the early stream, below)
+    const int bl = c->binned_lists ? 1 : 0;
+    if (evo && bl && c->sensor == 1) LAUNCH_SM(19, sf, k_hamming_batched_lists, MODE_ROW, dim3(2, 1, B), dim3(LS_THREADS), LS_LDS_BYTES, par, (seq_t)0);
+    if (evo) LAUNCH_SM(18, sf, k_candidates, MODE_ROW, dim3(256, 1, B), dim3(256), 0, 0, par, (seq_t)0, bl);  // (normal mode: on the early stream, below)
     if (evo) hipLaunchKernelGGL(k_feat_done, dim3(B), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));
     if (evo) (void)hipEventRecord(c->ev_feat[par], sf);
     // ---- early stream: projection, candidate lists and greedy resolution of the map points that survived the previous frame,
@@ -588,13 +599,15 @@ static void enqueue_frame(Context *c) {
     if (!evo) {
         hipStream_t se = c->stream_e;
         LAUNCH_S(1, se, k_gate, dim3(1, 1, B), dim3(64), 0, par, (seq_t)c->enq, seq);  // polls the previous k_pnp and this frame's features
-        LAUNCH_S(9, se, k_early_map, dim3(256, 1, B), dim3(256), 0, par, seq);
+        if (bl) LAUNCH_SM(11, se, k_hamming_batched_lists, MODE_MAP, dim3(1, 1, B), dim3(LS_THREADS), LS_LDS_BYTES, par, seq);
+        LAUNCH_S(9, se, k_early_map, dim3(256, 1, B), dim3(256), 0, par, seq, bl);
         LAUNCH_S(10, se, k_early_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, par, seq);
         if (c->sensor == 1) {
             // row-match candidate lists of THIS frame (needed by its k_triangulate, ~70 us from here): they need the two feature
             // sets only, and the feature stream is the longest chain -- here, behind the early part, they lengthen neither it nor
             // the hand-over to the tracking stream.  Few workgroups: the tracking chain's single-workgroup kernels run meanwhile.
-            LAUNCH_SM(18, se, k_candidates, MODE_ROW, dim3(B == 1 ? ROW_BLOCKS : ROW_BLOCKS_BATCH, 1, B), dim3(256), 0, 0, par, seq);
+            if (bl) LAUNCH_SM(19, se, k_hamming_batched_lists, MODE_ROW, dim3(2, 1, B), dim3(LS_THREADS), LS_LDS_BYTES, par, seq);
+            LAUNCH_SM(18, se, k_candidates, MODE_ROW, dim3(B == 1 ? ROW_BLOCKS : ROW_BLOCKS_BATCH, 1, B), dim3(256), 0, 0, par, seq, bl);
             hipLaunchKernelGGL(k_row_done, dim3(B), dim3(64), 0, se, S, par, seq);
         }
     }
@@ -628,7 +641,7 @@ static void enqueue_frame(Context *c) {
                  ep ? c->h_pose_done_dev + (size_t)slot * B : (seq_t *)nullptr);
     }
     if (p.staged_th > 0)  // (a configuration without staging -- EuRoC, TUM -- never has staged points to list)
-        LAUNCH_SM(16, st, k_candidates, MODE_STAGED, dim3(64, 1, B), dim3(256), 0, 0, par, (seq_t)0);
+        LAUNCH_SM(16, st, k_candidates, MODE_STAGED, dim3(64, 1, B), dim3(256), 0, 0, par, (seq_t)0, 0);
     LAUNCH_S(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, par, seq, c->h_ctl_dev + (size_t)slot * B,
            c->h_done_dev + (size_t)slot * B, evo ? 0 : 1, (evo || c->sync_call) ? 1 : 0);
     if (evo || c->sync_call) c->delivered = c->enq + 1;

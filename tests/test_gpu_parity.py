@@ -47,6 +47,19 @@ def test_sequence_parity(hip_lib, oracle_lib, name, kind, seed, scale, overrides
         assert c["n_right"] == 0
 
 
+@pytest.mark.parametrize("name", ["kitti_full", "kitti_dense_anms", "kitti_jump", "euroc", "tum_rgbd"])
+def test_binned_list_kernel_on_a_single_handle(hip_lib, oracle_lib, monkeypatch, name):
+    """k_hamming_batched_lists (the binned matcher's list-emitting form; lock-step batches use it by default) forced onto a single
+    handle: the early map lists and the row lists it builds must lead to the oracle's matches, maps and poses on every shape -- 3x3 and
+    5x5 cell windows (TUM: tracking radius 30), dense ANMS output, a 40-frame jump"""
+    monkeypatch.setenv("LVT_AMD_BINNED_LISTS", "1")
+    case = next(c for c in CASES if c[0] == name)
+    world, prm, sensor = make_case(case[1], case[2], case[3], case[4])
+    res, hip, orc = run_sequence(world, prm, sensor, case[5][:10])
+    bad = [(i, m) for i, m, _, _ in res if m]
+    assert not bad, f"{name}: first divergence at frame {bad[0][0]}: {bad[0][1][:6]}"
+
+
 def test_second_pass_and_lost_latch(hip_lib, oracle_lib):
     """a scene cut: the doubled-radius pass runs, then tracking is LOST and stays lost (lvt_system.cpp:161-166)"""
     world, prm, sensor = make_case("kitti", 7, 0.5, {"min_num_matches_for_tracking": 60})

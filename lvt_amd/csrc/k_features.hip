@@ -12,6 +12,16 @@ namespace lvt {
 __constant__ signed char c_brief[256][4] = {
 #include "../../include/lvt_brief256_pattern.inc"
 };
+// the same table for compile-time checks (k_brief sizes its window from the largest offset)
+constexpr signed char BRIEF_TABLE[256][4] = {
+#include "../../include/lvt_brief256_pattern.inc"
+};
+constexpr int brief_max_offset() {
+    int m = 0;
+    for (int i = 0; i < 256; i++)
+        for (int k = 0; k < 4; k++) m = (BRIEF_TABLE[i][k] > m) ? BRIEF_TABLE[i][k] : (-BRIEF_TABLE[i][k] > m) ? -BRIEF_TABLE[i][k] : m;
+    return m;
+}
 
 // =================================================================================================
 // k_score : OAST-9/16 score + 9x9 box sums, tile 64x16, halo 4
@@ -20,33 +30,43 @@ constexpr int TS_W = 64, TS_H = 16, HALO = 4;
 constexpr int TILE_W = TS_W + 2 * HALO;   // 72
 constexpr int TILE_H = TS_H + 2 * HALO;   // 24
 
-__device__ __forceinline__ int oast9_score(int p, const int r[16]) {
-    // score = max{b : 9 contiguous ring pixels all > p+b or all < p-b} = max_arc min(+-d) - 1
-    int d[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) d[i] = r[i] - p;
-    int mn2[16], mx2[16];
-#pragma unroll
-    for (int i = 0; i < 16; i++) {
-        mn2[i] = min(d[i], d[(i + 1) & 15]);
-        mx2[i] = max(d[i], d[(i + 1) & 15]);
-    }
-    int mn4[16], mx4[16];
+// two horizontally adjacent pixels at once, one in each 16-bit half (differences fit in 9 bits + sign): the packed min / max of
+// VOP3P halve the instruction count of the ring arithmetic, which is what k_score spends its VALU time on
+typedef short s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ s16x2 pk_min(s16x2 a, s16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ s16x2 pk_max(s16x2 a, s16x2 b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ s16x2 oast9_score2(const s16x2 d[16]) {
+    // score = max{b : 9 contiguous ring pixels all > p+b or all < p-b} = max_arc min(+-d) - 1,  d = ring - centre
+    s16x2 mn2[16], mx2[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        mn4[i] = min(mn2[i], mn2[(i + 2) & 15]);
-        mx4[i] = max(mx2[i], mx2[(i + 2) & 15]);
+        mn2[i] = pk_min(d[i], d[(i + 1) & 15]);
+        mx2[i] = pk_max(d[i], d[(i + 1) & 15]);
     }
-    int best_b = -1000, best_d = 1000;  // best_d = min over arcs of max(d)  (dark score = -best_d)
+    s16x2 mn4[16], mx4[16];
 #pragma unroll
     for (int i = 0; i < 16; i++) {
-        int mn9 = min(min(mn4[i], mn4[(i + 4) & 15]), d[(i + 8) & 15]);
-        int mx9 = max(max(mx4[i], mx4[(i + 4) & 15]), d[(i + 8) & 15]);
-        best_b = max(best_b, mn9);
-        best_d = min(best_d, mx9);
+        mn4[i] = pk_min(mn2[i], mn2[(i + 2) & 15]);
+        mx4[i] = pk_max(mx2[i], mx2[(i + 2) & 15]);
     }
-    int best = max(max(best_b, -best_d), 0);
-    return best - 1;
+    s16x2 best_b = (s16x2)(-1000), best_d = (s16x2)(1000);  // best_d = min over arcs of max(d)  (dark score = -best_d)
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const s16x2 mn9 = pk_min(pk_min(mn4[i], mn4[(i + 4) & 15]), d[(i + 8) & 15]);
+        const s16x2 mx9 = pk_max(pk_max(mx4[i], mx4[(i + 4) & 15]), d[(i + 8) & 15]);
+        best_b = pk_max(best_b, mn9);
+        best_d = pk_min(best_d, mx9);
+    }
+    const s16x2 best = pk_max(pk_max(best_b, -best_d), (s16x2)(0));
+    return best - (s16x2)(1);
+}
+// bytes j and j + 1 (j = 0 .. 10, a compile-time constant after unrolling) of the 12-byte row segment (w0, w1, w2), widened to the two
+// halves of one register: a single v_perm_b32
+__device__ __forceinline__ s16x2 seg_pair(uint32_t w0, uint32_t w1, uint32_t w2, int j) {
+    const uint32_t lo = (j <= 6) ? w0 : w1, hi = (j <= 6) ? w1 : w2;
+    const uint32_t jj = (uint32_t)((j <= 6) ? j : j - 4);
+    const uint32_t r = __builtin_amdgcn_perm(hi, lo, 0x0c000c00u | jj | ((jj + 1u) << 16));
+    return __builtin_bit_cast(s16x2, r);
 }
 
 // raw-corner key: (ly << 18) | (lx << 8) | score    (cell-local coords < 1024, score <= 254)
@@ -98,8 +118,10 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par)
     const uint8_t *img = BEGIN ? fa.img[eye] : FB.img[eye];
     const int pitch = BEGIN ? fa.img_pitch : FB.img_pitch;
 
-    __shared__ __attribute__((aligned(16))) uint8_t tile[TILE_H][TILE_W];
-    __shared__ uint16_t hs[TILE_H][TS_W];
+    // every LDS access below is a whole word (a thread owns 4 horizontally adjacent pixels, so a 12-byte row segment = 3 words holds
+    // all it needs from one tile row): 35 LDS instructions per thread where byte-wise reads needed 158, and the kernel was LDS-issue-bound
+    __shared__ __attribute__((aligned(16))) uint32_t tile[TILE_H][TILE_W / 4];
+    __shared__ __attribute__((aligned(8))) uint2 hs[TILE_H][TS_W / 4];  // horizontal 9-sums, four u16 per entry
 
     const int tid = threadIdx.x;
     // ---- load tile + halo as 32-bit words (rows are 4-byte aligned: x0 % 64 == 0, pitch % 16 == 0)
@@ -120,18 +142,20 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par)
                 v &= (keep >= 4) ? 0xFFFFFFFFu : ((1u << (8 * keep)) - 1u);
             }
         }
-        *reinterpret_cast<uint32_t *>(&tile[r][4 * wc]) = v;
+        tile[r][wc] = v;
     }
     __syncthreads();
-    // ---- horizontal 9-sums
-    for (int idx = tid; idx < TILE_H * TS_W; idx += 256) {
-        const int r = idx >> 6, c = idx & 63;
-        int s = 0;
-#pragma unroll
-        for (int d = 0; d < 9; d++) s += tile[r][c + d];
-        hs[r][c] = (uint16_t)s;
+    // ---- horizontal 9-sums of four adjacent columns from one 12-byte segment: v_sad_u8 against 0 adds the four bytes of a word
+    for (int idx = tid; idx < TILE_H * (TS_W / 4); idx += 256) {
+        const int r = idx >> 4, j = idx & 15;
+        const uint32_t w0 = tile[r][j], w1 = tile[r][j + 1], w2 = tile[r][j + 2];
+        const uint32_t s0 = __builtin_amdgcn_sad_u8(w0, 0u, __builtin_amdgcn_sad_u8(w1, 0u, w2 & 255u));
+        const uint32_t s1 = s0 - (w0 & 255u) + ((w2 >> 8) & 255u);
+        const uint32_t s2 = s1 - ((w0 >> 8) & 255u) + ((w2 >> 16) & 255u);
+        const uint32_t s3 = s2 - ((w0 >> 16) & 255u) + (w2 >> 24);
+        hs[r][j] = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
     }
-    // ---- corner score of 4 horizontally adjacent pixels per thread
+    // ---- corner score of 4 horizontally adjacent pixels per thread, as two packed pairs
     const int tx = tid & 15, ty = tid >> 4;
     const int gy = y0 + ty;
     const int cs = S.prm.cell_size;
@@ -147,50 +171,55 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par)
     if (gy < H) {
         const int cy = gy / cs, ly = gy - cy * cs, ch = min(cs, H - cy * cs);
         const bool vy = (ly >= 3) && (ly <= ch - 4);
+        const int gx0 = x0 + 4 * tx;
+        if (vy && gx0 < W) {
+            const int cx0 = gx0 / cs, lx0 = gx0 - cx0 * cs;
+            uint32_t w[7][3];  // rows r0-3 .. r0+3, byte columns 4 tx .. 4 tx + 11 of the tile (pixel k's centre is byte 4 + k)
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int gx = x0 + 4 * tx + k;
-            int sc = 0;
-            if (vy && gx < W) {
-                const int cx = gx / cs, lx = gx - cx * cs, cw = min(cs, W - cx * cs);
-                if (lx >= 3 && lx <= cw - 4) {
-                    const int r0 = ty + HALO, c0 = 4 * tx + k + HALO;
-                    const int p = tile[r0][c0];
-                    // quick reject: every 9-arc contains one pixel of each opposite pair
-                    const int a0 = tile[r0][c0 - 3], a8 = tile[r0][c0 + 3];
-                    const int a4 = tile[r0 - 3][c0], a12 = tile[r0 + 3][c0];
-                    const int cb = p + t_low, c_b = p - t_low;
-                    const bool br = (a0 > cb || a8 > cb) && (a4 > cb || a12 > cb);
-                    const bool dk = (a0 < c_b || a8 < c_b) && (a4 < c_b || a12 < c_b);
-                    if (br || dk) {
-                        int r[16];
-                        r[0] = a0;
-                        r[1] = tile[r0 - 1][c0 - 3];
-                        r[2] = tile[r0 - 2][c0 - 2];
-                        r[3] = tile[r0 - 3][c0 - 1];
-                        r[4] = a4;
-                        r[5] = tile[r0 - 3][c0 + 1];
-                        r[6] = tile[r0 - 2][c0 + 2];
-                        r[7] = tile[r0 - 1][c0 + 3];
-                        r[8] = a8;
-                        r[9] = tile[r0 + 1][c0 + 3];
-                        r[10] = tile[r0 + 2][c0 + 2];
-                        r[11] = tile[r0 + 3][c0 + 1];
-                        r[12] = a12;
-                        r[13] = tile[r0 + 3][c0 - 1];
-                        r[14] = tile[r0 + 2][c0 - 2];
-                        r[15] = tile[r0 + 1][c0 - 3];
-                        const int s = oast9_score(p, r);
-                        sc = (s >= t_low) ? s : 0;
-                        if (s >= t_hi) {
-                            ckey[k] = mk_key(ly, lx, s);
-                            cvalid |= 1u << k;
-                            ncl += (cx == cell_x0) ? 1 : 0;
+            for (int dy = 0; dy < 7; dy++) {
+                w[dy][0] = tile[ty + HALO - 3 + dy][tx];
+                w[dy][1] = tile[ty + HALO - 3 + dy][tx + 1];
+                w[dy][2] = tile[ty + HALO - 3 + dy][tx + 2];
+            }
+            const s16x2 T = (s16x2)((short)t_low);
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int c = 4 + 2 * q;  // segment byte of the pair's first centre
+#define LVT_RING(dy, dx) (seg_pair(w[3 + (dy)][0], w[3 + (dy)][1], w[3 + (dy)][2], c + (dx)) - P)
+                const s16x2 P = seg_pair(w[3][0], w[3][1], w[3][2], c);
+                s16x2 d[16];
+                d[0] = LVT_RING(0, -3), d[8] = LVT_RING(0, 3), d[4] = LVT_RING(-3, 0), d[12] = LVT_RING(3, 0);
+                // quick reject: every 9-arc contains one pixel of each opposite pair
+                const s16x2 e1 = pk_min(pk_max(d[0], d[8]), pk_max(d[4], d[12]));   // > t_low: could be a bright corner
+                const s16x2 e2 = pk_max(pk_min(d[0], d[8]), pk_min(d[4], d[12]));   // < -t_low: could be a dark corner
+                const s16x2 pass = pk_max(e1, -e2) - T;
+                if (pass.x > 0 || pass.y > 0) {  // (a pixel that fails the test alone scores below t_low: same outcome as skipping it)
+                    d[1] = LVT_RING(-1, -3), d[2] = LVT_RING(-2, -2), d[3] = LVT_RING(-3, -1), d[5] = LVT_RING(-3, 1);
+                    d[6] = LVT_RING(-2, 2), d[7] = LVT_RING(-1, 3), d[9] = LVT_RING(1, 3), d[10] = LVT_RING(2, 2);
+                    d[11] = LVT_RING(3, 1), d[13] = LVT_RING(3, -1), d[14] = LVT_RING(2, -2), d[15] = LVT_RING(1, -3);
+                    const s16x2 s2 = oast9_score2(d);
+#pragma unroll
+                    for (int h = 0; h < 2; h++) {
+                        const int k = 2 * q + h, s = h ? (int)s2.y : (int)s2.x;
+                        int cx = cx0, lx = lx0 + k;
+                        if (lx >= cs) {
+                            const int qq = lx / cs;
+                            cx += qq;
+                            lx -= qq * cs;
+                        }
+                        const int cw = min(cs, W - cx * cs);
+                        if (gx0 + k < W && lx >= 3 && lx <= cw - 4) {
+                            packed |= (uint32_t)((s >= t_low) ? s : 0) << (8 * k);
+                            if (s >= t_hi) {
+                                ckey[k] = mk_key(ly, lx, s);
+                                cvalid |= 1u << k;
+                                ncl += (cx == cell_x0) ? 1 : 0;
+                            }
                         }
                     }
                 }
+#undef LVT_RING
             }
-            packed |= (uint32_t)sc << (8 * k);
         }
     }
     {  // the 16 lanes of one DPP row hold one tile row, x-ascending: a row scan of the counts places the keys
@@ -210,17 +239,13 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par)
     if (gy < H) {
         const int pp = S.plane_pitch;
         *reinterpret_cast<uint32_t *>(FB.score[eye] + (size_t)gy * pp + x0 + 4 * tx) = packed;
-        uint16_t b[4];
+        uint2 o = make_uint2(0u, 0u);  // four u16 sums; 81 * 255 < 2^16, so whole-word adds never carry between the halves
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int s = 0;
-#pragma unroll
-            for (int d = 0; d < 9; d++) s += hs[ty + d][4 * tx + k];
-            b[k] = (uint16_t)s;
+        for (int d = 0; d < 9; d++) {
+            const uint2 h = hs[ty + d][tx];
+            o.x += h.x;
+            o.y += h.y;
         }
-        uint2 o;
-        o.x = (uint32_t)b[0] | ((uint32_t)b[1] << 16);
-        o.y = (uint32_t)b[2] | ((uint32_t)b[3] << 16);
         *reinterpret_cast<uint2 *>(FB.boxsum[eye] + (size_t)gy * pp + x0 + 4 * tx) = o;
     }
 }
@@ -1333,35 +1358,108 @@ __device__ __forceinline__ int box_at(const Seq &S, const FrameBuf &FB, int eye,
 
 // publish_seq != 0: k_brief is the last kernel of the feature stage and its last workgroup publishes the frame's sequence number
 // for the gates of the other streams (a one-thread kernel behind it cost the feature chain a launch and a boundary)
+// The 512 box sums of a key point lie in the 49x49 window around it (|offset| <= 24: a 48-px patch).  Fetching them one by one made every wave touch
+// ~50 cache lines per load instruction, eight times over (4 waves x 70 lines do not stay in the L1): the batched launch ran at the
+// L2 -> L1 rate.  Now the wave copies the window ONCE, row-contiguous, into its own 4.9 KB of LDS (20 coalesced loads per lane, issued
+// for the next key point before the current one is evaluated) and samples it there.  Lane l evaluates, in round w, the test whose
+// result is bit l of descriptor word w (test 64 w + 8 (l / 8) + 7 - l % 8: OpenCV packs test 8 j + k into bit 7 - k of byte j), so
+// four ballots ARE the descriptor -- no cross-lane traffic.
+constexpr int BR_R = 24, BR_ROWS = 2 * BR_R + 1, BR_DW = 25;      // window rows; dwords per window row (49 u16 columns + 1 for an odd start)
+static_assert(brief_max_offset() <= BR_R, "k_brief's window does not cover the test pattern");
+constexpr int BR_WIN_DW = BR_ROWS * BR_DW, BR_LOADS = (BR_WIN_DW + 63) / 64;
 __global__ __launch_bounds__(256) void k_brief(Seq *seqs, int par, seq_t publish_seq) {
-    Seq &S = seqs[blockIdx.z];
-    const int eye = blockIdx.y;
+    // workgroups go to the 8 XCDs round-robin by their linear id, and every XCD has its own L2: with the plain mapping each L2 sees the
+    // box-sum planes of ALL sequences (30 MB for a batch of 16) and every window comes from the Infinity Cache.  When the number of planes
+    // is a multiple of 8, XCD x takes planes x, x + 8, ... whole, so a plane is pulled into ONE L2, once.
+    const int planes = gridDim.y * gridDim.z;
+    int lid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    int plane = lid / gridDim.x, bx = lid % gridDim.x;
+    if ((planes & 7) == 0) {
+        const int j = lid >> 3;
+        plane = (lid & 7) + 8 * (j / gridDim.x);
+        bx = j % gridDim.x;
+    }
+    Seq &S = seqs[plane / gridDim.y];
+    const int eye = plane % gridDim.y;
     FrameBuf &FB = S.fb[par];
     Feat &F = FB.feat[eye];
     const bool poison = FB.fc->poison != 0;  // (block-uniform; reset by the publishing workgroup below, after every workgroup has read it)
     const int n = poison ? 0 : *F.n;
     const int lane = lane_id();
     const int wpb = blockDim.x >> 6;
-    for (int i = blockIdx.x * wpb + wave_id(); i < n; i += gridDim.x * wpb) {
-        const int cy = (int)((double)F.by[i] + 0.5), cx = (int)((double)F.bx[i] + 0.5);
-        int nib = 0;
+    __shared__ uint32_t s_win[4][BR_WIN_DW + 64];
+    uint32_t *win = s_win[wave_id()];
+    typedef uint16_t __attribute__((may_alias)) u16_alias;  // (the window is written as words and sampled as halves)
+    const u16_alias *win16 = reinterpret_cast<const u16_alias *>(win);
+    const int W = S.prm.W, H = S.prm.H, ppd = S.plane_pitch >> 1;  // (the pitch is a multiple of 64)
+    const uint32_t *box32 = reinterpret_cast<const uint32_t *>(FB.boxsum[eye]);
+    // per-lane constants: where this lane's window words come from, and which eight window entries its four tests compare
+    int goff[BR_LOADS];
 #pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const signed char *t = c_brief[4 * lane + k];
-            const int a = box_at(S, FB, eye, cy + t[0], cx + t[1]);
-            const int b = box_at(S, FB, eye, cy + t[2], cx + t[3]);
-            nib |= (a < b ? 1 : 0) << (3 - k);
-        }
-        // byte j = nibble(lane 2j) << 4 | nibble(lane 2j+1); gather 8 bytes into one u64 per 16 lanes
-        const int hi = __shfl(nib, lane & ~1, 64), lo = __shfl(nib, lane | 1, 64);
-        const uint32_t byte = (uint32_t)((hi << 4) | lo);  // valid on every lane for byte index lane>>1
-        uint64_t word = 0;
+    for (int i = 0; i < BR_LOADS; i++) {
+        const int e = min(lane + 64 * i, BR_WIN_DW - 1);
+        goff[i] = (e / BR_DW) * ppd + (e % BR_DW);
+    }
+    int ta[4], tb[4];
+    signed char tq[4][4];
 #pragma unroll
-        for (int b = 0; b < 8; b++) {
-            const uint32_t v = __shfl(byte, ((lane >> 4) << 4) + 2 * b, 64);
-            word |= (uint64_t)(v & 255u) << (8 * b);
+    for (int w = 0; w < 4; w++) {
+        const signed char *t = c_brief[64 * w + 8 * (lane >> 3) + 7 - (lane & 7)];
+        tq[w][0] = t[0], tq[w][1] = t[1], tq[w][2] = t[2], tq[w][3] = t[3];
+        ta[w] = (t[0] + BR_R) * (2 * BR_DW) + t[1] + BR_R;
+        tb[w] = (t[2] + BR_R) * (2 * BR_DW) + t[3] + BR_R;
+    }
+    auto centre = [&](int i, int &cy, int &cx) {
+        cy = (int)((double)F.by[i] + 0.5), cx = (int)((double)F.bx[i] + 0.5);
+    };
+    auto inside = [&](int cy, int cx) { return cx - BR_R >= 0 && cx + BR_R < W && cy - BR_R >= 0 && cy + BR_R < H; };
+    const int stride = gridDim.x * wpb;
+    int i = bx * wpb + wave_id();
+    uint32_t v[BR_LOADS];
+    int cy = 0, cx = 0;
+    bool fast = false;
+    auto fetch = [&](int cy_, int cx_) {  // the window's words, row-contiguous from the even column at or left of cx - 24
+        // (address space 1 spelled out: a flat load would also count on lgkmcnt, and the LDS waits below would then wait for this prefetch)
+        typedef const uint32_t __attribute__((address_space(1))) gu32;
+        gu32 *src = (gu32 *)(box32 + (size_t)(cy_ - BR_R) * ppd + ((cx_ - BR_R) >> 1));
+#pragma unroll
+        for (int k = 0; k < BR_LOADS; k++) v[k] = src[goff[k]];
+    };
+    if (i < n) {
+        centre(i, cy, cx);
+        fast = inside(cy, cx);
+        if (fast) fetch(cy, cx);
+    }
+    for (; i < n; i += stride) {
+        uint64_t word[4];
+        const int inext = i + stride;
+        int ncy = 0, ncx = 0;
+        bool nfast = false;
+        if (inext < n) {
+            centre(inext, ncy, ncx);
+            nfast = inside(ncy, ncx);
         }
-        if ((lane & 15) == 0) F.desc[(size_t)i * 4 + (lane >> 4)] = word;
+        if (fast) {
+#pragma unroll
+            for (int k = 0; k < BR_LOADS; k++) win[lane + 64 * k] = v[k];  // (the tail of the last round lands in the 64 spare words)
+            if (nfast) fetch(ncy, ncx);  // in flight while this key point is evaluated
+            const int odd = (cx - BR_R) & 1;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int a = win16[ta[w] + odd], b = win16[tb[w] + odd];
+                word[w] = __ballot(a < b);
+            }
+        } else {  // window not inside the image (external corners at the border only): element-wise, clipped box sums
+            if (nfast) fetch(ncy, ncx);
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int a = box_at(S, FB, eye, cy + tq[w][0], cx + tq[w][1]);
+                const int b = box_at(S, FB, eye, cy + tq[w][2], cx + tq[w][3]);
+                word[w] = __ballot(a < b);
+            }
+        }
+        if (lane < 4) F.desc[(size_t)i * 4 + lane] = (lane == 0) ? word[0] : (lane == 1) ? word[1] : (lane == 2) ? word[2] : word[3];
+        cy = ncy, cx = ncx, fast = nfast;
     }
     if (publish_seq) {
         __syncthreads();  // every wave's descriptors are written ...

@@ -445,11 +445,17 @@ __global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, seq_t want, int par)
     }
 }
 
-// last kernel of the feature stage (one thread per sequence): this buffer's features are complete
+// last kernel of the feature stage of a batch (one thread per sequence): this buffer's features are complete.  (A single sequence lets
+// k_brief's last workgroup publish instead -- one launch less on its longest chain.  With a batch's 2048 workgroups that cost 60 us:
+// every workgroup's release fence is an L2 write-back.)
 __global__ void k_feat_done(Seq *seqs, int par, seq_t seq) {
     if (threadIdx.x != 0) return;
     FeatCtl &fc = *seqs[blockIdx.x].fb[par].fc;
     seqs[blockIdx.x].ctl->dbg[47] = (long long)wall_clock64();  // (written from the feature stream: the frame it belongs to may differ)
+    if (fc.poison) {  // the frame has no features (k_gate_buf timed out): say so to the gates of the other streams, then release the flag
+        fc.skip_seq = seq;
+        fc.poison = 0;
+    }
     __threadfence();
     atomicExch(&fc.feat_seq, seq);
 }

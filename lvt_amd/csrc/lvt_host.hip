@@ -587,7 +587,9 @@ static void enqueue_frame(Context *c) {
         }
     }
     LAUNCH(5, sf, k_gather, dim3(1, 2, B), dim3(1024), 0, S, par);
-    LAUNCH(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, S, par, evo ? (seq_t)0 : (seq_t)(c->enq + 1));  // (its last workgroup publishes feat_seq)
+    const bool brief_publishes = !evo && B == 1;  // (single sequence: k_brief's last workgroup publishes feat_seq; see k_feat_done)
+    LAUNCH(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, S, par, brief_publishes ? (seq_t)(c->enq + 1) : (seq_t)0);
+    if (!evo && !brief_publishes) hipLaunchKernelGGL(k_feat_done, dim3(B), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));
     const int bl = c->binned_lists ? 1 : 0;
     if (evo && bl && c->sensor == 1) LAUNCH_SM(19, sf, k_hamming_batched_lists, MODE_ROW, dim3(2, 1, B), dim3(LS_THREADS), LS_LDS_BYTES, par, (seq_t)0);
     if (evo) LAUNCH_SM(18, sf, k_candidates, MODE_ROW, dim3(256, 1, B), dim3(256), 0, 0, par, (seq_t)0, bl);  // (normal mode: on the early stream, below)

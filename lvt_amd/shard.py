@@ -27,15 +27,25 @@ def assign_sequences(n_sequences: int, world_size: int, rank: int):
 
 
 def timed_region(fn, dist=None, sync=None, device=None):
-    """barrier + device sync on both sides, wall time of fn(), MAX over ranks (the driver's contract)."""
+    """barrier + device sync on both sides, wall time of fn(), MAX over ranks (the driver's contract).
+    The interpreter's cyclic collector is held off while fn() runs: with torch imported a full collection takes ~30 ms -- 300 frame
+    periods -- and where it lands depends on the allocation count, not on the frame (found as "frame 433 takes 34 ms" at one
+    particular --warmup)."""
+    import gc
     import torch
-    if sync: sync()
-    if dist is not None: dist.barrier()
-    t0 = time.perf_counter()
-    out = fn()
-    if sync: sync()
-    if dist is not None: dist.barrier()
-    dt = time.perf_counter() - t0
+    gc.collect()
+    gc_was_on = gc.isenabled()
+    gc.disable()
+    try:
+        if sync: sync()
+        if dist is not None: dist.barrier()
+        t0 = time.perf_counter()
+        out = fn()
+        if sync: sync()
+        if dist is not None: dist.barrier()
+        dt = time.perf_counter() - t0
+    finally:
+        if gc_was_on: gc.enable()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

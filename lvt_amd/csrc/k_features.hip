@@ -6,6 +6,7 @@
 // Integer stages are bit-exact restatements; see DESIGN.md for the layout and roofline of each kernel.
 #include "lvt_dev.h"
 #include "lvt_math.h"
+#include <type_traits>
 
 namespace lvt {
 
@@ -310,14 +311,21 @@ __device__ __forceinline__ void heap_sort_seq(uint32_t *f, int len) {
 // std::__unguarded_partition_pivot on arr[first,last) executed by ONE full wavefront.
 // Hoare partition evaluated with ballots: the k-th "left stop" (ascending) swaps with the k-th
 // "right stop" (descending) while they have not crossed (see DESIGN.md "std::sort emulation").
+// Only this wavefront touches arr[first,last) and its slice of posL / posR, and a wavefront's LDS operations execute in program
+// order: no fences between the steps when the arrays live in LDS (16-bit indices).  The global-memory path (32-bit indices) keeps them.
+template <typename I>
+__device__ __forceinline__ void part_fence() {
+    if (sizeof(I) == 4) __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+}
 template <typename I>
 __device__ __forceinline__ int wave_partition_pivot(uint32_t *arr, int first, int last, I *posL, I *posR) {
     const int lane = lane_id();
     const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const int mid = first + (last - first) / 2;
-    if (lane == 0) {  // std::__move_median_to_first(first, first+1, mid, last-1)
+    int piv;
+    {  // std::__move_median_to_first(first, first+1, mid, last-1): the four words are read by every lane at once (one round trip)
         const int a = first + 1, b = mid, c = last - 1;
-        const uint32_t va = arr[a], vb = arr[b], vc = arr[c];
+        const uint32_t va = arr[a], vb = arr[b], vc = arr[c], vf = arr[first];
         int pick;
         if (scomp(va, vb)) {
             if (scomp(vb, vc)) pick = b;
@@ -326,29 +334,38 @@ __device__ __forceinline__ int wave_partition_pivot(uint32_t *arr, int first, in
         } else if (scomp(va, vc)) pick = a;
         else if (scomp(vb, vc)) pick = c;
         else pick = b;
-        const uint32_t t = arr[first];
-        arr[first] = arr[pick];
-        arr[pick] = t;
+        const uint32_t vp = (pick == a) ? va : (pick == b) ? vb : vc;
+        if (lane == 0) {
+            arr[first] = vp;
+            arr[pick] = vf;
+        }
+        piv = key_r(vp);
     }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-    const int piv = key_r(arr[first]);
+    part_fence<I>();
     const int lo = first + 1, hi = last;
     int cntL = 0, cntR = 0;
-    for (int base = lo; base < hi; base += 64) {
-        const int p = base + lane;
-        const bool isL = (p < hi) && !(key_r(arr[p]) > piv);
-        const uint64_t m = __ballot(isL);
-        if (isL) posL[first + cntL + __popcll(m & lt_mask)] = (I)p;
-        cntL += __popcll(m);
+    // the left-stop scan (ascending) and the right-stop scan (descending) are independent: both run in the same trip, two 64-element
+    // groups each, so four LDS reads are in flight where the one-group-per-trip loops waited for one (the scans are latency-bound)
+    for (int base = lo, top = hi; base < hi; base += 128, top -= 128) {
+        const int p0 = base + lane, p1 = p0 + 64;
+        const int q0 = top - 1 - lane, q1 = q0 - 64;
+        // (clamped addresses, unconditional loads: a load under a branch gets its own wait and the four would run one after the other)
+        const uint32_t va0 = arr[min(p0, hi - 1)], va1 = arr[min(p1, hi - 1)], vb0 = arr[max(q0, lo)], vb1 = arr[max(q1, lo)];
+        const int a0 = (p0 < hi) ? key_r(va0) : 0x7FFF, a1 = (p1 < hi) ? key_r(va1) : 0x7FFF;
+        const int b0 = (q0 >= lo) ? key_r(vb0) : -1, b1 = (q1 >= lo) ? key_r(vb1) : -1;
+        const bool l0 = !(a0 > piv), l1 = !(a1 > piv);  // (the out-of-range fillers never stop a scan)
+        const bool r0 = !(piv > b0), r1 = !(piv > b1);
+        const uint64_t ml0 = __ballot(l0), ml1 = __ballot(l1), mr0 = __ballot(r0), mr1 = __ballot(r1);
+        if (l0) posL[first + cntL + __popcll(ml0 & lt_mask)] = (I)p0;
+        cntL += __popcll(ml0);
+        if (l1) posL[first + cntL + __popcll(ml1 & lt_mask)] = (I)p1;
+        cntL += __popcll(ml1);
+        if (r0) posR[first + cntR + __popcll(mr0 & lt_mask)] = (I)q0;
+        cntR += __popcll(mr0);
+        if (r1) posR[first + cntR + __popcll(mr1 & lt_mask)] = (I)q1;
+        cntR += __popcll(mr1);
     }
-    for (int top = hi; top > lo; top -= 64) {
-        const int q = top - 1 - lane;
-        const bool isR = (q >= lo) && !(piv > key_r(arr[q]));
-        const uint64_t m = __ballot(isR);
-        if (isR) posR[first + cntR + __popcll(m & lt_mask)] = (I)q;
-        cntR += __popcll(m);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    part_fence<I>();
     const int K = min(cntL, cntR);
     int m = 0;
     for (int base = 0; base < K; base += 64) {
@@ -366,25 +383,20 @@ __device__ __forceinline__ int wave_partition_pivot(uint32_t *arr, int first, in
     }
     const int pm = (m < cntL) ? (int)posL[first + m] : 0x7FFFFFFF;
     const int qm1 = (m > 0) ? (int)posR[first + m - 1] : last;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    part_fence<I>();
     return min(pm, qm1);
 }
 
-// std::__introsort_loop on arr[0,n): partitions only; the final insertion sort is a stable sort and
-// is done afterwards by ranking.  ONE wavefront; `stack` = 3*64 ints of LDS.
+// std::__introsort_loop on arr[first,last) with `depth` splits left, depth-first by ONE wavefront (partitions only; the final insertion
+// sort is a stable sort and is done afterwards by ranking).  `stack` = 3 ints per pending segment: at most one per halving of depth.
 template <typename I>
-__device__ __forceinline__ void wave_introsort_partitions(uint32_t *arr, int n, I *posL, I *posR, int *stack) {
-    if (n <= 16) return;
-    int depth0 = 0;
-    for (int v = n; v > 1; v >>= 1) depth0++;
-    depth0 *= 2;
+__device__ __forceinline__ void wave_introsort_segment(uint32_t *arr, int first, int last, int depth, I *posL, I *posR, int *stack) {
     int sp = 0;
-    int first = 0, last = n, depth = depth0;
     while (true) {
         while (last - first > 16) {
             if (depth == 0) {
                 if (lane_id() == 0) heap_sort_seq(arr + first, last - first);
-                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+                part_fence<I>();
                 break;
             }
             --depth;
@@ -401,7 +413,7 @@ __device__ __forceinline__ void wave_introsort_partitions(uint32_t *arr, int n, 
         }
         if (sp == 0) break;
         sp--;
-        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+        part_fence<I>();
         first = stack[3 * sp];
         last = stack[3 * sp + 1];
         depth = stack[3 * sp + 2];
@@ -792,12 +804,17 @@ __device__ __forceinline__ int cell_anms(const Seq &S, const CellGeom &g, uint32
     if (n_kp > max_kp) {
         I *posL = root;  // free after NMS
         I *posR = abv;
-        // ---- std::__introsort_loop, level by level: the segments of one recursion level are disjoint, so every
-        // wavefront partitions its own segments concurrently (queues live in the dead nms[] array)
+        // ---- std::__introsort_loop.  The segments of one recursion level are disjoint: the first levels run level by level, one
+        // wavefront per segment with a workgroup barrier between levels; as soon as a level holds one segment per wavefront each
+        // wavefront finishes its segments depth-first on its own (no more barriers, nobody waits for the level's largest segment).
+        // Queues and stacks live in the dead nms[] array.
         {
             int *q = reinterpret_cast<int *>(nms);
-            const int qcap = (int)((sizeof(I) * (size_t)n_cap) / (6 * sizeof(int)));  // per level
+            constexpr int DFS_AT = 64;  // (also bounds the queues: a level never holds more than 2 * DFS_AT segments)
+            constexpr int qcap = 2 * DFS_AT;  // per level (a level is handed over to the depth-first part at DFS_AT segments)
             int *qa = q, *qb = q + 3 * qcap;
+            int *stacks = q + 6 * qcap;  // [16 wavefronts][3 * 32]
+            const int nw = blockDim.x >> 6;
             if (tid == 0) {
                 int depth0 = 0;
                 for (int v = n_kp; v > 1; v >>= 1) depth0++;
@@ -806,10 +823,16 @@ __device__ __forceinline__ int cell_anms(const Seq &S, const CellGeom &g, uint32
                 misc[2] = 0;
             }
             __syncthreads();
+            int levels = 0;
             while (true) {
                 const int cnt = misc[1];
                 if (cnt == 0) break;
-                const int nw = blockDim.x >> 6;
+                levels++;
+                if (cnt >= DFS_AT) {  // depth-first from here
+                    for (int sgi = wave_id(); sgi < cnt; sgi += nw)
+                        wave_introsort_segment<I>(arr, qa[3 * sgi], qa[3 * sgi + 1], qa[3 * sgi + 2], posL, posR, stacks + 96 * wave_id());
+                    break;
+                }
                 for (int sgi = wave_id(); sgi < cnt; sgi += nw) {
                     const int first = qa[3 * sgi], last = qa[3 * sgi + 1], depth = qa[3 * sgi + 2];
                     if (depth == 0) {
@@ -820,17 +843,17 @@ __device__ __forceinline__ int cell_anms(const Seq &S, const CellGeom &g, uint32
                     if (lane_id() == 0) {
                         if (last - cut > 16) {
                             const int o = atomicAdd(&misc[2], 1);
-                            if (o < qcap) qb[3 * o] = cut, qb[3 * o + 1] = last, qb[3 * o + 2] = depth - 1;
+                            qb[3 * o] = cut, qb[3 * o + 1] = last, qb[3 * o + 2] = depth - 1;
                         }
                         if (cut - first > 16) {
                             const int o = atomicAdd(&misc[2], 1);
-                            if (o < qcap) qb[3 * o] = first, qb[3 * o + 1] = cut, qb[3 * o + 2] = depth - 1;
+                            qb[3 * o] = first, qb[3 * o + 1] = cut, qb[3 * o + 2] = depth - 1;
                         }
                     }
                 }
                 __syncthreads();
                 if (tid == 0) {
-                    misc[1] = min(misc[2], qcap);
+                    misc[1] = misc[2];
                     misc[2] = 0;
                 }
                 int *t = qa;
@@ -838,6 +861,8 @@ __device__ __forceinline__ int cell_anms(const Seq &S, const CellGeom &g, uint32
                 qb = t;
                 __syncthreads();
             }
+            __syncthreads();
+            if (dbg && tid == 0) dbg[41] = levels;
         }
         STAMP(6);
         // ---- final insertion sort == stable sort by response (descending).  rank = #(greater response) +
@@ -894,34 +919,65 @@ __device__ __forceinline__ int cell_anms(const Seq &S, const CellGeom &g, uint32
         }
         __syncthreads();
         STAMP(7);
-        // ---- suppression radius^2 (integers: exact in the reference's float arithmetic too).  sorted[] is
-        // descending, so the points stronger than 1.11 * response are a prefix whose length a binary search finds;
-        // four lanes share one key point.
+        // ---- suppression radius^2 (integers: exact in the reference's float arithmetic too).  sorted[] is descending, so the points
+        // stronger than 1.11 * response are a prefix [0, lo) whose length a binary search finds, and lo never decreases along the
+        // array.  One lane per key point; the lanes of a wave walk the prefix TOGETHER (every lane reads the same word: an LDS
+        // broadcast), coordinates packed as two 16-bit halves so that a distance is one packed subtract and one dot product.  The
+        // phase is VALU-bound on the cell's single CU (n^2 / 2 distances): 3 instructions per distance where the scalar form had 8.
         uint32_t *r2 = arr;  // arr consumed
-        for (int base = 0; base < n_kp; base += 256) {
-            const int i = base + (tid >> 2), sub = tid & 3;
-            uint32_t best = 0xFFFFFFFFu;
-            if (i < n_kp) {
-                const uint32_t k = sorted[i];
-                const float response = (float)key_r(k) * 1.11f;
-                const int yi = key_y(k), xi = key_x(k);
-                int lo = 0, hi = i;  // first index in [0,i) whose response is NOT > `response`
-                while (lo < hi) {
-                    const int m = (lo + hi) >> 1;
-                    if ((float)key_r(sorted[m]) > response) lo = m + 1;
-                    else hi = m;
+        uint32_t *sxy = reinterpret_cast<uint32_t *>(root);  // posL (and, with 16-bit indices, the adjacent posR) are dead: x | y << 16
+        for (int i = tid; i < n_kp; i += 1024) {
+            const uint32_t k = sorted[i];
+            sxy[i] = (uint32_t)key_x(k) | ((uint32_t)key_y(k) << 16);
+        }
+        __syncthreads();
+        // small cells: 2 or 4 lanes share a key point (its prefix in interleaved groups of four), so that all 16 wavefronts have work
+        auto radii = [&](auto lpp_log_c) {
+            constexpr int lpp_log = decltype(lpp_log_c)::value, lpp = 1 << lpp_log, ppp = 1024 >> lpp_log, step = 4 * lpp;
+            for (int base = 0; base < n_kp; base += ppp) {
+                const int i = base + (tid >> lpp_log), sub = tid & (lpp - 1);
+                const bool valid = i < n_kp;
+                int lo = 0;
+                if (valid) {
+                    const float response = (float)key_r(sorted[i]) * 1.11f;
+                    int hi = i;  // first index in [0,i) whose response is NOT > `response`
+                    while (lo < hi) {
+                        const int m = (lo + hi) >> 1;
+                        if ((float)key_r(sorted[m]) > response) lo = m + 1;
+                        else hi = m;
+                    }
                 }
-#pragma unroll 4
-                for (int j = sub; j < lo; j += 4) {
-                    const uint32_t kj = sorted[j];
-                    const int dx = xi - key_x(kj), dy = yi - key_y(kj);
-                    best = min(best, (uint32_t)(dx * dx + dy * dy));
+                const int wave_first = base + ((tid & ~63) >> lpp_log);
+                if (wave_first < n_kp) {  // (wave-uniform)
+                    const int n_valid = min(64 >> lpp_log, n_kp - wave_first);
+                    const int lo_min = __shfl(lo, 0, 64), lo_max = __shfl(lo, (n_valid << lpp_log) - 1, 64);
+                    const s16x2 pi = __builtin_bit_cast(s16x2, sxy[min(i, n_kp - 1)]);
+                    uint32_t best = 0xFFFFFFFFu;
+                    int j = 4 * sub;
+                    for (; j + 4 <= lo_min; j += step) {  // every lane's prefix covers these
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const s16x2 d = pi - __builtin_bit_cast(s16x2, sxy[j + c]);
+                            best = min(best, (uint32_t)__builtin_amdgcn_sdot2(d, d, 0, false));
+                        }
+                    }
+                    for (; j < lo_max; j += step) {
+#pragma unroll
+                        for (int c = 0; c < 4; c++) {
+                            const s16x2 d = pi - __builtin_bit_cast(s16x2, sxy[j + c]);  // (reads at most 3 words past the prefix: inside the arrays)
+                            const uint32_t d2 = (uint32_t)__builtin_amdgcn_sdot2(d, d, 0, false);
+                            best = (j + c < lo) ? min(best, d2) : best;
+                        }
+                    }
+                    if (lpp > 1) best = min(best, (uint32_t)__shfl_xor((int)best, 1, 64));
+                    if (lpp > 2) best = min(best, (uint32_t)__shfl_xor((int)best, 2, 64));
+                    if (valid && sub == 0) r2[i] = best;
                 }
             }
-            best = min(best, (uint32_t)__shfl_xor((int)best, 1, 64));
-            best = min(best, (uint32_t)__shfl_xor((int)best, 2, 64));
-            if (i < n_kp && sub == 0) r2[i] = best;
-        }
+        };
+        if (n_kp <= 512) radii(std::integral_constant<int, 2>{});
+        else if (n_kp <= 1024) radii(std::integral_constant<int, 1>{});
+        else radii(std::integral_constant<int, 0>{});
         __syncthreads();
         STAMP(8);
         // ---- decisionRadius = (max_kp)-th element (0-based) of the radii sorted descending: radix select over
@@ -1022,7 +1078,7 @@ __device__ __forceinline__ int cell_anms(const Seq &S, const CellGeom &g, uint32
         n_out = n_kp;
     }
     STAMP(10);
-    if (dbg && threadIdx.x == 0) { dbg[20] = n_raw; dbg[21] = n_kp; dbg[22] = n_out; }
+    if (dbg && threadIdx.x == 0) dbg[39] = (long long)n_raw | ((long long)n_kp << 16) | ((long long)n_out << 32);  // (one free slot)
     return n_out;
 }
 #undef STAMP
@@ -1131,7 +1187,7 @@ __global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass, int par) {
         if (dbg && tid == 0) dbg[1] = clock64();
         if (n_raw <= RAW_CAP) {
             n_out = cell_nms_anms<uint16_t>(S, g, L.keys, L.uf, L.root16, L.abv16, L.nms16, L.tie8, n_raw, RAW_CAP, L.row_first, L.row_end, L.scan, L.stack, L.misc, out, dbg);
-        } else if (S.prm.big_cell_strips) {
+        } else if (S.prm.big_cell_strips && pass == 0) {
             // more raw corners than this workgroup's LDS holds, in a cell tall enough to cut: k_cells_strip (NMS of row strips on several
             // CUs) and k_cells_big (ANMS of the merged survivors) take over; they also write cell_n / n_detected
             if (tid == 0) S.cell_big[eye][cell] = 1;
@@ -1231,7 +1287,7 @@ __global__ __launch_bounds__(1024) void k_cells_big(Seq *seqs, int pass, int par
     const int *cnt = S.strip_n[eye] + cell * STRIPS;
     int total = 0;
     bool bad = false;
-    for (int s = 0; s < STRIPS; s++) {  // (block-uniform: every thread reads the same eight words)
+    for (int s = 0; s < STRIPS; s++) {  // (block-uniform: every thread reads the same words)
         const int n = cnt[s];
         bad = bad || n < 0;
         total += max(n, 0);
@@ -1247,7 +1303,10 @@ __global__ __launch_bounds__(1024) void k_cells_big(Seq *seqs, int pass, int par
             off += cnt[s];
         }
         __syncthreads();
-        n_out = cell_anms<uint16_t>(S, g, L.keys, L.uf, L.root16, L.abv16, L.nms16, total, RAW_CAP, L.row_first, L.row_end, L.scan, L.misc, out, nullptr, total);
+        long long *dbg = (cell == 0 && eye == 0 && pass == 0) ? S.ctl->dbg : nullptr;  // (phase stamps 5 .. 10: tools/cells_phases.py)
+        if (dbg && tid == 0) dbg[5] = clock64();
+        n_out = cell_anms<uint16_t>(S, g, L.keys, L.uf, L.root16, L.abv16, L.nms16, total, RAW_CAP, L.row_first, L.row_end, L.scan, L.misc, out, dbg, total);
+        if (dbg && tid == 0) dbg[11] = clock64();
     }
     cell_finish(FB, eye, cell, pass, n_out);
 }

@@ -664,18 +664,27 @@ constexpr uint32_t PERM = 0xFFFFFFFFu;
 
 template <class NFn>
 __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint32_t *cand, ResolveLds &L, uint32_t &iter, float ratio,
-                                             float desc_th, int acc[2], int nq[2] = nullptr) {
+                                             float desc_th, int acc[2], int nq[2] = nullptr, const uint32_t *qidx = nullptr, int qid[2] = nullptr) {
+    // qidx != nullptr: b0 / M / the return value count entries of the COMPACTED query list qidx[] (query | candidate count << 24, in
+    // query order -- the greedy scan only ever decides queries that have candidates, and their relative order is all it depends on)
     const int tid = threadIdx.x;
-    int n[2], off[2];
+    int n[2], off[2], qq[2];
     const long long ts0 = clock64();
     if (tid == 0) L.misc[0] = QCAP;
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < 2; u++) {
         const int lq = tid + u * RES_THREADS, q = b0 + lq;
-        n[u] = (q < M) ? nfn(q) : 0;
+        qq[u] = q;
+        if (qidx) {
+            const uint32_t w = (q < M) ? qidx[q] : 0u;
+            qq[u] = (int)(w & 0xFFFFFFu);
+            n[u] = (int)(w >> 24);  // (capped at 255 > KC: still "overflow")
+        } else
+            n[u] = (q < M) ? nfn(q) : 0;
         if (n[u] > KC) atomicMin(&L.misc[0], lq);
     }
+    if (qid) qid[0] = qq[0], qid[1] = qq[1];
     __syncthreads();
     int limit = min(min(QCAP, M - b0), L.misc[0]);
     if (limit == 0) return -1;
@@ -705,41 +714,60 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
     }
     const long long ts1 = clock64();
     // pack the lists into LDS: 16-byte loads, 32 entries (8 loads) in flight per query -- one memory round trip for
-    // the usual list of < 32 candidates (rows of `cand` are KC words apart, so every row start is 16-byte aligned)
+    // the usual list of < 32 candidates (rows of `cand` are KC words apart, so every row start is 16-byte aligned).
+    // Candidates that already carry a permanent mark (matched by an earlier super-chunk, or before this call) are dropped here: they
+    // stay unavailable for the rest of the call, and on a large map most entries of the later super-chunks are such (TUM: 8000 queries
+    // compete for 1000 features) -- every fixpoint iteration would walk over them again.
+    if (nq) nq[0] = n[0], nq[1] = n[1];  // (original list lengths of this thread's queries: the caller need not fetch them again)
 #pragma unroll
     for (int u = 0; u < 2; u++) {
-        const uint4 *src = reinterpret_cast<const uint4 *>(cand + (size_t)(b0 + tid + u * RES_THREADS) * KC);
+        const uint4 *src = reinterpret_cast<const uint4 *>(cand + (size_t)qq[u] * KC);
+        uint32_t *dst = L.lists + off[u];
+        int w = 0;
         for (int e0 = 0; e0 < n[u]; e0 += 32) {
             uint4 v[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) v[k] = (e0 + 4 * k < n[u]) ? src[(e0 >> 2) + k] : make_uint4(0, 0, 0, 0);
+            uint32_t mk[32];
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                mk[4 * k] = L.tab0[v[k].x & (uint32_t)(NF_MAX - 1)];
+                mk[4 * k + 1] = L.tab0[v[k].y & (uint32_t)(NF_MAX - 1)];
+                mk[4 * k + 2] = L.tab0[v[k].z & (uint32_t)(NF_MAX - 1)];
+                mk[4 * k + 3] = L.tab0[v[k].w & (uint32_t)(NF_MAX - 1)];
+            }
 #pragma unroll
             for (int k = 0; k < 8; k++) {
                 const int e = e0 + 4 * k;
-                uint32_t *dst = L.lists + off[u] + e;
-                if (e < n[u]) dst[0] = v[k].x;
-                if (e + 1 < n[u]) dst[1] = v[k].y;
-                if (e + 2 < n[u]) dst[2] = v[k].z;
-                if (e + 3 < n[u]) dst[3] = v[k].w;
+                if (e < n[u] && mk[4 * k] != PERM) dst[w++] = v[k].x;
+                if (e + 1 < n[u] && mk[4 * k + 1] != PERM) dst[w++] = v[k].y;
+                if (e + 2 < n[u] && mk[4 * k + 2] != PERM) dst[w++] = v[k].z;
+                if (e + 3 < n[u] && mk[4 * k + 3] != PERM) dst[w++] = v[k].w;
             }
         }
+        n[u] = w;
     }
+    if (tid == 0) L.misc[12] = L.misc[13] = QCAP;  // first changed query of an iteration (two slots, by iteration parity)
     __syncthreads();
-    if (nq) nq[0] = n[0], nq[1] = n[1];  // (list lengths of this thread's queries: the caller need not fetch them again)
     int prev[2] = {-2, -2};
     acc[0] = acc[1] = -1;
     int dbg_steps = 0;
     const long long tj0 = clock64();
     const uint32_t it0 = iter;
+    // queries [0, fin) of this super-chunk are FINAL: none of them, nor any query before them, changed its decision in the last
+    // iteration, so their inputs -- the decisions of earlier queries -- will never change again.  They stop walking; the features
+    // they accepted get their permanent marks at once (a permanent mark hides a feature from every query, a claim only from the later
+    // ones -- and only later ones are still deciding).
+    int fin = 0;
     while (true) {
         iter++;
         const uint32_t *rd = (iter & 1u) ? L.tab0 : L.tab1;  // written during iteration iter-1
         uint32_t *wr = (iter & 1u) ? L.tab1 : L.tab0;
-        bool changed = false;
+        int first_changed = QCAP;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            if (n[u] == 0) continue;
             const int lq = tid + u * RES_THREADS;
+            if (n[u] == 0 || lq < fin) continue;
             const uint32_t *list = L.lists + off[u];
             uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
             int cnt = 0;
@@ -768,11 +796,26 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
             dbg_steps = max(dbg_steps, n[u]);
             acc[u] = ok ? (int)(k1 & 0xFFFFu) : -1;
             if (ok) atomicMax(&wr[acc[u]], (iter << 11) | (uint32_t)(2047 - lq));
-            changed = changed || (acc[u] != prev[u]);
+            if (acc[u] != prev[u]) first_changed = min(first_changed, lq);
             prev[u] = acc[u];
         }
-        if (threadIdx.x == 0 && iter - it0 <= 4) L.misc[8 + (iter - it0 - 1)] = (int)(clock64() - tj0);
-        if (!__syncthreads_or(changed ? 1 : 0)) break;
+        int *slot = &L.misc[12 + (iter & 1u)];
+        if (first_changed < QCAP) atomicMin(slot, first_changed);
+        __syncthreads();
+        const int fc = *slot;
+        if (fc >= QCAP) break;  // nothing changed: every decision is final
+        if (tid == 0) L.misc[12 + ((iter + 1u) & 1u)] = QCAP;  // the next iteration's slot (nobody touches it before the barrier below)
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int lq = tid + u * RES_THREADS;
+            if (lq >= fin && lq < fc && n[u] > 0 && acc[u] >= 0) {
+                L.flag[acc[u]] = 1;
+                L.tab0[acc[u]] = PERM;
+                L.tab1[acc[u]] = PERM;
+            }
+        }
+        fin = fc;
+        __syncthreads();
     }
     if (threadIdx.x == 0) {
         L.misc[4] = (int)(iter - it0);
@@ -804,7 +847,7 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
     __shared__ uint32_t r_tab[2 * NF_MAX];                  \
     __shared__ __attribute__((aligned(16))) uint32_t r_lists[LCAP]; \
     __shared__ int r_scan[32];                              \
-    __shared__ int r_misc[16];                              \
+    __shared__ int r_misc[16];  /* [12], [13]: first changed query of the odd / even fixpoint iterations */                              \
     ResolveLds L;                                           \
     L.flag = r_flag, L.tab0 = r_tab, L.tab1 = r_tab + NF_MAX, L.lists = r_lists, L.scan = r_scan, L.misc = r_misc;
 
@@ -845,27 +888,53 @@ __device__ __forceinline__ void resolve_body(const Seq &S, Ctl &ctl, int pass2, 
     uint32_t iter = 0;
     int accepted = (phase == 2) ? ctl.early_accepted : 0;  // block-uniform
     if (phase == 1) M = min(M, q_split);
+    int b0 = (phase == 2) ? q_split : 0;
+    // A map much larger than a super-chunk (TUM-shaped sequences: 9000 points, 800 of them visible with candidates) would walk
+    // through five mostly empty super-chunks: the points that have candidates are compacted first, in storage order, and the
+    // super-chunks run over that list -- the scan's decisions depend on nothing else.
+    const uint32_t *qidx = nullptr;
+    if (MODE == MODE_MAP && M - b0 > QCAP) {
+        const int per = (M - b0 + RES_THREADS - 1) / RES_THREADS;
+        const int i0 = min(b0 + tid * per, M), i1 = min(i0 + per, M);
+        int cnt = 0;
+        for (int i = i0; i < i1; i++) cnt += (ncand[i] > 0) ? 1 : 0;
+        int total;
+        int o = block_excl_scan(cnt, L.scan, &total);
+        for (int i = i0; i < i1; i++) {
+            const int nc = ncand[i];
+            if (nc > 0) S.qidx[o++] = (uint32_t)i | ((uint32_t)min(nc, 255) << 24);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        qidx = S.qidx;
+        b0 = 0;
+        M = total;
+    }
     __syncthreads();
+    if (qidx) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     const long long tk1 = clock64();
-    for (int b0 = (phase == 2) ? q_split : 0; b0 < M;) {
-        int acc[2], nq[2] = {0, 0};
+    int st_chunks = 0, st_slow = 0, st_iter = 0, st_itmax = 0, st_fix = 0, st_cs = 0, st_pack = 0;  // bring-up statistics (thread 0)
+    for (; b0 < M;) {
+        int acc[2], nq[2] = {0, 0}, qid[2];
         const uint8_t *lflag = S.fb[par].feat[0].flag;
-        const int used = resolve_super(b0, M, [&](int q) { return (MODE == MODE_ROW && lflag[q]) ? 0 : ncand[q]; }, cand, L, iter, ratio, desc_th, acc, nq);
+        const int used = resolve_super(b0, M, [&](int q) { return (MODE == MODE_ROW && lflag[q]) ? 0 : ncand[q]; }, cand, L, iter, ratio, desc_th, acc, nq, qidx, qid);
+        if (used < 0) st_slow++;
+        else if (tid == 0) st_chunks++, st_iter += L.misc[4], st_itmax = max(st_itmax, L.misc[4]), st_fix += L.misc[5], st_cs += L.misc[6], st_pack += L.misc[7];
         if (used < 0) {  // query b0 overflowed KC: exact scan of all train features by wavefront 0
+            const int qb = qidx ? (int)(qidx[b0] & 0xFFFFFFu) : b0;
             if (wave_id() == 0) {
                 float qx, qy;
-                if (MODE == MODE_MAP) qx = S.proj[2 * b0], qy = S.proj[2 * b0 + 1];
-                else qx = S.fb[par].feat[0].x[b0], qy = S.fb[par].feat[0].y[b0];
-                const int idx = decide_query_slow<MODE>(S, T, N, L.flag, qdesc, b0, qx, qy, radius, ratio, desc_th);
+                if (MODE == MODE_MAP) qx = S.proj[2 * qb], qy = S.proj[2 * qb + 1];
+                else qx = S.fb[par].feat[0].x[qb], qy = S.fb[par].feat[0].y[qb];
+                const int idx = decide_query_slow<MODE>(S, T, N, L.flag, qdesc, qb, qx, qy, radius, ratio, desc_th);
                 if (lane_id() == 0) {
-                    if (MODE == MODE_MAP) S.match[b0] = idx;
+                    if (MODE == MODE_MAP) S.match[qb] = idx;
                     if (idx >= 0) {
                         L.flag[idx] = 1;
                         L.tab0[idx] = L.tab1[idx] = PERM;
                         if (MODE == MODE_ROW) {
-                            S.pair_l[accepted] = b0;
+                            S.pair_l[accepted] = qb;
                             S.pair_r[accepted] = idx;
-                            S.fb[par].feat[0].flag[b0] = 1;
+                            S.fb[par].feat[0].flag[qb] = 1;
                         }
                     }
                     L.misc[1] = (idx >= 0) ? 1 : 0;
@@ -890,7 +959,7 @@ __device__ __forceinline__ void resolve_body(const Seq &S, Ctl &ctl, int pass2, 
         const int tot = tot0 + tot1;
 #pragma unroll
         for (int u = 0; u < 2; u++) {
-            const int lq = tid + u * RES_THREADS, q = b0 + lq;
+            const int lq = tid + u * RES_THREADS, q = qid[u];
             if (lq >= used) continue;
             if (MODE == MODE_MAP) {
                 if (nq[u] > 0) S.match[q] = acc[u];  // invisible / candidate-less points keep -2 / -1 (k_match_map / k_early_map)
@@ -912,12 +981,12 @@ __device__ __forceinline__ void resolve_body(const Seq &S, Ctl &ctl, int pass2, 
         if (tid == 0 && phase == 1) {
             ctl.early_accepted = accepted;
             // bring-up stamps of the resolver (tools/cells_phases.py): the early part is where most of find_matches is resolved
-            ctl.dbg[18] = L.misc[4];
-            ctl.dbg[19] = L.misc[5];
+            ctl.dbg[18] = st_iter;   // sums over the super-chunks of this call
+            ctl.dbg[19] = st_fix;
             ctl.dbg[28] = L.misc[3];
-            for (int k = 0; k < 4; k++) ctl.dbg[24 + k] = L.misc[8 + k];
-            ctl.dbg[29] = L.misc[6];
-            ctl.dbg[30] = L.misc[7];
+            ctl.dbg[24] = st_chunks, ctl.dbg[25] = st_slow, ctl.dbg[26] = st_itmax, ctl.dbg[27] = M;
+            ctl.dbg[29] = st_cs;
+            ctl.dbg[30] = st_pack;
             ctl.dbg[31] = tk1 - tk0;
             ctl.dbg[23] = clock64() - tk0;
         }

@@ -183,6 +183,7 @@ struct Seq {
     int *match;                 // [MAP_MAX]  -2 invisible, -1 none, else feature index
     uint32_t *cand;             // [MAP_MAX][KC] packed (dist << 16 | idx), ascending
     int *ncand;                 // [MAP_MAX]  (> KC => overflow, slow path)
+    uint32_t *qidx;             // [MAP_MAX]  resolver scratch: the map points that have candidates, in storage order (index | count << 24)
     // staged temporaries
     float *sproj; int8_t *svis; int *smatch; uint32_t *scand; int *sncand; uint8_t *sdel;
     // pnp input

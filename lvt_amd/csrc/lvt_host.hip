@@ -476,6 +476,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
             S.match = c->dalloc<int>(MAP_MAX);
             S.cand = c->dalloc<uint32_t>((size_t)MAP_MAX * KC);
             S.ncand = c->dalloc<int>(MAP_MAX);
+            S.qidx = c->dalloc<uint32_t>(MAP_MAX);
             S.sproj = c->dalloc<float>((size_t)STAGED_MAX * 2);
             S.svis = c->dalloc<int8_t>(STAGED_MAX);
             S.smatch = c->dalloc<int>(STAGED_MAX);
@@ -579,7 +580,7 @@ static void enqueue_frame(Context *c) {
     if (!ext) {
         for (int pass = 0; pass < 2; pass++) {
             LAUNCH(3 + pass, sf, k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, S, pass, par);
-            if (p.big_cell_strips) {  // oversized cells: NMS as row strips on several CUs, then ANMS of the merged survivors
+            if (p.big_cell_strips && pass == 0) {  // (the rare retry pass keeps its single launch: an oversized cell takes the global-memory path there)  // oversized cells: NMS as row strips on several CUs, then ANMS of the merged survivors
                 hipLaunchKernelGGL(k_cells_strip, dim3(p.n_cells * STRIPS, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
                 hipLaunchKernelGGL(k_cells_big, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
                 if (c->prof) (void)hipEventRecord(c->ev[3 + pass][1], sf);  // (the slot's time covers the three launches)

@@ -28,6 +28,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <functional>
 #include <vector>
 
 namespace lvt {
@@ -129,6 +130,9 @@ struct Context {
     // the only dispatch slot while what it waits for cannot start.
     bool events_only = false;
     hipEvent_t ev_feat[NPAR] = {};
+    hipEvent_t ev_depth = nullptr;  // RGB-D host-buffer calls: the depth plane is pulled on the early stream beside the feature kernels; k_gather waits for it
+    bool depth_wait = false;
+    std::function<void()> before_gather;  // host work to run once the detection kernels are enqueued (the RGB-D depth upload)
     // owned staging for the host-buffer entry points, per feature buffer
     uint8_t *d_img[NPAR][2] = {};
     uint8_t *h_stage[NPAR] = {}, *h_stage_dev[NPAR] = {};  // pinned staging of host images (lvt_track): [left | right or depth]
@@ -181,6 +185,7 @@ struct Context {
                 if (x) (void)hipEventDestroy(x);
         for (auto &x : ev_done) if (x) (void)hipEventDestroy(x);
         for (auto &x : ev_feat) if (x) (void)hipEventDestroy(x);
+        if (ev_depth) (void)hipEventDestroy(ev_depth);
         for (auto &x : h_stage) if (x) (void)hipHostFree(x);
         if (h_ctl) (void)hipHostFree(h_ctl);
         if (h_done) (void)hipHostFree(h_done);
@@ -393,6 +398,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         c->own_stream = true;
         for (auto &e : c->ev_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto &e : c->ev_feat) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_depth, hipEventDisableTiming));
         {
             // "events": barrier-only ordering; "polling": the polling gates + early stream; unset: polling for the first live
             // handle of the process, events for the ones created beside it -- the gates of several independent handles share
@@ -586,6 +592,14 @@ static void enqueue_frame(Context *c) {
                 if (c->prof) (void)hipEventRecord(c->ev[3 + pass][1], sf);  // (the slot's time covers the three launches)
             }
         }
+    }
+    if (c->before_gather) {  // (the GPU is busy with k_score / k_cells from here on: host-side copies behind this point are free)
+        c->before_gather();
+        c->before_gather = nullptr;
+    }
+    if (c->depth_wait) {
+        (void)hipStreamWaitEvent(sf, c->ev_depth, 0);
+        c->depth_wait = false;
     }
     LAUNCH(5, sf, k_gather, dim3(1, 2, B), dim3(1024), 0, S, par);
     const bool brief_publishes = !evo && B == 1;  // (single sequence: k_brief's last workgroup publishes feat_seq; see k_feat_done)
@@ -1052,8 +1066,8 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
         std::memcpy(c->h_stage[par], left, nbytes);
         s0 = c->h_stage_dev[par];
     }
-    if (!s1) {
-        std::memcpy(c->h_stage[par] + c->stage_img, second, rgbd ? sizeof(float) * nbytes : nbytes);
+    if (!s1 && !rgbd) {
+        std::memcpy(c->h_stage[par] + c->stage_img, second, nbytes);
         s1 = c->h_stage_dev[par] + c->stage_img;
     }
     drain(c);
@@ -1065,10 +1079,26 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
     f.depth = nullptr;
     f.depth_pitch = 0;
     if (rgbd) {
-        const size_t nv = (sizeof(float) * nbytes + 15) / 16;
-        hipLaunchKernelGGL(k_stage_copy, dim3(256), dim3(256), 0, sf, reinterpret_cast<const uint4 *>(s1), reinterpret_cast<uint4 *>(c->d_depth[par]), nv);
+        // The depth plane (1.2 MB: ~60 us of CPU copy into the staging buffer when the caller's buffer is pageable, ~45 us of PCIe pull)
+        // is not needed before k_gather's depth filter.  Both happen once the detection kernels are enqueued -- the copy on the
+        // host while the GPU runs them, the pull on the early stream (idle until this frame's features exist) beside them -- and
+        // the feature stream waits for the pull in front of k_gather.
         f.depth = c->d_depth[par];
         f.depth_pitch = n_cols;
+        c->before_gather = [c, s1, second, nbytes, par, sf]() {
+            const uint8_t *src = s1;
+            if (!src) {
+                std::memcpy(c->h_stage[par] + c->stage_img, second, sizeof(float) * nbytes);
+                src = c->h_stage_dev[par] + c->stage_img;
+            }
+            const size_t nv = (sizeof(float) * nbytes + 15) / 16;
+            hipStream_t sd = c->events_only ? sf : c->stream_e;
+            hipLaunchKernelGGL(k_stage_copy, dim3(256), dim3(256), 0, sd, reinterpret_cast<const uint4 *>(src), reinterpret_cast<uint4 *>(c->d_depth[par]), nv);
+            if (sd != sf) {
+                (void)hipEventRecord(c->ev_depth, sd);
+                c->depth_wait = true;
+            }
+        };
     }
     f.ext_corners = ext;
     f.n_ext[0] = ncl;

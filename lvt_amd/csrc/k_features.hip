@@ -789,9 +789,14 @@ __device__ __forceinline__ int cell_nms(uint32_t *keys, uint32_t *uf, I *root, I
 
 // second half: LVT's ANMS when the cell is too dense (handler.cpp:140-143, 34-83), else the survivors as they are.  arr = uf[0..n_kp) in
 // raster order; keys / root / abv / nms are scratch of n_cap elements each.
+// `parts`: 1 = std::sort emulation + rank (-> sorted[] in keys), 2 = suppression radii of the key points i_first, i_first + i_stride, ...
+// (sorted[] in keys -> r2[] in uf), 4 = decision radius + emit (sorted[] in keys, r2[] in uf).  7 = the whole thing on one workgroup;
+// the oversized-cell kernels run the parts in three launches, the radii on several workgroups (they are n^2 / 2 distances).
+constexpr int ANMS_SORT = 1, ANMS_RADII = 2, ANMS_SELECT = 4, ANMS_ALL = 7;
 template <typename I>
 __device__ __forceinline__ int cell_anms(const Seq &S, const CellGeom &g, uint32_t *keys, uint32_t *uf, I *root, I *abv, I *nms, int n_kp, int n_cap, int *row_first,
-                                         int *row_end, int *scan, int *misc, float *out, long long *dbg, int n_raw_dbg) {
+                                         int *row_end, int *scan, int *misc, float *out, long long *dbg, int n_raw_dbg, int parts = ANMS_ALL, int i_first = 0,
+                                         int i_stride = 1) {
     constexpr uint32_t NONE = IdxT<I>::NONE, LEFT = IdxT<I>::LEFT, MAXF = IdxT<I>::MAXF;
     (void)NONE, (void)LEFT, (void)MAXF;
     const int tid = threadIdx.x;
@@ -804,6 +809,8 @@ __device__ __forceinline__ int cell_anms(const Seq &S, const CellGeom &g, uint32
     if (n_kp > max_kp) {
         I *posL = root;  // free after NMS
         I *posR = abv;
+        uint32_t *sorted = keys;  // raw keys no longer needed
+        if (parts & ANMS_SORT) {
         // ---- std::__introsort_loop.  The segments of one recursion level are disjoint: the first levels run level by level, one
         // wavefront per segment with a workgroup barrier between levels; as soon as a level holds one segment per wavefront each
         // wavefront finishes its segments depth-first on its own (no more barriers, nobody waits for the level's largest segment).
@@ -868,7 +875,6 @@ __device__ __forceinline__ int cell_anms(const Seq &S, const CellGeom &g, uint32
         // ---- final insertion sort == stable sort by response (descending).  rank = #(greater response) +
         // #(equal response earlier in the array); the second term comes from one wavefront walking the array in
         // 64-element steps with a running 256-bin histogram, equal keys inside a step grouped by 8 ballots.
-        uint32_t *sorted = keys;  // raw keys no longer needed
         int *hist = row_first;    // [256] (row tables are dead)
         int *gtab = row_end;      // [256] #elements with a strictly greater response
         if (wave_id() == 0) {
@@ -918,25 +924,31 @@ __device__ __forceinline__ int cell_anms(const Seq &S, const CellGeom &g, uint32
             sorted[gtab[key_r(k)] + (int)posL[i]] = k;
         }
         __syncthreads();
+        }
         STAMP(7);
+        if (!(parts & (ANMS_RADII | ANMS_SELECT))) return n_kp;
         // ---- suppression radius^2 (integers: exact in the reference's float arithmetic too).  sorted[] is descending, so the points
         // stronger than 1.11 * response are a prefix [0, lo) whose length a binary search finds, and lo never decreases along the
         // array.  One lane per key point; the lanes of a wave walk the prefix TOGETHER (every lane reads the same word: an LDS
         // broadcast), coordinates packed as two 16-bit halves so that a distance is one packed subtract and one dot product.  The
         // phase is VALU-bound on the cell's single CU (n^2 / 2 distances): 3 instructions per distance where the scalar form had 8.
         uint32_t *r2 = arr;  // arr consumed
+        if (parts & ANMS_RADII) {
         uint32_t *sxy = reinterpret_cast<uint32_t *>(root);  // posL (and, with 16-bit indices, the adjacent posR) are dead: x | y << 16
         for (int i = tid; i < n_kp; i += 1024) {
             const uint32_t k = sorted[i];
             sxy[i] = (uint32_t)key_x(k) | ((uint32_t)key_y(k) << 16);
         }
         __syncthreads();
-        // small cells: 2 or 4 lanes share a key point (its prefix in interleaved groups of four), so that all 16 wavefronts have work
+        // this workgroup's key points: i_first + k * i_stride, k = 0 .. n_pts - 1 (all of them when the cell has one workgroup)
+        const int n_pts = (n_kp > i_first) ? (n_kp - i_first + i_stride - 1) / i_stride : 0;
+        // few key points: 2, 4 or 8 lanes share one (its prefix in interleaved groups of four), so that all 16 wavefronts have work
         auto radii = [&](auto lpp_log_c) {
             constexpr int lpp_log = decltype(lpp_log_c)::value, lpp = 1 << lpp_log, ppp = 1024 >> lpp_log, step = 4 * lpp;
-            for (int base = 0; base < n_kp; base += ppp) {
-                const int i = base + (tid >> lpp_log), sub = tid & (lpp - 1);
-                const bool valid = i < n_kp;
+            for (int base = 0; base < n_pts; base += ppp) {
+                const int k = base + (tid >> lpp_log), sub = tid & (lpp - 1);
+                const int i = i_first + k * i_stride;
+                const bool valid = k < n_pts;
                 int lo = 0;
                 if (valid) {
                     const float response = (float)key_r(sorted[i]) * 1.11f;
@@ -948,8 +960,8 @@ __device__ __forceinline__ int cell_anms(const Seq &S, const CellGeom &g, uint32
                     }
                 }
                 const int wave_first = base + ((tid & ~63) >> lpp_log);
-                if (wave_first < n_kp) {  // (wave-uniform)
-                    const int n_valid = min(64 >> lpp_log, n_kp - wave_first);
+                if (wave_first < n_pts) {  // (wave-uniform)
+                    const int n_valid = min(64 >> lpp_log, n_pts - wave_first);
                     const int lo_min = __shfl(lo, 0, 64), lo_max = __shfl(lo, (n_valid << lpp_log) - 1, 64);
                     const s16x2 pi = __builtin_bit_cast(s16x2, sxy[min(i, n_kp - 1)]);
                     uint32_t best = 0xFFFFFFFFu;
@@ -971,14 +983,18 @@ __device__ __forceinline__ int cell_anms(const Seq &S, const CellGeom &g, uint32
                     }
                     if (lpp > 1) best = min(best, (uint32_t)__shfl_xor((int)best, 1, 64));
                     if (lpp > 2) best = min(best, (uint32_t)__shfl_xor((int)best, 2, 64));
+                    if (lpp > 4) best = min(best, (uint32_t)__shfl_xor((int)best, 4, 64));
                     if (valid && sub == 0) r2[i] = best;
                 }
             }
         };
-        if (n_kp <= 512) radii(std::integral_constant<int, 2>{});
-        else if (n_kp <= 1024) radii(std::integral_constant<int, 1>{});
+        if (n_pts <= 128) radii(std::integral_constant<int, 3>{});
+        else if (n_pts <= 512) radii(std::integral_constant<int, 2>{});
+        else if (n_pts <= 1024) radii(std::integral_constant<int, 1>{});
         else radii(std::integral_constant<int, 0>{});
         __syncthreads();
+        }
+        if (!(parts & ANMS_SELECT)) return n_kp;
         STAMP(8);
         // ---- decisionRadius = (max_kp)-th element (0-based) of the radii sorted descending: radix select over
         // three 8-bit digits (finite radii^2 < 2^24; 0xFFFFFFFF stands for sqrt(FLT_MAX))
@@ -1305,9 +1321,68 @@ __global__ __launch_bounds__(1024) void k_cells_big(Seq *seqs, int pass, int par
         __syncthreads();
         long long *dbg = (cell == 0 && eye == 0 && pass == 0) ? S.ctl->dbg : nullptr;  // (phase stamps 5 .. 10: tools/cells_phases.py)
         if (dbg && tid == 0) dbg[5] = clock64();
+        if (total > S.prm.max_kp_cell) {
+            // ANMS in three launches: the sort here, the radii (n^2 / 2 distances: VALU-bound on one CU) on RADII_WGS workgroups, the
+            // selection on one again.  sorted[] travels through strip 0's (now dead) buffer, the radii through strip 1's.
+            cell_anms<uint16_t>(S, g, L.keys, L.uf, L.root16, L.abv16, L.nms16, total, RAW_CAP, L.row_first, L.row_end, L.scan, L.misc, out, dbg, total, ANMS_SORT);
+            uint32_t *gs = S.strip_kp[eye] + (size_t)cell * STRIPS * RAW_CAP;
+            for (int i = tid; i < total; i += 1024) gs[i] = L.keys[i];
+            if (tid == 0) {
+                S.strip_n[eye][cell * STRIPS] = total;
+                S.cell_big[eye][cell] = 2;
+            }
+            if (dbg && tid == 0) dbg[11] = clock64();
+            return;
+        }
         n_out = cell_anms<uint16_t>(S, g, L.keys, L.uf, L.root16, L.abv16, L.nms16, total, RAW_CAP, L.row_first, L.row_end, L.scan, L.misc, out, dbg, total);
         if (dbg && tid == 0) dbg[11] = clock64();
     }
+    cell_finish(FB, eye, cell, pass, n_out);
+}
+
+constexpr int RADII_WGS = 16;
+static_assert(STRIPS >= 2, "the ANMS launches pass sorted[] and r2[] through the first two strip buffers");
+__global__ __launch_bounds__(1024) void k_cells_radii(Seq *seqs, int pass, int par) {
+    Seq &S = seqs[blockIdx.z];
+    const int eye = blockIdx.y, cell = blockIdx.x / RADII_WGS, wg = blockIdx.x % RADII_WGS;
+    FrameBuf &FB = S.fb[par];
+    CellGeom g;
+    int cxi;
+    if (!cell_begin(S, FB, eye, cell, pass, g, cxi)) return;
+    if (S.cell_big[eye][cell] != 2) return;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const CellLds L = carve_cell_lds(smem);
+    const int tid = threadIdx.x;
+    const int n = S.strip_n[eye][cell * STRIPS];
+    const uint32_t *gs = S.strip_kp[eye] + (size_t)cell * STRIPS * RAW_CAP;
+    uint32_t *gr = S.strip_kp[eye] + ((size_t)cell * STRIPS + 1) * RAW_CAP;
+    for (int i = tid; i < n; i += 1024) L.keys[i] = gs[i];
+    __syncthreads();
+    cell_anms<uint16_t>(S, g, L.keys, L.uf, L.root16, L.abv16, L.nms16, n, RAW_CAP, L.row_first, L.row_end, L.scan, L.misc, nullptr, nullptr, n, ANMS_RADII, wg, RADII_WGS);
+    for (int i = wg + tid * RADII_WGS; i < n; i += 1024 * RADII_WGS) gr[i] = L.uf[i];
+}
+
+__global__ __launch_bounds__(1024) void k_cells_select(Seq *seqs, int pass, int par) {
+    Seq &S = seqs[blockIdx.z];
+    const int eye = blockIdx.y, cell = blockIdx.x;
+    FrameBuf &FB = S.fb[par];
+    CellGeom g;
+    int cxi;
+    if (!cell_begin(S, FB, eye, cell, pass, g, cxi)) return;
+    if (S.cell_big[eye][cell] != 2) return;
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const CellLds L = carve_cell_lds(smem);
+    const int tid = threadIdx.x;
+    const int n = S.strip_n[eye][cell * STRIPS];
+    const uint32_t *gs = S.strip_kp[eye] + (size_t)cell * STRIPS * RAW_CAP;
+    const uint32_t *gr = S.strip_kp[eye] + ((size_t)cell * STRIPS + 1) * RAW_CAP;
+    for (int i = tid; i < n; i += 1024) {
+        L.keys[i] = gs[i];
+        L.uf[i] = gr[i];
+    }
+    __syncthreads();
+    float *out = FB.cell_kp[eye] + (size_t)cell * CELL_OUT_CAP * 3;
+    const int n_out = cell_anms<uint16_t>(S, g, L.keys, L.uf, L.root16, L.abv16, L.nms16, n, RAW_CAP, L.row_first, L.row_end, L.scan, L.misc, out, nullptr, n, ANMS_SELECT);
     cell_finish(FB, eye, cell, pass, n_out);
 }
 

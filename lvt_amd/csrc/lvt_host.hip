@@ -510,6 +510,8 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hamming_batched_lists<MODE_ROW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_strip), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_big), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_radii), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_select), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pnp<true>), hipFuncAttributeMaxDynamicSharedMemorySize, PNP_DYN_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pnp<false>), hipFuncAttributeMaxDynamicSharedMemorySize, PNP_DYN_BYTES));
         reset_state(c);
@@ -589,7 +591,9 @@ static void enqueue_frame(Context *c) {
             if (p.big_cell_strips && pass == 0) {  // (the rare retry pass keeps its single launch: an oversized cell takes the global-memory path there)  // oversized cells: NMS as row strips on several CUs, then ANMS of the merged survivors
                 hipLaunchKernelGGL(k_cells_strip, dim3(p.n_cells * STRIPS, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
                 hipLaunchKernelGGL(k_cells_big, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
-                if (c->prof) (void)hipEventRecord(c->ev[3 + pass][1], sf);  // (the slot's time covers the three launches)
+                hipLaunchKernelGGL(k_cells_radii, dim3(p.n_cells * RADII_WGS, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
+                hipLaunchKernelGGL(k_cells_select, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
+                if (c->prof) (void)hipEventRecord(c->ev[3 + pass][1], sf);  // (the slot's time covers the five launches)
             }
         }
     }

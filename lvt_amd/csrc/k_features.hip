@@ -1175,18 +1175,13 @@ __device__ __forceinline__ int cell_global_path(const Seq &S, const FrameBuf &FB
                                    dbg);
 }
 
-__global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass, int par) {
-    Seq &S = seqs[blockIdx.z];
-    const int eye = blockIdx.y, cell = blockIdx.x;
-    FrameBuf &FB = S.fb[par];
+// one detection cell of one image: AGAST NMS + LVT's ANMS (or the hand-over of an oversized cell to the strip kernels)
+__device__ __forceinline__ void cells_work(Seq &S, FrameBuf &FB, int eye, int cell, int pass, const CellLds &L) {
     FeatCtl &ctl = *FB.fc;
     const int tid = threadIdx.x;
-    if (tid == 0 && cell < CELLS_MAX) S.cell_big[eye][cell] = 0;  // (nobody reads it before this launch is over)
     CellGeom g;
     int cxi;
     if (!cell_begin(S, FB, eye, cell, pass, g, cxi)) return;
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const CellLds L = carve_cell_lds(smem);
     const int cs = S.prm.cell_size;
     float *out = FB.cell_kp[eye] + (size_t)cell * CELL_OUT_CAP * 3;
 
@@ -1205,7 +1200,7 @@ __global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass, int par) {
             n_out = cell_nms_anms<uint16_t>(S, g, L.keys, L.uf, L.root16, L.abv16, L.nms16, L.tie8, n_raw, RAW_CAP, L.row_first, L.row_end, L.scan, L.stack, L.misc, out, dbg);
         } else if (S.prm.big_cell_strips && pass == 0) {
             // more raw corners than this workgroup's LDS holds, in a cell tall enough to cut: k_cells_strip (NMS of row strips on several
-            // CUs) and k_cells_big (ANMS of the merged survivors) take over; they also write cell_n / n_detected
+            // CUs) and the kernels behind it take over; they also write cell_n / n_detected
             if (tid == 0) S.cell_big[eye][cell] = 1;
             return;
         } else {
@@ -1214,6 +1209,17 @@ __global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass, int par) {
     }
     if (dbg && tid == 0) dbg[11] = clock64();
     cell_finish(FB, eye, cell, pass, n_out);
+}
+
+// pass 0 of the detection (the <200-corner retry, handler.cpp:161-169, runs inside k_gather)
+__global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass, int par) {
+    Seq &S = seqs[blockIdx.z];
+    const int eye = blockIdx.y, cell = blockIdx.x;
+    FrameBuf &FB = S.fb[par];
+    if (threadIdx.x == 0 && cell < CELLS_MAX) S.cell_big[eye][cell] = 0;  // (nobody reads it before this launch is over)
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const CellLds L = carve_cell_lds(smem);
+    cells_work(S, FB, eye, cell, pass, L);
 }
 
 // ---- an oversized cell as row strips --------------------------------------------------------------------------------------------
@@ -1401,11 +1407,25 @@ __global__ __launch_bounds__(1024) void k_gather(Seq *seqs, int par) {
     const int eye = blockIdx.y;
     FrameBuf &FB = S.fb[par];
     FeatCtl &ctl = *FB.fc;
-    __shared__ int cell_off[CELLS_MAX + 1];
-    __shared__ int scan[32];
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    const CellLds L = carve_cell_lds(smem);
+    int *cell_off = L.row_first;  // [CELLS_MAX + 1]
+    int *scan = L.scan;
     const int tid = threadIdx.x;
     Feat &F = FB.feat[eye];
     if (ctl.poison) return;
+    // handler.cpp:161-169: fewer than 200 corners in the whole image -> every cell again with the lowered threshold.  Almost never
+    // taken, so it has no launch of its own (that launch cost every frame 6.5 us of its longest chain): this workgroup runs the
+    // image's cells one after the other, then gathers.
+    if (!ctl.ext_corners && !(eye == 1 && S.prm.sensor == 2) && ctl.n_detected[eye] < CORNERS_LOW_TH) {
+        for (int cell = 0; cell < S.prm.n_cells; cell++) {
+            cells_work(S, FB, eye, cell, 1, L);
+            __syncthreads();
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __syncthreads();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    }
     if (eye == 1 && S.prm.sensor == 2) {
         if (tid == 0) *F.n = 0;
         return;

@@ -509,6 +509,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hamming_batched_lists<MODE_ROW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hamming_batched_lists<MODE_ROW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_strip), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gather), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_big), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_radii), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_select), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
@@ -524,7 +525,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
 
 // ---- the per-frame launch chain -------------------------------------------------------------------
 static const char *kProfNames[Context::PROF_SLOTS] = {
-    "k_feat_begin", "k_gate [early stream: waits for the previous k_pnp]", "k_score", "k_cells(pass0)", "k_cells(retry)", "k_gather", "k_brief", "k_gate_late [waits for the early stream]",
+    "k_feat_begin", "k_gate [early stream: waits for the previous k_pnp]", "k_score", "k_cells(pass0)", "", "k_gather(+ the rare retry pass)", "k_brief", "k_gate_late [waits for the early stream]",
     "k_match_map(wait for the early stream + begin + new points)", "k_early_map [early stream]", "k_early_mid [early stream]", "k_hamming_batched_lists(map) [early stream]", "k_track_mid(resolve+pass2+bookkeep+cull)", "k_pnp(+project staged)", "",
     "", "k_candidates(staged)", "", "k_candidates(row) [early stream]", "k_hamming_batched_lists(row)", "k_triangulate(staged update+row resolve+triangulate+finalize)", "",
     "", ""};
@@ -586,14 +587,15 @@ static void enqueue_frame(Context *c) {
         LAUNCH(2, sf, k_score<false>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2 * B), dim3(256), 0, S, FrameArgs{}, par);
     }
     if (!ext) {
-        for (int pass = 0; pass < 2; pass++) {
-            LAUNCH(3 + pass, sf, k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, S, pass, par);
-            if (p.big_cell_strips && pass == 0) {  // (the rare retry pass keeps its single launch: an oversized cell takes the global-memory path there)  // oversized cells: NMS as row strips on several CUs, then ANMS of the merged survivors
+        {
+            const int pass = 0;  // (the <200-corner retry pass runs inside k_gather: it is almost never taken)
+            LAUNCH(3, sf, k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, S, pass, par);
+            if (p.big_cell_strips) {  // oversized cells: NMS as row strips on several CUs, then ANMS of the merged survivors in three launches
                 hipLaunchKernelGGL(k_cells_strip, dim3(p.n_cells * STRIPS, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
                 hipLaunchKernelGGL(k_cells_big, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
                 hipLaunchKernelGGL(k_cells_radii, dim3(p.n_cells * RADII_WGS, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
                 hipLaunchKernelGGL(k_cells_select, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
-                if (c->prof) (void)hipEventRecord(c->ev[3 + pass][1], sf);  // (the slot's time covers the five launches)
+                if (c->prof) (void)hipEventRecord(c->ev[3][1], sf);  // (the slot's time covers the five launches)
             }
         }
     }
@@ -605,7 +607,7 @@ static void enqueue_frame(Context *c) {
         (void)hipStreamWaitEvent(sf, c->ev_depth, 0);
         c->depth_wait = false;
     }
-    LAUNCH(5, sf, k_gather, dim3(1, 2, B), dim3(1024), 0, S, par);
+    LAUNCH(5, sf, k_gather, dim3(1, 2, B), dim3(1024), CELLS_LDS_BYTES, S, par);
     const bool brief_publishes = !evo && B == 1;  // (single sequence: k_brief's last workgroup publishes feat_seq; see k_feat_done)
     LAUNCH(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, S, par, brief_publishes ? (seq_t)(c->enq + 1) : (seq_t)0);
     if (!evo && !brief_publishes) hipLaunchKernelGGL(k_feat_done, dim3(B), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));

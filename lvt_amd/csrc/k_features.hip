@@ -1152,7 +1152,7 @@ __device__ __forceinline__ bool cell_begin(const Seq &S, const FrameBuf &FB, int
     g.pp = S.plane_pitch;
     return true;
 }
-__device__ __forceinline__ void cell_finish(FrameBuf &FB, int eye, int cell, int pass, int n_out) {
+__device__ __forceinline__ void cell_finish(const FrameBuf &FB, int eye, int cell, int pass, int n_out) {
     FeatCtl &ctl = *FB.fc;
     if (threadIdx.x == 0) {
         if (n_out > CELL_OUT_CAP) {
@@ -1176,7 +1176,7 @@ __device__ __forceinline__ int cell_global_path(const Seq &S, const FrameBuf &FB
 }
 
 // one detection cell of one image: AGAST NMS + LVT's ANMS (or the hand-over of an oversized cell to the strip kernels)
-__device__ __forceinline__ void cells_work(Seq &S, FrameBuf &FB, int eye, int cell, int pass, const CellLds &L) {
+__device__ __forceinline__ void cells_work(const Seq &S, const FrameBuf &FB, int eye, int cell, int pass, const CellLds &L) {
     FeatCtl &ctl = *FB.fc;
     const int tid = threadIdx.x;
     CellGeom g;
@@ -1212,10 +1212,11 @@ __device__ __forceinline__ void cells_work(Seq &S, FrameBuf &FB, int eye, int ce
 }
 
 // pass 0 of the detection (the <200-corner retry, handler.cpp:161-169, runs inside k_gather)
-__global__ __launch_bounds__(1024) void k_cells(Seq *seqs, int pass, int par) {
-    Seq &S = seqs[blockIdx.z];
+template <bool BV>  // (a single sequence's descriptor travels in the kernel arguments: one dependent memory hop less at the head of the longest kernel)
+__global__ __launch_bounds__(1024) void k_cells(SeqArg<BV> sa, int pass, int par) {
+    const Seq &S = sa.get();
     const int eye = blockIdx.y, cell = blockIdx.x;
-    FrameBuf &FB = S.fb[par];
+    const FrameBuf &FB = S.fb[par];
     if (threadIdx.x == 0 && cell < CELLS_MAX) S.cell_big[eye][cell] = 0;  // (nobody reads it before this launch is over)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const CellLds L = carve_cell_lds(smem);
@@ -1402,17 +1403,21 @@ __device__ __forceinline__ bool brief_border_keep(float x, float y, int rows, in
     return ix >= B && ix < cols - B && iy >= B && iy < rows - B;
 }
 
-__global__ __launch_bounds__(1024) void k_gather(Seq *seqs, int par) {
-    Seq &S = seqs[blockIdx.z];
+// (`seqs` = the descriptors in device memory: the per-frame inputs -- image / depth pointers and pitches -- are published there by the
+//  head of the feature stage and are NOT part of a descriptor that travels by value)
+template <bool BV>
+__global__ __launch_bounds__(1024) void k_gather(SeqArg<BV> sa, const Seq *seqs, int par) {
+    const Seq &S = sa.get();
     const int eye = blockIdx.y;
-    FrameBuf &FB = S.fb[par];
+    const FrameBuf &FB = S.fb[par];
+    const FrameBuf &FBd = seqs[blockIdx.z].fb[par];
     FeatCtl &ctl = *FB.fc;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const CellLds L = carve_cell_lds(smem);
     int *cell_off = L.row_first;  // [CELLS_MAX + 1]
     int *scan = L.scan;
     const int tid = threadIdx.x;
-    Feat &F = FB.feat[eye];
+    const Feat &F = FB.feat[eye];
     if (ctl.poison) return;
     // handler.cpp:161-169: fewer than 200 corners in the whole image -> every cell again with the lowered threshold.  Almost never
     // taken, so it has no launch of its own (that launch cost every frame 6.5 us of its longest chain): this workgroup runs the
@@ -1464,7 +1469,7 @@ __global__ __launch_bounds__(1024) void k_gather(Seq *seqs, int par) {
             oy = y;
             keep = brief_border_keep(x, y, H, W);
             if (keep && rgbd) {  // handler.cpp:255-265 (depth at the distorted pixel), :268-294
-                dep = FB.depth_img[(size_t)((int)y) * FB.depth_pitch + (int)x];
+                dep = FBd.depth_img[(size_t)((int)y) * FBd.depth_pitch + (int)x];
                 keep = (dep >= S.prm.near_plane && dep <= S.prm.far_plane);
                 if (keep && S.prm.undistort) {
                     undistort_point(S.prm, x, y, x, y);
@@ -1500,13 +1505,13 @@ __global__ __launch_bounds__(1024) void k_gather(Seq *seqs, int par) {
 // =================================================================================================
 // k_brief : one wavefront per key point, lane l evaluates tests 4l..4l+3
 // =================================================================================================
-__device__ __forceinline__ int box_at(const Seq &S, const FrameBuf &FB, int eye, int iy, int ix) {
+__device__ __forceinline__ int box_at(const Seq &S, const FrameBuf &FB, const FrameBuf &FBd, int eye, int iy, int ix) {
     const int W = S.prm.W, H = S.prm.H;
     if (ix >= 0 && ix < W && iy >= 0 && iy < H) return FB.boxsum[eye][(size_t)iy * S.plane_pitch + ix];
     // centre outside the image (fractional external corners at the border only): clipped window
     int s = 0;
     for (int y = max(iy - 4, 0); y <= min(iy + 4, H - 1); y++)
-        for (int x = max(ix - 4, 0); x <= min(ix + 4, W - 1); x++) s += FB.img[eye][(size_t)y * FB.img_pitch + x];
+        for (int x = max(ix - 4, 0); x <= min(ix + 4, W - 1); x++) s += FBd.img[eye][(size_t)y * FBd.img_pitch + x];
     return s;
 }
 
@@ -1521,7 +1526,8 @@ __device__ __forceinline__ int box_at(const Seq &S, const FrameBuf &FB, int eye,
 constexpr int BR_R = 24, BR_ROWS = 2 * BR_R + 1, BR_DW = 25;      // window rows; dwords per window row (49 u16 columns + 1 for an odd start)
 static_assert(brief_max_offset() <= BR_R, "k_brief's window does not cover the test pattern");
 constexpr int BR_WIN_DW = BR_ROWS * BR_DW, BR_LOADS = (BR_WIN_DW + 63) / 64;
-__global__ __launch_bounds__(256) void k_brief(Seq *seqs, int par, seq_t publish_seq) {
+template <bool BV>
+__global__ __launch_bounds__(256) void k_brief(SeqArg<BV> sa, const Seq *seqs, int par, seq_t publish_seq) {
     // workgroups go to the 8 XCDs round-robin by their linear id, and every XCD has its own L2: with the plain mapping each L2 sees the
     // box-sum planes of ALL sequences (30 MB for a batch of 16) and every window comes from the Infinity Cache.  When the number of planes
     // is a multiple of 8, XCD x takes planes x, x + 8, ... whole, so a plane is pulled into ONE L2, once.
@@ -1533,10 +1539,11 @@ __global__ __launch_bounds__(256) void k_brief(Seq *seqs, int par, seq_t publish
         plane = (lid & 7) + 8 * (j / gridDim.x);
         bx = j % gridDim.x;
     }
-    Seq &S = seqs[plane / gridDim.y];
+    const Seq &S = BV ? sa.get() : seqs[plane / gridDim.y];  // (sa.get() indexes by blockIdx.z: the batch form picks its plane's sequence itself)
+    const FrameBuf &FBd = seqs[plane / gridDim.y].fb[par];  // per-frame image pointers (border fall-back only)
     const int eye = plane % gridDim.y;
-    FrameBuf &FB = S.fb[par];
-    Feat &F = FB.feat[eye];
+    const FrameBuf &FB = S.fb[par];
+    const Feat &F = FB.feat[eye];
     const bool poison = FB.fc->poison != 0;  // (block-uniform; reset by the publishing workgroup below, after every workgroup has read it)
     const int n = poison ? 0 : *F.n;
     const int lane = lane_id();
@@ -1607,8 +1614,8 @@ __global__ __launch_bounds__(256) void k_brief(Seq *seqs, int par, seq_t publish
             if (nfast) fetch(ncy, ncx);
 #pragma unroll
             for (int w = 0; w < 4; w++) {
-                const int a = box_at(S, FB, eye, cy + tq[w][0], cx + tq[w][1]);
-                const int b = box_at(S, FB, eye, cy + tq[w][2], cx + tq[w][3]);
+                const int a = box_at(S, FB, FBd, eye, cy + tq[w][0], cx + tq[w][1]);
+                const int b = box_at(S, FB, FBd, eye, cy + tq[w][2], cx + tq[w][3]);
                 word[w] = __ballot(a < b);
             }
         }

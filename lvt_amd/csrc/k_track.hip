@@ -25,23 +25,6 @@ namespace lvt {
 
 enum : int { MODE_MAP = 0, MODE_STAGED = 1, MODE_ROW = 2 };
 
-// A sequence's descriptor reaches the kernels of the early and tracking chains either BY VALUE (single sequence: its fields are
-// kernel arguments, fetched with the kernel's own argument load) or as an element of the device array (lock-step batch: one more
-// dependent memory hop at every kernel head).  These kernels never read the per-frame mutable fields of Seq (FrameBuf::img ...),
-// which only the feature stage writes and reads.
-template <bool BYVAL>
-struct SeqArg;
-template <>
-struct SeqArg<false> {
-    const Seq *p;
-    __device__ __forceinline__ const Seq &get() const { return p[blockIdx.z]; }
-};
-template <>
-struct SeqArg<true> {
-    Seq v;
-    __device__ __forceinline__ const Seq &get() const { return v; }
-};
-
 // =================================================================================================
 // frame prologue (the head of lvt_system::track, lvt_system.cpp:157-167,196-197), evaluated by k_match_map.  The motion
 // model's next state goes to a shadow (mm_next) committed by k_track_mid.

@@ -241,4 +241,22 @@ __device__ __forceinline__ int block_excl_scan(int v, int *scratch, int *total) 
     return base + incl - v;
 }
 
+// A sequence's descriptor reaches the kernels of the early and tracking chains (and k_cells, which touches the feature stage's fixed buffers only) either BY VALUE (single sequence: its fields are
+// kernel arguments, fetched with the kernel's own argument load) or as an element of the device array (lock-step batch: one more
+// dependent memory hop at every kernel head).  These kernels never read the per-frame mutable fields of Seq (FrameBuf::img ...),
+// which only the feature stage writes and reads.
+template <bool BYVAL>
+struct SeqArg;
+template <>
+struct SeqArg<false> {
+    const Seq *p;
+    __device__ __forceinline__ const Seq &get() const { return p[blockIdx.z]; }
+};
+template <>
+struct SeqArg<true> {
+    Seq v;
+    __device__ __forceinline__ const Seq &get() const { return v; }
+};
+
+
 }  // namespace lvt

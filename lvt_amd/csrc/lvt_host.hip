@@ -502,14 +502,15 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         }
         c->d_seqs = c->dalloc<Seq>(B);
         HIPCHK(c, hipMemcpy(c->d_seqs, c->h_seqs.data(), sizeof(Seq) * B, hipMemcpyHostToDevice));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                      CELLS_LDS_BYTES));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hamming_batched_lists<MODE_MAP, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hamming_batched_lists<MODE_MAP, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hamming_batched_lists<MODE_ROW, true>), hipFuncAttributeMaxDynamicSharedMemorySize, LS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_hamming_batched_lists<MODE_ROW, false>), hipFuncAttributeMaxDynamicSharedMemorySize, LS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_strip), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
-        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gather), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gather<true>), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
+        HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_gather<false>), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_big), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_radii), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
         HIPCHK(c, hipFuncSetAttribute(reinterpret_cast<const void *>(&k_cells_select), hipFuncAttributeMaxDynamicSharedMemorySize, CELLS_LDS_BYTES));
@@ -589,7 +590,7 @@ static void enqueue_frame(Context *c) {
     if (!ext) {
         {
             const int pass = 0;  // (the <200-corner retry pass runs inside k_gather: it is almost never taken)
-            LAUNCH(3, sf, k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, S, pass, par);
+            LAUNCH_S(3, sf, k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, pass, par);
             if (p.big_cell_strips) {  // oversized cells: NMS as row strips on several CUs, then ANMS of the merged survivors in three launches
                 hipLaunchKernelGGL(k_cells_strip, dim3(p.n_cells * STRIPS, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
                 hipLaunchKernelGGL(k_cells_big, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
@@ -607,9 +608,9 @@ static void enqueue_frame(Context *c) {
         (void)hipStreamWaitEvent(sf, c->ev_depth, 0);
         c->depth_wait = false;
     }
-    LAUNCH(5, sf, k_gather, dim3(1, 2, B), dim3(1024), CELLS_LDS_BYTES, S, par);
+    LAUNCH_S(5, sf, k_gather, dim3(1, 2, B), dim3(1024), CELLS_LDS_BYTES, (const Seq *)S, par);
     const bool brief_publishes = !evo && B == 1;  // (single sequence: k_brief's last workgroup publishes feat_seq; see k_feat_done)
-    LAUNCH(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, S, par, brief_publishes ? (seq_t)(c->enq + 1) : (seq_t)0);
+    LAUNCH_S(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, (const Seq *)S, par, brief_publishes ? (seq_t)(c->enq + 1) : (seq_t)0);
     if (!evo && !brief_publishes) hipLaunchKernelGGL(k_feat_done, dim3(B), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));
     const int bl = c->binned_lists ? 1 : 0;
     if (evo && bl && c->sensor == 1) LAUNCH_SM(19, sf, k_hamming_batched_lists, MODE_ROW, dim3(2, 1, B), dim3(LS_THREADS), LS_LDS_BYTES, par, (seq_t)0);

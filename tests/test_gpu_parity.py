@@ -422,6 +422,25 @@ def test_pinned_host_buffers_are_read_in_place(hip_lib):
     assert a.counts() == b.counts() and b.last_error() == ""
 
 
+def test_rgbd_depth_upload_beside_detection(hip_lib):
+    """lvt_amd_track_rgbd copies and pulls the depth image only once the detection kernels are enqueued (k_gather is the first to need it):
+    pageable buffers (host copy into the staging buffer) and page-locked ones (read in place) must give the poses and maps of each other,
+    frame after frame, with a fresh depth image every call"""
+    import torch
+    world, prm, sensor = make_case("tum", 3, 1.0)
+    a = hip_lib.LvtSystem.create(prm, 2); b = hip_lib.LvtSystem.create(prm, 2)
+    for i in range(6):
+        g, d = world.render_rgbd(i)
+        d = np.ascontiguousarray(d, dtype=np.float32)
+        gp, dp = torch.from_numpy(g).pin_memory().numpy(), torch.from_numpy(d).pin_memory().numpy()
+        Ra, ta = a.track(g, d)
+        Rb, tb = b.track(gp, dp)
+        assert np.array_equal(ta, tb) and np.array_equal(Ra, Rb), f"frame {i}"
+        assert a.counts() == b.counts(), f"frame {i}"
+    assert a.get_state() == 2 and a.last_error() == "" and b.last_error() == ""
+    assert a.counts()["map_size"] > 1000  # (the depth filter saw real depths: every kept feature became a map point)
+
+
 def test_featureless_and_saturated_frames(hip_lib, oracle_lib):
     """degenerate inputs through the whole chain, stage by stage against the oracle: a black first frame (no corner, empty map,
     the <200-corner retry on both eyes) followed by a saturated one (no match -> LOST) and one with a single bright pixel (LOST:

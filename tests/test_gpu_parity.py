@@ -105,6 +105,30 @@ def test_external_corners(hip_lib, oracle_lib):
         assert np.allclose(th, to, atol=1e-6) and np.allclose(Rh, Ro, atol=1e-6)
 
 
+def test_candidate_lists_longer_than_their_capacity(hip_lib, oracle_lib):
+    """a 28 x 28 block of corners at 1-px spacing (through the external-corner entry point) puts several hundred features inside the
+    search window of the map points that project there and 140 into every 5-row band of row_match: candidate lists overflow their
+    128 slots, and the resolvers must take their exact wave-wide path for those queries -- in map order, between ordinary super-chunks"""
+    from oracle import pyoracle as O
+    world, prm, sensor = make_case("kitti", 11, 0.5)
+    hip = hip_lib.LvtSystem.create(prm, 1)
+    orc = O.Oracle(prm, 1)
+    gx, gy = np.meshgrid(np.arange(28, dtype=np.float64), np.arange(28, dtype=np.float64))
+    block = np.stack([gx.ravel() + world.W // 2 - 14, gy.ravel() + world.H // 2 - 14], axis=1)
+    for i in range(4):
+        a, b = world.render_stereo(i)
+        xl, _, _, _ = O.compute_features(a, prm)
+        xr, _, _, _ = O.compute_features(b, prm)
+        cl = np.vstack([xl.astype(np.float64), block]); cr = np.vstack([xr.astype(np.float64), block + [[-6.0, 0.0]]])
+        Ro, to = orc.track_with_external_corners(a, b, cl, cr)
+        Rh, th = hip.track_with_external_corners(a, b, cl, cr)
+        msgs = diff_frame(hip, orc)
+        assert not msgs, f"frame {i}: {msgs[:5]}"
+        assert np.allclose(th, to, atol=1e-6) and np.allclose(Rh, Ro, atol=1e-6)
+    assert hip.counts()["n_left"] > 784 and hip.get_state() == orc.status
+    assert hip.debug_stamps()[25] > 0, "no map point took the resolver's exact path for over-long lists (bring-up counter of k_early_mid)"
+
+
 def test_create_from_yaml_matches_struct_create(hip_lib, oracle_lib, tmp_path):
     """lvt_create(config.yaml) (lvt_c.cpp:33-48) == lvt_system::create(params): same poses, missing keys read as 0"""
     world, prm, sensor = make_case("kitti", 9, 0.5)

@@ -129,6 +129,22 @@ def test_candidate_lists_longer_than_their_capacity(hip_lib, oracle_lib):
     assert hip.debug_stamps()[25] > 0, "no map point took the resolver's exact path for over-long lists (bring-up counter of k_early_mid)"
 
 
+def test_more_features_than_capacity_is_reported(hip_lib):
+    """4 900 external corners survive the border filter, the feature arrays hold 4 096: the frame is tracked on the first 4 096 and the cut
+    is reported through lvt_amd_last_error (the reference has no such limit: include/lvt_c.h, "capacities") -- never silently"""
+    world, prm, sensor = make_case("kitti", 12, 1.0)
+    hip = hip_lib.LvtSystem.create(prm, 1)
+    gx, gy = np.meshgrid(np.arange(70, dtype=np.float64) * 3 + 40, np.arange(70, dtype=np.float64) * 3 + 40)
+    grid = np.stack([gx.ravel(), gy.ravel()], axis=1)
+    a, b = world.render_stereo(0)
+    hip.track_with_external_corners(a, b, grid, grid)
+    c = hip.counts()
+    assert c["n_left"] == 4096 and c["n_right"] == 4096 and c["overflow"] != 0
+    assert "capacity overflow" in hip.last_error()
+    hip.track_with_external_corners(a, b, grid[:500], grid[:500])      # the handle keeps working
+    assert hip.counts()["n_left"] == 500 and hip.counts()["overflow"] == 0
+
+
 def test_create_from_yaml_matches_struct_create(hip_lib, oracle_lib, tmp_path):
     """lvt_create(config.yaml) (lvt_c.cpp:33-48) == lvt_system::create(params): same poses, missing keys read as 0"""
     world, prm, sensor = make_case("kitti", 9, 0.5)

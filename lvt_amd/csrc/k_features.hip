@@ -1316,9 +1316,12 @@ __global__ __launch_bounds__(1024) void k_cells_big(Seq *seqs, int pass, int par
         total += max(n, 0);
     }
     int n_out;
+    long long *route = (cell == 0 && eye == 0 && pass == 0 && tid == 0) ? S.ctl->dbg + 10 : nullptr;  // (tests: which way the cell went)
     if (bad || total > RAW_CAP) {
+        if (route) *route = 1003;  // a strip could not vouch or overflowed: the whole cell on one workgroup
         n_out = cell_global_path(S, FB, eye, cell, cxi, (pass == 0) && (S.prm.cell_size >= TS_W), g, L, out, nullptr);
     } else {
+        if (route) *route = (total > S.prm.max_kp_cell) ? 1001 : 1002;  // strips + three-launch ANMS / strips, no ANMS needed
         int off = 0;
         for (int s = 0; s < STRIPS; s++) {
             const uint32_t *src = S.strip_kp[eye] + ((size_t)cell * STRIPS + s) * RAW_CAP;

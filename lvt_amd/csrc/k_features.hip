@@ -875,16 +875,30 @@ __device__ __forceinline__ int cell_anms(const Seq &S, const CellGeom &g, uint32
         // ---- final insertion sort == stable sort by response (descending).  rank = #(greater response) +
         // #(equal response earlier in the array); the second term comes from one wavefront walking the array in
         // 64-element steps with a running 256-bin histogram, equal keys inside a step grouped by 8 ballots.
+        // More than 512 key points: every wavefront walks ITS block of the array with a histogram of its own (in the dead nms[] area), the
+        // blocks' counts are prefix-summed per key afterwards -- the single-wavefront walk over 1 650 key points took 17k cycles.
         int *hist = row_first;    // [256] (row tables are dead)
         int *gtab = row_end;      // [256] #elements with a strictly greater response
-        if (wave_id() == 0) {
+        const int nwv = blockDim.x >> 6;
+        const bool par_rank = n_kp > 512;
+        const int blk = par_rank ? (((n_kp + nwv - 1) / nwv + 63) & ~63) : n_kp;  // elements per wavefront (a multiple of 64)
+        int *hw = par_rank ? reinterpret_cast<int *>(nms) : hist;                  // [nwv][256] | [256]
+        if (par_rank) {
+            for (int k = tid; k < nwv * 256; k += 1024) hw[k] = 0;
+            __syncthreads();
+        }
+        if (par_rank || wave_id() == 0) {
             const int lane = lane_id();
             const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
-            for (int k = lane; k < 256; k += 64) hist[k] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
-            for (int base = 0; base < n_kp; base += 64) {
+            int *myh = par_rank ? hw + 256 * wave_id() : hist;
+            if (!par_rank) {
+                for (int k = lane; k < 256; k += 64) hist[k] = 0;
+                __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+            }
+            const int b_lo = par_rank ? wave_id() * blk : 0, b_hi = min(n_kp, b_lo + blk);
+            for (int base = b_lo; base < b_hi; base += 64) {
                 const int i = base + lane;
-                const bool valid = i < n_kp;
+                const bool valid = i < b_hi;
                 const int key = valid ? key_r(arr[i]) : 0;
                 uint64_t m = __ballot(valid);
 #pragma unroll
@@ -893,12 +907,28 @@ __device__ __forceinline__ int cell_anms(const Seq &S, const CellGeom &g, uint32
                     m &= ((key >> b) & 1) ? bb : ~bb;
                 }
                 if (valid) {
-                    const int hb = hist[key];
+                    const int hb = myh[key];
                     posL[i] = (I)(hb + __popcll(m & lt_mask));
-                    if ((m & lt_mask) == 0ull) hist[key] = hb + __popcll(m);  // group leader
+                    if ((m & lt_mask) == 0ull) myh[key] = hb + __popcll(m);  // group leader
                 }
                 __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
             }
+        }
+        if (par_rank) {  // per key: the blocks' counts -> exclusive prefix over the blocks (in place), total -> hist
+            __syncthreads();
+            if (tid < 256) {
+                int run = 0;
+                for (int w = 0; w < nwv; w++) {
+                    const int t = hw[256 * w + tid];
+                    hw[256 * w + tid] = run;
+                    run += t;
+                }
+                hist[tid] = run;
+            }
+            __syncthreads();
+        }
+        if (wave_id() == 0) {
+            const int lane = lane_id();
             // suffix sums: gtab[k] = sum_{k' > k} hist[k']
             int h[4], tot = 0;
 #pragma unroll
@@ -921,7 +951,8 @@ __device__ __forceinline__ int cell_anms(const Seq &S, const CellGeom &g, uint32
         __syncthreads();
         for (int i = tid; i < n_kp; i += 1024) {
             const uint32_t k = arr[i];
-            sorted[gtab[key_r(k)] + (int)posL[i]] = k;
+            const int kr = key_r(k);
+            sorted[gtab[kr] + (par_rank ? hw[256 * (i / blk) + kr] : 0) + (int)posL[i]] = k;
         }
         __syncthreads();
         }

@@ -2,7 +2,8 @@
 """bench.py -- stereo frames/sec of the MI355X-native LVT tracking path on KITTI-shaped input.
 
 Contract (driver): `python bench.py --gpus N --steps K --warmup W`; for N > 1 it is launched as
-`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU).
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...` (one rank per GPU) -- and a plain
+`python bench.py --gpus N` starts those N ranks itself (same launcher module, 127.0.0.1, a free port) and passes rank 0's line on.
 A "step" is one pass of the hot path over one stereo pair of a synthetic KITTI-00-shaped sequence (1241x376,
 BASELINE.json configs[1]): `lvt_amd_track_device_async` on a frame resident in HBM, its pose collected with
 `lvt_amd_wait_status` (at most --depth frames in flight).  Independent sequences (seed = rank) shard one per GPU, there is
@@ -497,32 +498,88 @@ def parse_args(argv=None):
     ap.add_argument("--batch-seqs", type=int, default=16)
     ap.add_argument("--batch-frames", type=int, default=44)
     ap.add_argument("--config-frames", type=int, default=60)
+    ap.add_argument("--total-seqs", type=int, default=0, help="track this many sequences in all: ceil(T / gpus) per GPU in lock-step (cfg 5 with T = 8 on fewer than 8 GPUs)")
+    ap.add_argument("--backend", default="hip", choices=["hip", "standin"], help="standin: sleeps instead of GPU work (CPU test of the multi-rank launch path)")
     ap.add_argument("--skip", default="", help="comma-separated side legs to skip: kernels,roofline,sync,batch,configs,cpu")
     args = ap.parse_args(argv)
     args.skip = [s for s in args.skip.split(",") if s]
     return args
 
 
+class StandInBackend:
+    """--backend standin: the five methods run_rank needs, with sleeps for steps (no GPU).  It exists so that the N > 1 launch path --
+    self-launch, rendezvous, barriers, reductions, the one JSON line -- runs end to end on a CPU box (tests/test_shard_gloo.py);
+    rank r's step takes (1 + r) ms, rank 1 reports one lost frame."""
+    device = None
+    workload = "stand-in (sleeps; no GPU work)"
+
+    def __init__(self, args, env):
+        self.env = env
+        self.sequences_per_gpu = args.seqs_per_gpu
+
+    def sync(self):
+        pass
+
+    def prepare(self, n_frames):
+        self.n_frames = n_frames
+
+    def warmup(self, Wm):
+        return [None] * Wm
+
+    def timed(self, first, K, depth):
+        for _ in range(K):
+            time.sleep(0.001 * (1 + self.env.rank))
+        return [(None, None)] * K, (1 if self.env.rank == 1 else 0)
+
+    def extras(self, args, env, warm, poses):
+        return {"roofline": None, "cpu_baseline": None}
+
+
+def _free_port():
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` from a plain shell: start the N ranks the way the driver does (one process per GPU under
+    torch.distributed.run, rendezvous on 127.0.0.1) and hand their exit code on; rank 0 prints the one JSON line."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # the host driver only supports dmabuf IPC (RCCL would fail without it)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse_args()
     env = rank_env()
-    if env.world_size != args.gpus and args.gpus > 1 and env.world_size == 1:
-        raise SystemExit("launch N>1 with: python -m torch.distributed.run --nnodes=1 --nproc-per-node N "
-                         "--master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
-    backend = HipBackend(args, env)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    if env.world_size != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {env.world_size}")
+    if args.total_seqs > 0:  # cfg 5 on G < 8 GPUs: ceil(total / G) sequences per GPU in lock-step (SURVEY 8e)
+        args.seqs_per_gpu = -(-args.total_seqs // env.world_size)
+    standin = args.backend == "standin"
+    backend = StandInBackend(args, env) if standin else HipBackend(args, env)
     dist = None
     if env.world_size > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=backend.device)  # RCCL; used for the barrier + the two scalar reductions only
+        if standin:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=backend.device)  # RCCL; used for the barrier + the two scalar reductions only
     result = run_rank(args, env, dist, backend)
     if dist:
         dist.barrier()
         dist.destroy_process_group()
     if env.rank == 0:
-        print(json.dumps(result))
+        print(json.dumps(result), flush=True)
         se3 = result.get("se3")
-        if result["tracking"]["frames_not_tracking"] or (se3 is not None and not se3["pass"]):
+        if not standin and (result["tracking"]["frames_not_tracking"] or (se3 is not None and not se3["pass"])):
             raise SystemExit("bench.py: the run left TRACKING or its poses differ from the CPU reference by more than 1e-4 -- the number above is INVALID")
 
 

@@ -90,3 +90,30 @@ def test_assignment_covers_every_gpu_count():
         all_ = sorted(s for r in range(g) for s in assign_sequences(8, g, r))
         assert all_ == list(range(8))
         assert max(len(assign_sequences(8, g, r)) for r in range(g)) == 8 // g
+
+
+def test_plain_bench_command_starts_its_own_ranks():
+    """`python bench.py --gpus 2 ...` from a plain shell (no WORLD_SIZE): bench.py launches the two ranks itself under
+    torch.distributed.run on 127.0.0.1 and rank 0 prints the one JSON line; rc 0.  The stand-in backend replaces the GPU work,
+    everything else -- self-launch, rendezvous, barriers, MAX / SUM reductions -- is the path the driver's 8-GPU run takes."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "12", "--warmup", "3", "--backend", "standin"],
+                       env=env, capture_output=True, text=True, timeout=300)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout
+    r = json.loads(lines[0])
+    assert r["n_gpus"] == 2 and r["steps"] == 12 and r["warmup"] == 3 and r["scaling"] == "weak"
+    assert r["ms_per_step"] >= 2.0                               # the slow rank (2 ms per step) sets the time
+    assert abs(r["value"] - 2 * 12 / (r["ms_per_step"] * 12e-3)) < 0.05 * r["value"]
+    assert r["tracking"]["frames_not_tracking"] == 1             # rank 1's lost frame, summed into rank 0's line
+
+
+def test_total_seqs_spreads_cfg5_over_fewer_gpus():
+    import bench
+    for g, want in ((1, 8), (2, 4), (4, 2), (8, 1), (3, 3)):
+        assert -(-8 // g) == want
+    a = bench.parse_args(["--gpus", "2", "--total-seqs", "8"])
+    assert a.total_seqs == 8 and a.seqs_per_gpu == 1             # resolved against WORLD_SIZE in main()

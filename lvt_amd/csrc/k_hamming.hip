@@ -140,7 +140,12 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     }
     __syncthreads();
     if (dbg) dbg[2] = clock64();
-    {  // counts -> exclusive starts, in place; entry nbins receives the total.  One contiguous chunk per thread.
+    if (nbins + 1 <= HB_THREADS) {  // (the usual case) one entry per thread: no chunk loops, no index arithmetic
+        const int v = (tid <= nbins) ? s_start[tid] : 0;
+        int total;
+        const int run = block_excl_scan(v, s_scan, &total);
+        if (tid <= nbins) s_start[tid] = run;
+    } else {  // counts -> exclusive starts, in place; entry nbins receives the total.  One contiguous chunk per thread.
         const int chunk = (nbins + 1 + HB_THREADS - 1) / HB_THREADS;
         const int i0 = min(tid * chunk, nbins + 1), i1 = min(i0 + chunk, nbins + 1);
         int sum = 0;

@@ -1,0 +1,47 @@
+// Development harness (not part of the product): ONE instantiation of the batched matcher behind a C entry, so that a kernel
+// experiment compiles in seconds.  tools/hamming_lab/lab.py builds it, times it and diffs its output against the shipped library.
+#include LAB_KERNEL
+#include <cstdio>
+#include <cstdlib>
+using namespace lvt;
+extern "C" float lab_run(const void *q_desc, const void *q_xy, const void *t_desc, const void *t_xy, const void *t_flag, int B, int M, int N,
+                         float r2, int img_rows, int img_cols, void *out, int launches, long long *dbg_host) {
+    HammingArgs a;
+    a.q_desc = (const uint64_t *)q_desc, a.q_xy = (const float2 *)q_xy, a.t_desc = (const uint64_t *)t_desc, a.t_xy = (const float2 *)t_xy;
+    a.t_flag = (const uint8_t *)t_flag, a.out = (int4 *)out;
+    a.M = M, a.N = N, a.r2 = r2, a.img_rows = img_rows, a.img_cols = img_cols;
+#ifdef LAB_HAS_B
+    a.B = B;
+#endif
+    a.nbx = (img_cols + HASH_CELL - 1) / HASH_CELL, a.nby = (img_rows + HASH_CELL - 1) / HASH_CELL, a.csr = 1;
+    long long *d_dbg = nullptr;
+    a.dbg = nullptr;
+    const size_t dbg_bytes = (dbg_host && dbg_host[15] == 12345) ? (16 + 4 * (size_t)B) * 8 : 128;
+    if (dbg_host && hipMalloc((void **)&d_dbg, dbg_bytes) == hipSuccess && hipMemset(d_dbg, 0, dbg_bytes) == hipSuccess) {
+        a.dbg = d_dbg;
+        hipMemcpy(d_dbg + 15, dbg_host + 15, 8, hipMemcpyHostToDevice);
+    }
+    size_t lds = hamming_lds_bytes(N, M, a.nbx * a.nby);
+    if (getenv("LAB_LDS_EXTRA")) lds += atoi(getenv("LAB_LDS_EXTRA"));  // e.g. force one workgroup per CU
+    auto kern = LAB_INSTANCE;
+    if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1.f;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0), hipEventCreate(&e1);
+    hipEventRecord(e0, 0);
+    int grid = B;
+#ifdef LAB_HAS_B
+    grid = B < 512 ? B : 512;  // resident workgroups: two per CU
+    if (getenv("LAB_GRID")) grid = atoi(getenv("LAB_GRID"));
+#endif
+    for (int l = 0; l < launches; l++) hipLaunchKernelGGL(kern, dim3(grid), dim3(HB_THREADS), lds, 0, a);
+    hipEventRecord(e1, 0);
+    if (hipEventSynchronize(e1) != hipSuccess) return -2.f;
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    hipEventDestroy(e0), hipEventDestroy(e1);
+    if (d_dbg) {
+        hipMemcpy(dbg_host, d_dbg, dbg_bytes, hipMemcpyDeviceToHost);
+        hipFree(d_dbg);
+    }
+    return ms * 1000.f / launches;
+}

@@ -96,6 +96,11 @@ LVT_API const char *lvt_amd_last_error(lvt_handle h);
 
 /* per-kernel timing with HIP events recorded on the handle's stream around every launch of the frame chain.
  * enable=1 resets the accumulators.  lvt_amd_profile_read returns 0 past the last slot. */
+/* host-side counters of a handle: out[0] frames enqueued, out[1] frames collected, out[2] image / depth planes of host-buffer calls
+   (lvt_track, lvt_amd_track_rgbd, ...) that were read IN PLACE because the caller's buffer is page-locked, out[3] planes copied through the
+   library's staging buffer; out[4..7] reserved (0) */
+LVT_API void lvt_amd_get_host_stats(lvt_handle h, long long out[8]);
+
 LVT_API void lvt_amd_profile_enable(lvt_handle h, int enable);
 LVT_API int lvt_amd_profile_read(lvt_handle h, int slot, char *name, int name_cap, double *total_ms, long *calls);
 

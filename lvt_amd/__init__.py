@@ -32,7 +32,7 @@ ABI_SYMBOLS = [
     "lvt_amd_rectify_device", "lvt_amd_rectify", "lvt_amd_rectifier_get_maps",
     "lvt_amd_odometry_create", "lvt_amd_odometry_destroy", "lvt_amd_odometry_reset", "lvt_amd_odometry_push_pose", "lvt_amd_odometry_update", "lvt_amd_profile_enable", "lvt_amd_profile_read", "lvt_amd_get_debug", "lvt_amd_get_timeline", "lvt_amd_get_ordering",
     "lvt_amd_batch_create", "lvt_amd_batch_size", "lvt_amd_batch_track_device_async", "lvt_amd_batch_wait",
-    "lvt_amd_batch_get_counts", "lvt_amd_create_on_device", "lvt_amd_get_device", "lvt_amd_wait_status",
+    "lvt_amd_batch_get_counts", "lvt_amd_create_on_device", "lvt_amd_get_device", "lvt_amd_wait_status", "lvt_amd_get_host_stats",
 ]
 
 N_COUNTS = 32
@@ -126,6 +126,7 @@ def load_library():
     L.lvt_amd_batch_wait.argtypes = [vp, vp, vp, vp]
     L.lvt_amd_batch_get_counts.argtypes = [vp, C.c_int, vp]
     L.lvt_amd_get_debug.argtypes = [vp, vp]
+    L.lvt_amd_get_host_stats.argtypes = [vp, vp]
     L.lvt_amd_profile_read.argtypes = [vp, C.c_int, C.c_char_p, C.c_int, vp, vp]
     _lib = L
     return L
@@ -197,6 +198,12 @@ class LvtSystem:
 
     def last_error(self) -> str:
         return load_library().lvt_amd_last_error(self._h).decode()
+
+    def host_stats(self) -> dict:
+        """host-side counters: frames enqueued / collected, host-buffer planes read in place (page-locked caller buffers) / staged"""
+        a = (C.c_longlong * 8)()
+        load_library().lvt_amd_get_host_stats(self._h, a)
+        return {"enqueued": int(a[0]), "collected": int(a[1]), "planes_in_place": int(a[2]), "planes_staged": int(a[3])}
 
     # lvt_system::track(img1, img2)  -- lvt_system.cpp:157-207
     def track(self, img1, img2):

@@ -62,28 +62,49 @@ __global__ void k_feat_begin(Seq *seqs, const FrameArgs *fa, int par) {
 }
 
 // tightly packed host-layout images (stride == cols) -> pitched device images.
-// Host images enter through a pinned staging buffer that this kernel reads over PCIe (16 B per lane) and writes as the
-// pitched planes k_score wants: blockIdx.y = image.  One launch replaces two pageable H2D copies + two re-pitch kernels
-// (0.32 ms per stereo pair -> see DESIGN.md section 6).
+// Host images enter through a pinned staging buffer -- or, when the caller's buffer is page-locked itself, in place -- that this
+// kernel reads over PCIe and writes as the pitched planes k_score wants: blockIdx.y = image.  One launch replaces two pageable H2D
+// copies + two re-pitch kernels (0.32 ms per stereo pair -> see DESIGN.md section 6).  The source may start at ANY byte address and
+// hold any byte count (1241 x 376 = 466 616 is 8 mod 16): bytes up to the first 16-byte boundary and behind the last whole vector
+// travel one by one, everything between as aligned 16-byte loads -- no load reaches outside [src, src + n).
+__device__ __forceinline__ void stage_put(uint8_t *dst, size_t i, int W, int pitch, uint8_t v) {
+    const size_t y = i / (size_t)W;
+    dst[y * pitch + (i - y * W)] = v;
+}
 __global__ __launch_bounds__(256) void k_stage_in(const uint8_t *src0, const uint8_t *src1, uint8_t *dst0, uint8_t *dst1, int W, int H, int pitch) {
     const uint8_t *src = blockIdx.y ? src1 : src0;
     uint8_t *dst = blockIdx.y ? dst1 : dst0;
-    const size_t n = (size_t)W * H, nv = (n + 15) / 16;  // the staging buffer is padded to 16 B
-    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (size_t)gridDim.x * blockDim.x) {
-        const uint4 q = reinterpret_cast<const uint4 *>(src)[v];
+    const size_t n = (size_t)W * H;
+    const size_t head = min((size_t)((16 - ((uintptr_t)src & 15)) & 15), n);
+    const size_t nv = (n - head) / 16, tail0 = head + nv * 16;
+    const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t v = t0; v < nv; v += stride) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(src + head + v * 16);
         const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
-        size_t i = v * 16;
+        size_t i = head + v * 16;
         int y = (int)(i / (size_t)W), x = (int)(i - (size_t)y * W);
 #pragma unroll
-        for (int k = 0; k < 16; k++, i++) {
-            if (i < n) dst[(size_t)y * pitch + x] = (uint8_t)(wds[k >> 2] >> (8 * (k & 3)));
+        for (int k = 0; k < 16; k++) {
+            dst[(size_t)y * pitch + x] = (uint8_t)(wds[k >> 2] >> (8 * (k & 3)));
             if (++x == W) x = 0, y++;
         }
     }
+    if (t0 < head) stage_put(dst, t0, W, pitch, src[t0]);
+    if (t0 < n - tail0) stage_put(dst, tail0 + t0, W, pitch, src[tail0 + t0]);
 }
-// plain 16-B copy of the (unpitched) depth image out of the staging buffer
-__global__ __launch_bounds__(256) void k_stage_copy(const uint4 *src, uint4 *dst, size_t nv) {
-    for (size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x; v < nv; v += (size_t)gridDim.x * blockDim.x) dst[v] = src[v];
+// the (unpitched) fp32 depth image: 16-byte loads between the first 16-byte boundary of the source and its last whole vector, single
+// floats on either side; the destination is written float by float (it is 16-byte aligned, the source need not be)
+__global__ __launch_bounds__(256) void k_stage_copy(const float *src, float *dst, size_t n) {
+    const size_t head = min((size_t)(((16 - ((uintptr_t)src & 15)) & 15) / 4), n);
+    const size_t nv = (n - head) / 4, tail0 = head + nv * 4;
+    const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t v = t0; v < nv; v += stride) {
+        const float4 q = *reinterpret_cast<const float4 *>(src + head + v * 4);
+        float *d = dst + head + v * 4;
+        d[0] = q.x, d[1] = q.y, d[2] = q.z, d[3] = q.w;
+    }
+    if (t0 < head) dst[t0] = src[t0];
+    if (t0 < n - tail0) dst[tail0 + t0] = src[tail0 + t0];
 }
 
 // handles alive in this process: a handle whose k_match_map polls for its early stream parks 32 workgroups (50 KB of LDS each)
@@ -97,6 +118,7 @@ struct Context {
     double host_enq_us = 0, host_wait_us = 0;  // host time spent enqueueing / blocking (LVT_AMD_HOST_TIMING=1 prints it at destroy)
     long host_enq_n = 0, host_wait_n = 0;
     int gate_timeouts_seen = 0, gate_fatal_seen = 0;
+    long long planes_in_place = 0, planes_staged = 0;  // host-buffer entry points: image / depth planes read in place (page-locked caller buffers) / copied through the staging buffer
     int device = 0;            // the HIP device that owns every allocation, stream and event of this handle (recorded at creation)
     int B = 1;                 // sequences advanced in lock-step by one launch chain
     int sensor = 1;
@@ -885,7 +907,23 @@ LVT_API void lvt_amd_set_stream(lvt_handle h, void *hip_stream) {
 
 LVT_API const char *lvt_amd_last_error(lvt_handle h) {
     if (!h) return "no handle (creation failed: bad parameters, or no HIP device -- there is no CPU fallback)";
-    return static_cast<Context *>(h)->err.c_str();
+    Context *c = static_cast<Context *>(h);
+    if (c->early_pending) {  // the last synchronous call returned on its pose: the frame's own reports (capacity overflow, a gate that
+                             // timed out, a skipped frame) arrive with its full record -- collect it before answering
+        DeviceGuard guard(c);
+        try {
+            drain(c);
+        } catch (...) {
+        }
+    }
+    return c->err.c_str();
+}
+
+LVT_API void lvt_amd_get_host_stats(lvt_handle h, long long out[8]) {
+    Context *c = static_cast<Context *>(h);
+    for (int i = 0; i < 8; i++) out[i] = 0;
+    if (!c) return;
+    out[0] = (long long)c->enq, out[1] = (long long)c->done, out[2] = c->planes_in_place, out[3] = c->planes_staged;
 }
 
 LVT_API void lvt_amd_profile_enable(lvt_handle h, int enable) {
@@ -1059,16 +1097,18 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
     // the borrowed buffers are copied into pinned memory by the CPU and the GPU pulls them from there -- unless the caller's
     // buffer already IS pinned host memory (hipHostMalloc / hipHostRegister, 16-byte aligned): then the GPU reads it in place
     // (this call only returns after the frame has been tracked, so the buffer outlives every read)
-    // (k_stage_in / k_stage_copy read whole 16-byte vectors: a borrowed buffer is only read in place when its byte count is a
-    //  multiple of 16 -- otherwise the last vector would reach up to 15 bytes past its end, possibly past a registered page)
-    auto device_view = [](const void *p, size_t bytes) -> const uint8_t * {
+    // (k_stage_in / k_stage_copy never load outside [p, p + bytes): any base address and byte count qualify -- 1241 x 376 bytes are
+    //  8 mod 16 -- except a depth image that is not even float-aligned)
+    auto device_view = [](const void *p, size_t align) -> const uint8_t * {
         hipPointerAttribute_t a;
-        if (((uintptr_t)p & 15) == 0 && (bytes & 15) == 0 && hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost && a.devicePointer)
+        if (((uintptr_t)p & (align - 1)) == 0 && hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost && a.devicePointer)
             return static_cast<const uint8_t *>(a.devicePointer);
         (void)hipGetLastError();  // (an ordinary malloc'ed pointer is "invalid value" to the query: not an error of this call)
         return nullptr;
     };
-    const uint8_t *s0 = device_view(left, nbytes), *s1 = device_view(second, rgbd ? sizeof(float) * nbytes : nbytes);
+    const uint8_t *s0 = device_view(left, 1), *s1 = device_view(second, rgbd ? sizeof(float) : 1);
+    c->planes_in_place += (s0 != nullptr) + (s1 != nullptr);
+    c->planes_staged += (s0 == nullptr) + (s1 == nullptr);
     if (!s0) {
         std::memcpy(c->h_stage[par], left, nbytes);
         s0 = c->h_stage_dev[par];
@@ -1098,9 +1138,8 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
                 std::memcpy(c->h_stage[par] + c->stage_img, second, sizeof(float) * nbytes);
                 src = c->h_stage_dev[par] + c->stage_img;
             }
-            const size_t nv = (sizeof(float) * nbytes + 15) / 16;
             hipStream_t sd = c->events_only ? sf : c->stream_e;
-            hipLaunchKernelGGL(k_stage_copy, dim3(256), dim3(256), 0, sd, reinterpret_cast<const uint4 *>(src), reinterpret_cast<uint4 *>(c->d_depth[par]), nv);
+            hipLaunchKernelGGL(k_stage_copy, dim3(256), dim3(256), 0, sd, reinterpret_cast<const float *>(src), reinterpret_cast<float *>(c->d_depth[par]), nbytes);
             if (sd != sf) {
                 (void)hipEventRecord(c->ev_depth, sd);
                 c->depth_wait = true;
@@ -1306,9 +1345,13 @@ LVT_API void lvt_amd_get_debug(lvt_handle h, long long out[32]) {
 LVT_API int lvt_amd_get_ordering(lvt_handle h) {  // 0: polling gates + early stream, 1: event barriers only
     return h && static_cast<Context *>(h)->events_only ? 1 : 0;
 }
-LVT_API void lvt_amd_get_timeline(lvt_handle h, long long out[16]) {  // of the frame lvt_amd_wait returned last; does not drain
-    Context *c = static_cast<Context *>(h);
+LVT_API void lvt_amd_get_timeline(lvt_handle h, long long out[16]) {  // of the frame collected last; a frame whose synchronous call
+    Context *c = static_cast<Context *>(h);                            // returned on its pose is collected first, nothing else is drained
     DeviceGuard guard(c);
+    try {
+        if (c->early_pending) drain(c);
+    } catch (...) {
+    }
     for (int i = 0; i < 16; i++) out[i] = last_ctl(c).dbg[32 + i];
 }
 LVT_API int lvt_amd_get_plane(lvt_handle h, int eye, int what, void *dst, int cap_bytes, int *pitch_out) {

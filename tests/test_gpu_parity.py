@@ -441,25 +441,51 @@ def test_lockstep_batch_with_one_sequence_lost(hip_lib):
     assert batch.last_error() == ""
 
 
-def test_pinned_host_buffers_are_read_in_place(hip_lib):
-    """lvt_track with page-locked host images (torch pin_memory = hipHostMalloc) skips the staging copy; same poses as with
-    ordinary numpy buffers, including an unaligned view that has to take the copying path"""
+@pytest.mark.parametrize("scale", [0.5, 1.0], ids=["half_size", "kitti_1241x376"])
+def test_pinned_host_buffers_are_read_in_place(hip_lib, scale):
+    """lvt_track with page-locked host images (torch pin_memory = hipHostMalloc) skips the staging copy -- at the headline shape too,
+    whose 466 616 bytes per image are not a multiple of the 16-byte vectors the pull kernel loads (it reads the odd head and tail byte
+    by byte), and from a base address that is not 16-byte aligned.  Same poses as with ordinary numpy buffers, and the ROUTE is asserted
+    (lvt_amd_get_host_stats), not just the result."""
     import torch
-    world, prm, sensor = make_case("kitti", 17, 0.5)
+    world, prm, sensor = make_case("kitti", 17, scale)
     a = hip_lib.LvtSystem.create(prm, 1); b = hip_lib.LvtSystem.create(prm, 1)
-    for i in range(8):
+    n = 8
+    for i in range(n):
         L, R = world.render_stereo(i)
-        pl, pr = torch.from_numpy(L).pin_memory(), torch.from_numpy(R).pin_memory()
-        if i == 5:  # an unaligned pinned view: base + 1 byte
-            buf = torch.empty(L.size + 1, dtype=torch.uint8).pin_memory()
-            buf[1:] = torch.from_numpy(L).reshape(-1)
-            Lp = buf[1:].numpy().reshape(L.shape)
-        else:
-            Lp = pl.numpy()
+        pr = torch.from_numpy(R).pin_memory()
+        off = (0, 1, 0, 7, 0, 13, 0, 0)[i]   # page-locked views that start 1, 7, 13 bytes behind a 16-byte boundary
+        buf = torch.empty(L.size + 16, dtype=torch.uint8).pin_memory()
+        buf[off:off + L.size] = torch.from_numpy(L).reshape(-1)
+        Lp = buf[off:off + L.size].numpy().reshape(L.shape)
+        assert Lp.ctypes.data % 16 == off
         Ra, ta = a.track(L, R)
         Rb, tb = b.track(Lp, pr.numpy())
         assert np.array_equal(ta, tb) and np.array_equal(Ra, Rb), f"frame {i}"
     assert a.counts() == b.counts() and b.last_error() == ""
+    if scale == 1.0:
+        assert (world.W * world.H) % 16 != 0      # the case that used to fall back to the staging copy
+    sa, sb = a.host_stats(), b.host_stats()
+    assert sa["planes_in_place"] == 0 and sa["planes_staged"] == 2 * n, sa        # pageable numpy buffers: copied
+    assert sb["planes_in_place"] == 2 * n and sb["planes_staged"] == 0, sb        # page-locked: every plane read where it lies
+
+
+def test_last_error_reports_the_frame_just_tracked(hip_lib):
+    """a synchronous call may return on the pose k_pnp hands over, before the frame's full record exists; lvt_amd_last_error must still
+    speak for THAT frame when it is called right behind lvt_track (it collects the frame first) -- here: more external corners than the
+    feature arrays hold"""
+    world, prm, sensor = make_case("kitti", 21, 0.5)
+    vo = hip_lib.LvtSystem.create(prm, 1)
+    for i in range(3):
+        L, R = world.render_stereo(i)
+        vo.track(L, R)
+        assert vo.last_error() == ""
+    L, R = world.render_stereo(3)
+    rng = np.random.default_rng(3)
+    many = np.stack([rng.uniform(30, world.W - 30, 5000), rng.uniform(30, world.H - 30, 5000)], axis=1)   # 5000 > the 4096 feature slots
+    vo.track_with_external_corners(L, R, many, many[:100])
+    err = vo.last_error()          # first call after the frame: no counts() / get_state() in between
+    assert "capacity" in err or "overflow" in err, err
 
 
 def test_rgbd_depth_upload_beside_detection(hip_lib):

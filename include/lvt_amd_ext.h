@@ -111,6 +111,7 @@ enum {
     LVT_AMD_C_RETRY_LEFT, LVT_AMD_C_RETRY_RIGHT, LVT_AMD_C_PNP_ITERS, LVT_AMD_C_PNP_INLIERS,
     LVT_AMD_C_MAP_SIZE_AT_MATCH, LVT_AMD_C_N_STAGED_ERASED, LVT_AMD_C_N_STAGED_PROMOTED, LVT_AMD_C_N_CULLED,
     LVT_AMD_C_FRAME, LVT_AMD_C_OVERFLOW /* bitmask of capacity overflows, 0 = none */,
+    LVT_AMD_C_PNP_BORDERLINE /* chi2-gate decisions of this frame's pose refinement within 1e-8 of the 5.991 threshold */,
     LVT_AMD_C__COUNT = 32
 };
 LVT_API void lvt_amd_get_counts(lvt_handle h, int out[LVT_AMD_C__COUNT]);
@@ -139,6 +140,12 @@ LVT_API int lvt_amd_get_plane(lvt_handle h, int eye, int what, void *dst, int ca
 /* motion-only BA alone (reference lvt_pnp_solver.cpp:60-128): pts n x 3 f64, obs n x 2 f32 (host) */
 LVT_API int lvt_amd_pnp(const lvt_amd_params *p, const double q_in[4], const double p_in[3], const double *pts,
                         const float *obs, int n, double q_out[4], double p_out[3], int *n_solve_calls);
+/* the same with the chi2 gates laid open (each may be NULL): err_out = the 2n edge errors the second gate saw, level_out[i] = 1 for an
+ * edge a gate demoted (lvt_pnp_solver.cpp:109-116), *borderline = decisions taken within 1e-8 of the 5.991 threshold (those are
+ * re-evaluated in the reference's operation order before they are taken; LVT_AMD_C_PNP_BORDERLINE reports the same per frame) */
+LVT_API int lvt_amd_pnp_detail(const lvt_amd_params *p, const double q_in[4], const double p_in[3], const double *pts,
+                               const float *obs, int n, double q_out[4], double p_out[3], int *n_solve_calls,
+                               double *err_out, int *level_out, int *borderline);
 /* batched masked 2-NN Hamming (reference lvt_image_features_struct.cpp:68-120 + cv::BFMatcher knnMatch k=2):
  * B independent problems; per problem M queries (desc 32 B, xy f32) against N train (desc, xy, flag u8);
  * candidate iff !flag && dx*dx+dy*dy < r2 (f32, strict) [mode 0] or |band| row test [mode 1].

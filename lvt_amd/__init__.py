@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "lvt_amd_track_rgbd", "lvt_amd_track_device", "lvt_amd_track_device_async", "lvt_amd_wait",
     "lvt_amd_set_stream", "lvt_amd_last_error", "lvt_amd_get_counts", "lvt_amd_get_features",
     "lvt_amd_get_matches", "lvt_amd_get_row_matches", "lvt_amd_get_map", "lvt_amd_get_staged",
-    "lvt_amd_get_pose", "lvt_amd_get_predicted_pose", "lvt_amd_get_plane", "lvt_amd_pnp",
+    "lvt_amd_get_pose", "lvt_amd_get_predicted_pose", "lvt_amd_get_plane", "lvt_amd_pnp", "lvt_amd_pnp_detail",
     "lvt_amd_hamming_match_batched", "lvt_amd_hamming_match_batched_n", "lvt_amd_rectifier_create", "lvt_amd_rectifier_destroy",
     "lvt_amd_rectify_device", "lvt_amd_rectify", "lvt_amd_rectifier_get_maps",
     "lvt_amd_odometry_create", "lvt_amd_odometry_destroy", "lvt_amd_odometry_reset", "lvt_amd_odometry_push_pose", "lvt_amd_odometry_update", "lvt_amd_profile_enable", "lvt_amd_profile_read", "lvt_amd_get_debug", "lvt_amd_get_timeline", "lvt_amd_get_ordering",
@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
 N_COUNTS = 32
 COUNT_NAMES = ["n_left", "n_right", "map_size", "staged_size", "n_matches", "second_pass", "n_row_matches",
                "n_triangulated", "triangulated", "retry_left", "retry_right", "pnp_iters", "pnp_inliers",
-               "map_size_at_match", "n_staged_erased", "n_staged_promoted", "n_culled", "frame", "overflow"]
+               "map_size_at_match", "n_staged_erased", "n_staged_promoted", "n_culled", "frame", "overflow", "pnp_borderline"]
 
 eState_NOT_INITIALIZED, eState_TRACKING, eState_LOST = 1, 2, 3
 eSensor_STEREO, eSensor_RGBD = 1, 2
@@ -97,6 +97,7 @@ def load_library():
     L.lvt_amd_get_predicted_pose.argtypes = [vp, vp, vp]
     L.lvt_amd_get_plane.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp]
     L.lvt_amd_pnp.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]
+    L.lvt_amd_pnp_detail.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
     L.lvt_amd_hamming_match_batched.restype = C.c_float
     L.lvt_amd_hamming_match_batched.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp]
     L.lvt_amd_get_timeline.argtypes = [vp, vp]
@@ -384,6 +385,22 @@ def pnp(params: LvtParameters, q_in, p_in, pts, obs):
     if inl < 0:
         raise RuntimeError("lvt_amd_pnp failed")
     return q, p, inl, calls.value
+
+
+def pnp_detail(params: LvtParameters, q_in, p_in, pts, obs):
+    """lvt_amd_pnp with the chi2 gates laid open: (q, p, inliers, solve calls, err (n x 2: what the second gate saw), level (n: 1 = demoted),
+    borderline = gate decisions taken within 1e-8 of the threshold)"""
+    L = load_library()
+    pod = params.to_pod()
+    q_in = np.ascontiguousarray(q_in, np.float64); p_in = np.ascontiguousarray(p_in, np.float64)
+    pts = np.ascontiguousarray(pts, np.float64); obs = np.ascontiguousarray(obs, np.float32)
+    n = len(pts)
+    q = np.zeros(4); p = np.zeros(3); calls = C.c_int(0); border = C.c_int(0)
+    err = np.zeros((n, 2)); level = np.zeros(n, np.int32)
+    inl = L.lvt_amd_pnp_detail(C.byref(pod), _p(q_in), _p(p_in), _p(pts), _p(obs), n, _p(q), _p(p), C.byref(calls), _p(err), _p(level), C.byref(border))
+    if inl < 0:
+        raise RuntimeError("lvt_amd_pnp_detail failed")
+    return q, p, inl, calls.value, err, level, border.value
 
 
 def hamming_match_batched(q_desc, q_xy, t_desc, t_xy, t_flag, r2: float, mode: int, img_rows: int, img_cols: int, out, stream: int = 0,

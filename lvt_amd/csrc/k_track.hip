@@ -1559,7 +1559,7 @@ __device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3]
 // buildSystem would recompute exactly those values (same estimate, same active edges, same arithmetic), so they are
 // reused; a rejected last trial or a new pass falls back to a fresh sweep.
 __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, const double *X, const float *obs, double *err, double *sink,
-                        int8_t *level, int n, PnpShared &sh, double *red, Pose &result, int &inliers, int &solve_calls, long long *dbg = nullptr) {
+                        int8_t *level, int n, PnpShared &sh, double *red, Pose &result, int &inliers, int &solve_calls, int &borderline, long long *dbg = nullptr) {
     const int tid = threadIdx.x;
     long long t_sweep = 0, t_solve = 0, t_dec = 0, t_red = 0, t_all = clock64();
     long long bs[5] = {0, 0, 0, 0, 0};
@@ -1587,6 +1587,14 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
     };
     load_cam();
     int calls = 0;
+    // the estimate of the most recent sweep = the one the stored edge errors belong to (after a rejected last trial that is NOT the
+    // estimate the pass ends with: pop() restores the camera, the errors stay those of the trial)
+    double swr[4], swt[3];
+    auto note_sweep_cam = [&]() {
+        for (int k = 0; k < 4; k++) swr[k] = cr[k];
+        for (int k = 0; k < 3; k++) swt[k] = ct[k];
+    };
+    double n_border[1] = {0.0};
 
     for (int pass = 0; pass < 2; pass++) {
         double na[1] = {0.0};
@@ -1601,6 +1609,7 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
             if (!have_sys) {
                 double acc[28];
                 pnp_sweep<true>(cam, ct, fx, fy, cx, cy, dsqr, dsqrReci, X, obs, err, sink, level, n, acc);
+                note_sweep_cam();
                 block_sum<28>(acc, red, sh.sys[sh.cur]);
             }
             t_sweep += clock64() - c0;
@@ -1657,6 +1666,7 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
                 load_cam();
                 c1 = clock64();
                 double tempChi;
+                note_sweep_cam();
                 {
                     double acc[28];
                     if (speculate) {
@@ -1715,10 +1725,29 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
                 __syncthreads();  // sh.cont / sh.r consumed before thread 0 publishes again
             } while (cont);
         }
-        // chi2 gate on the last computed errors (lvt_pnp_solver.cpp:109-116)
-        for (int i = tid; i < n; i += PNP_THREADS) {
-            const double e0 = err[2 * i], e1 = err[2 * i + 1];
-            if ((e0 * e0 + e1 * e1) > REPROJ_TH2) level[i] = 1;
+        // chi2 gate on the last computed errors (lvt_pnp_solver.cpp:109-116).  The sweep evaluates an edge's error with refined
+        // reciprocals and in the camera-frame form (section 4.6 of DESIGN.md): within ~1e-11 of the value the reference's expression
+        // px / pz - u gives.  A decision that close to the threshold is re-taken on the reference's own expression, IEEE divisions, at the
+        // estimate the stored errors belong to -- and counted, so that tests see how often (and how near) that happens.
+        {
+            for (int i = tid; i < n; i += PNP_THREADS) {
+                if (level[i] != 0) continue;
+                const double e0 = err[2 * i], e1 = err[2 * i + 1];
+                const double e2 = e0 * e0 + e1 * e1;
+                bool out = e2 > REPROJ_TH2;
+                if (fabs(e2 - REPROJ_TH2) < PNP_GATE_MARGIN) {
+                    CamRegs gc;  // (rare) the camera of the last sweep; cam_refresh forms w2i in the reference's order
+                    cam_refresh(gc, swr, swt, fx, fy, cx, cy);
+                    const double x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2];
+                    const double px = ((gc.w2i[0] * x + gc.w2i[1] * y) + gc.w2i[2] * z) + gc.w2i[3];
+                    const double py = ((gc.w2i[4] * x + gc.w2i[5] * y) + gc.w2i[6] * z) + gc.w2i[7];
+                    const double pz = ((gc.w2i[8] * x + gc.w2i[9] * y) + gc.w2i[10] * z) + gc.w2i[11];
+                    const double r0 = px / pz - (double)obs[2 * i], r1 = py / pz - (double)obs[2 * i + 1];
+                    out = (r0 * r0 + r1 * r1) > REPROJ_TH2;
+                    n_border[0] += 1.0;
+                }
+                if (out) level[i] = 1;
+            }
         }
         __syncthreads();
     }
@@ -1726,6 +1755,8 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
     for (int i = tid; i < n; i += PNP_THREADS) inl[0] += (level[i] == 0) ? 1.0 : 0.0;
     block_sum<1>(inl, red);
     inliers = (int)inl[0];
+    block_sum<1>(n_border, red);
+    borderline = (int)n_border[0];
     solve_calls = calls;
     for (int k = 0; k < 4; k++) result.q[k] = cr[k];
     for (int k = 0; k < 3; k++) result.p[k] = ct[k];
@@ -1741,7 +1772,7 @@ constexpr int PNP_STAGE_MAX = 1536;
 constexpr int PNP_DYN_BYTES = PNP_STAGE_MAX * (24 + 16 + 8 + 1);
 
 __device__ __forceinline__ void pnp_solve(const Params &prm, const Pose &prior, const double *X, const float *obs, double *err, int8_t *level,
-                                          int n, PnpShared &sh, double *red, uint8_t *dyn, Pose &res, int &inliers, int &calls, long long *dbg) {
+                                          int n, PnpShared &sh, double *red, uint8_t *dyn, Pose &res, int &inliers, int &calls, int &borderline, long long *dbg) {
     if (n <= PNP_STAGE_MAX) {
         double *sX = reinterpret_cast<double *>(dyn);
         double *sErr = sX + 3 * PNP_STAGE_MAX;
@@ -1751,11 +1782,11 @@ __device__ __forceinline__ void pnp_solve(const Params &prm, const Pose &prior, 
         for (int i = threadIdx.x; i < 2 * n; i += PNP_THREADS) sObs[i] = obs[i];
         for (int i = threadIdx.x; i < n; i += PNP_THREADS) sLvl[i] = level[i];
         __syncthreads();
-        pnp_run(prm, prior, sX, sObs, sErr, red + 382, sLvl, n, sh, red, res, inliers, calls, dbg);  // red[382..383]: free (block_sum uses [0, 32) and [384, ...))
+        pnp_run(prm, prior, sX, sObs, sErr, red + 382, sLvl, n, sh, red, res, inliers, calls, borderline, dbg);  // red[382..383]: free (block_sum uses [0, 32) and [384, ...))
         for (int i = threadIdx.x; i < 2 * n; i += PNP_THREADS) err[i] = sErr[i];
         for (int i = threadIdx.x; i < n; i += PNP_THREADS) level[i] = sLvl[i];
     } else
-        pnp_run(prm, prior, X, obs, err, err + 2 * (size_t)n, level, n, sh, red, res, inliers, calls, dbg);  // the caller allocates 2 n + 2 doubles
+        pnp_run(prm, prior, X, obs, err, err + 2 * (size_t)n, level, n, sh, red, res, inliers, calls, borderline, dbg);  // the caller allocates 2 n + 2 doubles
 }
 
 // the pose of a synchronous call, delivered the moment it exists (pinned host memory): lvt_track returns on it while the frame's
@@ -1780,9 +1811,9 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(SeqArg<BV> sa, int par, seq
     __shared__ double red[384 + 28 * (PNP_THREADS + 8)];
     extern __shared__ __attribute__((aligned(16))) uint8_t pnp_dyn[];
     Pose res;
-    int inliers, calls;
+    int inliers, calls, borderline;
     // err must be defined for every edge before the first gate: all edges are active in pass 1
-    pnp_solve(S.prm, ctl.predicted, S.pnp_X, S.pnp_obs, S.pnp_err, S.pnp_level, ctl.n_matches, sh, red, pnp_dyn, res, inliers, calls, ctl.dbg);
+    pnp_solve(S.prm, ctl.predicted, S.pnp_X, S.pnp_obs, S.pnp_err, S.pnp_level, ctl.n_matches, sh, red, pnp_dyn, res, inliers, calls, borderline, ctl.dbg);
     if (threadIdx.x == 0) {
         ctl.optimized = res;
         ctl.last_pose = res;  // lvt_system.cpp:205
@@ -1790,6 +1821,7 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(SeqArg<BV> sa, int par, seq
         ctl.out_status = 2;
         ctl.counts[C_PNP_ITERS] = calls;
         ctl.counts[C_PNP_INLIERS] = inliers;
+        ctl.counts[C_PNP_BORDERLINE] = borderline;
         ctl.early_done = *S.map_n;  // the map after clean_untracked_points: the next frame may start on these points now
         ctl.early_accepted = 0;
         ctl.dbg[45] = (long long)wall_clock64();
@@ -1817,12 +1849,13 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp_standalone(Params prm, Pose
     for (int i = threadIdx.x; i < n; i += PNP_THREADS) level[i] = 0;
     __syncthreads();
     Pose res;
-    int inliers, calls;
-    pnp_solve(prm, prior, X, obs, err, level, n, sh, red, pnp_dyn, res, inliers, calls, nullptr);
+    int inliers, calls, borderline;
+    pnp_solve(prm, prior, X, obs, err, level, n, sh, red, pnp_dyn, res, inliers, calls, borderline, nullptr);
     if (threadIdx.x == 0) {
         *out = res;
         info[0] = calls;
         info[1] = inliers;
+        info[2] = borderline;
     }
 }
 

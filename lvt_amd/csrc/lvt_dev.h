@@ -28,11 +28,14 @@ enum : int { OVF_RAW = 1, OVF_CELL_OUT = 2, OVF_FEATURES = 4, OVF_MAP = 8, OVF_S
 enum : int {
     C_N_LEFT = 0, C_N_RIGHT, C_MAP_SIZE, C_STAGED_SIZE, C_N_MATCHES, C_SECOND_PASS, C_N_ROW_MATCHES,
     C_N_TRIANGULATED, C_TRIANGULATED, C_RETRY_LEFT, C_RETRY_RIGHT, C_PNP_ITERS, C_PNP_INLIERS,
-    C_MAP_SIZE_AT_MATCH, C_N_STAGED_ERASED, C_N_STAGED_PROMOTED, C_N_CULLED, C_FRAME, C_OVERFLOW
+    C_MAP_SIZE_AT_MATCH, C_N_STAGED_ERASED, C_N_STAGED_PROMOTED, C_N_CULLED, C_FRAME, C_OVERFLOW, C_PNP_BORDERLINE
 };
 
 // constants of the reference -- lvt/src/lvt_definitions.h:29-34
 constexpr double REPROJ_TH2 = 5.991;
+// k_pnp's chi2 gates: an edge whose squared error lies this close to the threshold is counted (C_PNP_BORDERLINE) and decided on an
+// error re-evaluated in the reference's operation order with IEEE divisions (the sweep's own arithmetic agrees with it to ~1e-11)
+constexpr double PNP_GATE_MARGIN = 1e-8;
 constexpr int N_MAP_POINTS = 250;
 constexpr int ROW_RADIUS = 2;
 constexpr int HASH_CELL = 25;

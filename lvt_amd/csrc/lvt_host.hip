@@ -1373,8 +1373,10 @@ LVT_API int lvt_amd_get_plane(lvt_handle h, int eye, int what, void *dst, int ca
 }
 
 // ---- stage entry: motion-only BA on caller data ---------------------------------------------------
-LVT_API int lvt_amd_pnp(const lvt_amd_params *pin, const double q_in[4], const double p_in[3], const double *pts, const float *obs, int n,
-                        double q_out[4], double p_out[3], int *n_solve_calls) {
+// err_out (2n doubles, may be NULL): the edge errors the second chi2 gate saw; level_out (n ints, may be NULL): 1 = demoted by a gate;
+// *borderline (may be NULL): gate decisions taken within PNP_GATE_MARGIN of the threshold
+LVT_API int lvt_amd_pnp_detail(const lvt_amd_params *pin, const double q_in[4], const double p_in[3], const double *pts, const float *obs, int n,
+                               double q_out[4], double p_out[3], int *n_solve_calls, double *err_out, int *level_out, int *borderline) {
     Params prm;
     lvt_amd_params tmp = *pin;
     if (tmp.img_width <= 0) tmp.img_width = 64;
@@ -1389,7 +1391,7 @@ LVT_API int lvt_amd_pnp(const lvt_amd_params *pin, const double q_in[4], const d
     const size_t nn = (size_t)std::max(n, 1);
     if (hipMalloc((void **)&dX, nn * 24) == hipSuccess && hipMalloc((void **)&dErr, nn * 16 + 16) == hipSuccess &&
         hipMalloc((void **)&dObs, nn * 8) == hipSuccess && hipMalloc((void **)&dLevel, nn) == hipSuccess &&
-        hipMalloc((void **)&dOut, sizeof(Pose)) == hipSuccess && hipMalloc((void **)&dInfo, 8) == hipSuccess) {
+        hipMalloc((void **)&dOut, sizeof(Pose)) == hipSuccess && hipMalloc((void **)&dInfo, 16) == hipSuccess) {
         (void)hipMemcpy(dX, pts, (size_t)n * 24, hipMemcpyHostToDevice);
         (void)hipMemcpy(dObs, obs, (size_t)n * 8, hipMemcpyHostToDevice);
         Pose prior;
@@ -1398,17 +1400,28 @@ LVT_API int lvt_amd_pnp(const lvt_amd_params *pin, const double q_in[4], const d
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pnp_standalone), hipFuncAttributeMaxDynamicSharedMemorySize, PNP_DYN_BYTES);
         hipLaunchKernelGGL(k_pnp_standalone, dim3(1), dim3(PNP_THREADS), PNP_DYN_BYTES, 0, prm, prior, dX, dObs, dErr, dLevel, n, dOut, dInfo);
         Pose out;
-        int info[2] = {0, 0};
+        int info[4] = {0, 0, 0, 0};
         if (hipMemcpy(&out, dOut, sizeof(Pose), hipMemcpyDeviceToHost) == hipSuccess &&
-            hipMemcpy(info, dInfo, 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            hipMemcpy(info, dInfo, 16, hipMemcpyDeviceToHost) == hipSuccess) {
             for (int k = 0; k < 4; k++) q_out[k] = out.q[k];
             for (int k = 0; k < 3; k++) p_out[k] = out.p[k];
             if (n_solve_calls) *n_solve_calls = info[0];
+            if (borderline) *borderline = info[2];
             rc = info[1];
+            if (err_out && hipMemcpy(err_out, dErr, (size_t)n * 16, hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
+            if (level_out) {
+                std::vector<int8_t> lv((size_t)std::max(n, 1));
+                if (hipMemcpy(lv.data(), dLevel, (size_t)n, hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
+                for (int i = 0; i < n; i++) level_out[i] = lv[i];
+            }
         }
     }
     (void)hipFree(dX), (void)hipFree(dErr), (void)hipFree(dObs), (void)hipFree(dLevel), (void)hipFree(dOut), (void)hipFree(dInfo);
     return rc;
+}
+LVT_API int lvt_amd_pnp(const lvt_amd_params *pin, const double q_in[4], const double p_in[3], const double *pts, const float *obs, int n,
+                        double q_out[4], double p_out[3], int *n_solve_calls) {
+    return lvt_amd_pnp_detail(pin, q_in, p_in, pts, obs, n, q_out, p_out, n_solve_calls, nullptr, nullptr, nullptr);
 }
 
 

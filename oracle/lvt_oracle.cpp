@@ -23,6 +23,9 @@ namespace {
 // constants -- lvt/src/lvt_definitions.h:29-34
 // ---------------------------------------------------------------------------------------------
 constexpr double kReprojTh2 = 5.991;
+// edges whose squared error lies this close to the chi2 threshold are COUNTED (LVTO_C_PNP_BORDERLINE): an implementation that evaluates
+// the same error in a different operation order agrees on e^2 to ~1e-11, so only those decisions could differ
+constexpr double kGateMargin = 1e-8;
 constexpr int kNMapPoints = 250;
 constexpr int kRowRadius = 2;
 constexpr int kHashCell = 25;
@@ -691,7 +694,12 @@ struct PnpResult {
     Pose pose;
     int solve_calls = 0;
     int inliers = 0;
+    int borderline = 0;      // gate decisions (both passes) taken within kGateMargin of the threshold
+    double min_margin = 1e300;  // the closest any gate decision came to it
 };
+// the last pnp_compute_pose of this thread: errors the gates saw (pass 2's), for tests that compare them edge by edge
+static thread_local std::vector<double> g_last_pnp_err;
+static thread_local PnpResult g_last_pnp;
 
 PnpResult pnp_compute_pose(const lvto_params &prm, const Pose &prior, const std::vector<V3> &pts,
                            const std::vector<float> &obs /* n x 2 */, std::vector<int> *inlier_marks,
@@ -828,6 +836,11 @@ PnpResult pnp_compute_pose(const lvto_params &prm, const Pose &prior, const std:
         // chi2 gate on the errors of the last computeActiveErrors() (pnp_solver.cpp:109-116)
         for (int k = 0; k < n; k++) {
             double chi2 = err[2 * k] * err[2 * k] + err[2 * k + 1] * err[2 * k + 1];
+            if (level[k] == 0) {
+                const double m = std::fabs(chi2 - kReprojTh2);
+                res.min_margin = std::min(res.min_margin, m);
+                if (m < kGateMargin) res.borderline++;
+            }
             if (chi2 > kReprojTh2) {
                 level[k] = 1;
                 marks[k] = 0;
@@ -838,6 +851,8 @@ PnpResult pnp_compute_pose(const lvto_params &prm, const Pose &prior, const std:
     res.pose.p = cam.t;
     for (int k = 0; k < n; k++) res.inliers += marks[k];
     if (inlier_marks) *inlier_marks = marks;
+    g_last_pnp_err = err;
+    g_last_pnp = res;
     return res;
 }
 
@@ -1208,6 +1223,7 @@ struct System {
         PnpResult pr = pnp_compute_pose(prm, estimated, map_points, obs, nullptr, nullptr);
         counts[LVTO_C_PNP_ITERS] = pr.solve_calls;
         counts[LVTO_C_PNP_INLIERS] = pr.inliers;
+        counts[LVTO_C_PNP_BORDERLINE] = pr.borderline;
         const Pose optimized = pr.pose;
         clean_untracked(ls);
         if (prm.staged_threshold > 0) update_staged(optimized, ls);
@@ -1535,6 +1551,11 @@ int lvto_pnp(const lvto_params *p, const double q_in[4], const double p_in[3], c
     if (trace)
         for (int i = 0; i < std::min(rows, trace_cap) * 4; i++) trace[i] = tr[i];
     return rows;
+}
+int lvto_pnp_last_gate(double *err_out, int n, double *min_margin) {
+    for (int i = 0; i < std::min(2 * n, (int)g_last_pnp_err.size()); i++) err_out[i] = g_last_pnp_err[i];
+    if (min_margin) *min_margin = g_last_pnp.min_margin;
+    return g_last_pnp.borderline;
 }
 int lvto_triangulate_one(const lvto_params *p, const double q[4], const double pos[3], float ulx, float uly, float urx, float ury,
                          double out_xyz[3]) {

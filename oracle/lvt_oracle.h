@@ -82,6 +82,8 @@ enum {
     LVTO_C_N_STAGED_PROMOTED,
     LVTO_C_N_CULLED,
     LVTO_C_FRAME,
+    LVTO_C_OVERFLOW_UNUSED,  /* (slot 18 is the HIP path's capacity-overflow mask; always 0 here) */
+    LVTO_C_PNP_BORDERLINE,   /* chi2-gate decisions (both passes) within 1e-8 of the 5.991 threshold */
     LVTO_C__COUNT = 32
 };
 void lvto_get_counts(lvto_handle h, int out[LVTO_C__COUNT]);
@@ -123,6 +125,9 @@ void lvto_hamming_top2(const uint8_t *query, const uint8_t *train, int n, const 
 int lvto_pnp(const lvto_params *p, const double q_in[4], const double p_in[3], const double *pts,
              const float *obs, int n, double q_out[4], double p_out[3], int *inlier_marks,
              double *trace, int trace_cap, int *solve_calls);
+/* the gates of the last lvto_pnp / frame on this thread: copies the 2n edge errors they saw, *min_margin = the closest
+   |e^2 - 5.991| of any decision; returns the number of decisions within 1e-8 of the threshold */
+int lvto_pnp_last_gate(double *err_out, int n, double *min_margin);
 /* linear-LS stereo triangulation of one pair incl. gates (local_map.cpp:276-319); returns 1 if kept */
 int lvto_triangulate_one(const lvto_params *p, const double q[4], const double pos[3], float ulx,
                          float uly, float urx, float ury, double out_xyz[3]);

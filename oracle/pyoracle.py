@@ -13,7 +13,7 @@ _SO = os.path.join(_HERE, "liblvt_oracle.so")
 N_COUNTS = 32
 COUNT_NAMES = ["n_left", "n_right", "map_size", "staged_size", "n_matches", "second_pass", "n_row_matches",
                "n_triangulated", "triangulated", "retry_left", "retry_right", "pnp_iters", "pnp_inliers",
-               "map_size_at_match", "n_staged_erased", "n_staged_promoted", "n_culled", "frame"]
+               "map_size_at_match", "n_staged_erased", "n_staged_promoted", "n_culled", "frame", "overflow", "pnp_borderline"]
 
 
 def build(force: bool = False):
@@ -60,6 +60,7 @@ def lib():
         L.lvto_compute_features.argtypes = [vp, C.c_int, C.c_int, vp, vp, vp, vp, C.c_int, vp]
         L.lvto_hamming_top2.argtypes = [vp, vp, C.c_int, vp, vp]
         L.lvto_pnp.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp]
+        L.lvto_pnp_last_gate.argtypes = [vp, C.c_int, vp]
         L.lvto_triangulate_one.argtypes = [vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]
         L.lvto_motion_predict.argtypes = [vp, vp, vp, vp, vp]
         _lib = L
@@ -241,6 +242,10 @@ def pnp(params, q_in, p_in, pts, obs, trace_cap=256):
     calls = C.c_int(0)
     n = lib().lvto_pnp(C.byref(pod), _p(q_in), _p(p_in), _p(pts), _p(obs), len(pts), _p(q), _p(p), _p(marks), _p(tr), trace_cap, C.byref(calls))
     pnp.last_solve_calls = calls.value   # optimize() iterations (g2o solve() calls) of both passes
+    err = np.zeros(2 * len(pts)); mm = C.c_double(0.0)
+    pnp.last_borderline = lib().lvto_pnp_last_gate(_p(err), len(pts), C.byref(mm))   # gate decisions within 1e-8 of the threshold
+    pnp.last_min_margin = mm.value
+    pnp.last_err = err.reshape(-1, 2)     # the edge errors pass 2's gate saw
     return q, p, marks, tr[:min(n, trace_cap)].copy()
 
 

@@ -255,6 +255,83 @@ def test_pnp_standalone(hip_lib, oracle_lib):
         assert calls == oracle_lib.pnp.last_solve_calls and 0 < calls <= 10, (trial, calls, oracle_lib.pnp.last_solve_calls)
         assert np.allclose(ph, po, rtol=0, atol=1e-7) and np.allclose(qh, qo, atol=1e-9), (trial, ph, po)
         assert np.linalg.norm(ph - p_true) < 0.05
+        # the gates laid open: k_pnp's edge errors (refined reciprocals, camera-frame form, FMA sums) against the oracle's px / pz - u,
+        # edge by edge -- the deviation must stay two orders of magnitude inside the margin within which a decision is re-evaluated
+        _, _, inl2, _, err_h, level_h, border_h = hip_lib.pnp_detail(prm, q0, p0, X, uv)
+        e2h = (err_h ** 2).sum(axis=1); e2o = (oracle_lib.pnp.last_err ** 2).sum(axis=1)
+        seen = (level_h == 0) | (marks == 0)      # (an edge demoted by the FIRST gate keeps the error of pass 1 on both sides)
+        dev = np.abs(e2h - e2o)[seen].max()
+        assert dev < 1e-10, (trial, dev)
+        assert inl2 == inl and np.array_equal(level_h == 0, marks == 1), trial
+        assert border_h == oracle_lib.pnp.last_borderline == 0, (trial, border_h, oracle_lib.pnp.last_borderline, oracle_lib.pnp.last_min_margin)
+
+
+def _pnp_case(rng, prm, n):
+    X = np.column_stack([rng.uniform(-20, 20, n), rng.uniform(-5, 5, n), rng.uniform(6, 60, n)])
+    ang = rng.normal(0, 0.01, 3)
+    q = np.array([1.0, *(ang / 2)]); q /= np.linalg.norm(q)
+    p_true = rng.normal(0, 0.3, 3)
+    w, x, y, z = q
+    Rm = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                   [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                   [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    Xc = (X - p_true) @ Rm
+    uv = np.column_stack([prm.fx * Xc[:, 0] / Xc[:, 2] + prm.cx, prm.fy * Xc[:, 1] / Xc[:, 2] + prm.cy])
+    uv = np.rint(uv + rng.normal(0, 0.4, uv.shape)).astype(np.float32)
+    uv[::9] += 25.0
+    return X, uv
+
+
+def test_pnp_edge_planted_on_the_chi2_threshold(hip_lib, oracle_lib):
+    """an edge whose squared error sits ON the 5.991 gate: one 3-D point is moved (bisection on the ORACLE's decision) until the oracle's
+    e^2 for that edge is within 1e-9 of the threshold, once just below and once just above.  k_pnp must notice the edge (borderline
+    counter), re-evaluate it in the reference's operation order, and demote / keep exactly what the oracle does on either side."""
+    import lvt_amd
+    rng = np.random.default_rng(11)
+    prm = lvt_amd.kitti_params()
+    q0 = np.array([1.0, 0, 0, 0]); p0 = np.zeros(3)
+    X, uv = _pnp_case(rng, prm, 400)
+    d = np.array([0.0, 1.0, 0.0])                   # the edge's point moves along y: its v-error grows with it
+
+    def oracle_e2(k, s):
+        Xs = X.copy(); Xs[k] += s * d
+        oracle_lib.pnp(prm, q0, p0, Xs, uv)
+        return float((oracle_lib.pnp.last_err[k] ** 2).sum()), Xs
+
+    def closest(k, s):          # how near any gate decision of the oracle came to the threshold with edge k's point moved by s
+        oracle_e2(k, s)
+        return oracle_lib.pnp.last_min_margin
+
+    planted = None
+    for k in (5, 6, 7, 8, 10, 11, 12):              # inlier edges (the gross outliers sit at 0, 9, 18, ...)
+        lo, hi = 0.0, 2.0
+        if not (oracle_e2(k, lo)[0] < 5.991 < oracle_e2(k, hi)[0]):
+            continue
+        for _ in range(200):                        # bisection on "edge k ends above the threshold": converges on the point where one of the
+            mid = 0.5 * (lo + hi)                   # two gates sees its e^2 cross 5.991 (the first gate's flip makes the final error jump)
+            if oracle_e2(k, mid)[0] > 5.991:
+                hi = mid
+            else:
+                lo = mid
+            if hi - lo < 1e-13:
+                break
+        if closest(k, lo) < 1e-9 and closest(k, hi) < 1e-9:
+            planted = (k, lo, hi)
+            break
+    assert planted is not None, "no edge could be planted on the threshold"
+    k, lo, hi = planted
+    kept = []
+    for s in (lo, hi):
+        e2, Xs = oracle_e2(k, s)
+        qo, po, marks, _ = oracle_lib.pnp(prm, q0, p0, Xs, uv)
+        assert oracle_lib.pnp.last_borderline >= 1 and oracle_lib.pnp.last_min_margin < 1e-9
+        qh, ph, inl, calls, err_h, level_h, border_h = hip_lib.pnp_detail(prm, q0, p0, Xs, uv)
+        assert border_h >= 1, "k_pnp did not notice the edge on the threshold"
+        assert np.array_equal(level_h == 0, marks == 1) and inl == int(marks.sum()), (s, e2, level_h[k], marks[k])
+        assert calls == oracle_lib.pnp.last_solve_calls
+        assert np.allclose(ph, po, rtol=0, atol=1e-7) and np.allclose(qh, qo, atol=1e-9)
+        kept.append((int(marks[k]), e2))
+    assert kept[0] != kept[1]       # the two sides really differ: the edge is kept on one side and demoted (or re-estimated) on the other
 
 
 def test_rectify_matches_the_oracle(hip_lib):

@@ -20,6 +20,11 @@ CASES = [
     # second pass (lvt_local_map.cpp:173-199) runs while tracking continues (asserted below)
     ("kitti_sparse_second_pass", "kitti", 3, 1.0, {"max_keypoints_per_cell": 8}, list(range(12))),
     ("kitti_full_long", "kitti", 9, 1.0, {}, list(range(220))),               # staging / promotion / culling at full size over 220 frames
+    # BASELINE.json's sequence LENGTHS (kitti_example.cpp:113-138 walks the whole sequence; cfg 2 has 4 541 frames, cfg 3 3 682, cfg 4 573):
+    # long enough for every slow drift of the map bookkeeping (culling ages, staged promotion, the 3-deep match window) to recur many times
+    ("kitti_full_1000", "kitti", 13, 1.0, {}, list(range(1000))),
+    ("euroc_300", "euroc", 2, 1.0, {}, list(range(300))),
+    ("tum_rgbd_300", "tum", 2, 1.0, {}, list(range(300))),
     ("kitti_always_triangulate", "kitti", 5, 0.5, {"triangulation_policy": 2, "staged_threshold": 0}, list(range(10))),
     ("kitti_map_size_policy", "kitti", 6, 0.5, {"triangulation_policy": 3}, list(range(10))),
     ("euroc", "euroc", 0, 1.0, {}, list(range(10))),                           # configs[2] shape
@@ -43,6 +48,8 @@ def test_sequence_parity(hip_lib, oracle_lib, name, kind, seed, scale, overrides
         assert c["second_pass"] == 1 and hip.get_state() == 2, "the second pass of find_matches was not exercised while TRACKING"
     if name == "kitti_full_long":
         assert hip.get_state() == 2 and c["frame"] == 219
+    if name in ("kitti_full_1000", "euroc_300", "tum_rgbd_300"):
+        assert hip.get_state() == 2 and c["frame"] == len(frames) - 1, (hip.get_state(), c["frame"])
     if name == "tum_rgbd":
         assert c["n_right"] == 0
         # (more map points than one resolver super-chunk holds: the compacted query list and several super-chunks were exercised)
@@ -105,11 +112,15 @@ def test_external_corners(hip_lib, oracle_lib):
         assert np.allclose(th, to, atol=1e-6) and np.allclose(Rh, Ro, atol=1e-6)
 
 
-def test_candidate_lists_longer_than_their_capacity(hip_lib, oracle_lib):
-    """a 28 x 28 block of corners at 1-px spacing (through the external-corner entry point) puts several hundred features inside the
+@pytest.mark.parametrize("binned", ["0", "1"], ids=["wave_per_query_lists", "binned_list_kernel"])
+def test_candidate_lists_longer_than_their_capacity(hip_lib, oracle_lib, monkeypatch, binned):
+    """(both list builders: k_early_map / k_candidates and, forced onto the single handle, k_hamming_batched_lists -- whose lists longer than
+    128 entries only report their length and leave the query to the resolvers' exact path, k_lists.hip)
+    a 28 x 28 block of corners at 1-px spacing (through the external-corner entry point) puts several hundred features inside the
     search window of the map points that project there and 140 into every 5-row band of row_match: candidate lists overflow their
     128 slots, and the resolvers must take their exact wave-wide path for those queries -- in map order, between ordinary super-chunks"""
     from oracle import pyoracle as O
+    monkeypatch.setenv("LVT_AMD_BINNED_LISTS", binned)
     world, prm, sensor = make_case("kitti", 11, 0.5)
     hip = hip_lib.LvtSystem.create(prm, 1)
     orc = O.Oracle(prm, 1)
@@ -127,6 +138,31 @@ def test_candidate_lists_longer_than_their_capacity(hip_lib, oracle_lib):
         assert np.allclose(th, to, atol=1e-6) and np.allclose(Rh, Ro, atol=1e-6)
     assert hip.counts()["n_left"] > 784 and hip.get_state() == orc.status
     assert hip.debug_stamps()[25] > 0, "no map point took the resolver's exact path for over-long lists (bring-up counter of k_early_mid)"
+
+
+@pytest.mark.parametrize("binned", ["0", "1"], ids=["wave_per_query_lists", "binned_list_kernel"])
+def test_more_than_2048_features_per_image(hip_lib, oracle_lib, monkeypatch, binned):
+    """2 600 external corners per image: more than the 2 048 features the binned list kernel holds in its LDS image -- with
+    LVT_AMD_BINNED_LISTS=1 it must stand down for these frames (k_lists.hip: N > 2048) and the wave-per-query kernels behind it build
+    the lists; either way matches, maps and poses are the oracle's"""
+    from oracle import pyoracle as O
+    monkeypatch.setenv("LVT_AMD_BINNED_LISTS", binned)
+    world, prm, sensor = make_case("kitti", 14, 1.0)
+    hip = hip_lib.LvtSystem.create(prm, 1)
+    orc = O.Oracle(prm, 1)
+    rng = np.random.default_rng(14)
+    for i in range(4):
+        a, b = world.render_stereo(i)
+        xl, _, _, _ = O.compute_features(a, prm)
+        xr, _, _, _ = O.compute_features(b, prm)
+        extra = np.stack([rng.integers(40, world.W - 40, 1800), rng.integers(40, world.H - 40, 1800)], axis=1).astype(np.float64)
+        cl = np.vstack([xl.astype(np.float64), extra]); cr = np.vstack([xr.astype(np.float64), extra + [[-8.0, 0.0]]])
+        Ro, to = orc.track_with_external_corners(a, b, cl, cr)
+        Rh, th = hip.track_with_external_corners(a, b, cl, cr)
+        msgs = diff_frame(hip, orc)
+        assert not msgs, f"frame {i}: {msgs[:5]}"
+        assert np.allclose(th, to, atol=1e-6) and np.allclose(Rh, Ro, atol=1e-6)
+    assert 2048 < hip.counts()["n_left"] <= 4096 and hip.get_state() == orc.status == 2
 
 
 def test_more_features_than_capacity_is_reported(hip_lib):

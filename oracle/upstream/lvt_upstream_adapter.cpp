@@ -6,7 +6,7 @@
 // oracle restates them from SURVEY Appendix A and parity stays "unpinned".  This file is what closes that gap the day an
 // environment HAS the libraries: it calls exactly the upstream entry points the reference calls, with the reference's arguments,
 // behind a plain C ABI, so that tests/test_upstream_pin.py can hold the oracle's primitives to them and
-// tests/golden/make_upstream_golden.py can freeze their outputs (incl. the genuine BRIEF test-pair table, recovered by probing)
+// tests/golden/make_upstream_golden.py freezes their outputs (incl. the genuine BRIEF test-pair table, recovered by probing)
 // into committed vectors.  Build: `make -C oracle upstream` (skips with a message when <opencv2/xfeatures2d.hpp> is absent).
 //
 // Entry point                     reference call site                                    upstream API

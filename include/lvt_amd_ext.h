@@ -112,6 +112,7 @@ enum {
     LVT_AMD_C_MAP_SIZE_AT_MATCH, LVT_AMD_C_N_STAGED_ERASED, LVT_AMD_C_N_STAGED_PROMOTED, LVT_AMD_C_N_CULLED,
     LVT_AMD_C_FRAME, LVT_AMD_C_OVERFLOW /* bitmask of capacity overflows, 0 = none */,
     LVT_AMD_C_PNP_BORDERLINE /* chi2-gate decisions of this frame's pose refinement within 1e-8 of the 5.991 threshold */,
+    LVT_AMD_C_ROW_FALLBACK /* 1: the tracking stream built this frame's row-match candidate lists itself (the early stream's were late) */,
     LVT_AMD_C__COUNT = 32
 };
 LVT_API void lvt_amd_get_counts(lvt_handle h, int out[LVT_AMD_C__COUNT]);
@@ -121,6 +122,9 @@ LVT_API int lvt_amd_get_row_matches(lvt_handle h, int *pairs, int cap);
 LVT_API int lvt_amd_get_map(lvt_handle h, double *xyz, int *counter, int *age, uint8_t *desc, int cap);
 LVT_API int lvt_amd_get_staged(lvt_handle h, double *xyz, int *counter, uint8_t *desc, int cap);
 LVT_API void lvt_amd_get_pose(lvt_handle h, double q_wxyz[4], double p[3]);
+/* pose (as the tracker holds it) and state (1 / 2 / 3, -1 on error) of the frame the last tracking call returned; unlike lvt_amd_get_pose and
+   lvt_get_status it does not wait for that frame's tail (staged update, triangulation) when the call returned on the early pose */
+LVT_API int lvt_amd_get_last_pose(lvt_handle h, double q_wxyz[4], double p[3]);
 LVT_API void lvt_amd_get_predicted_pose(lvt_handle h, double q_wxyz[4], double p[3]);
 /* bring-up profiling: cycle stamps written by detection cell 0 of the left image */
 LVT_API void lvt_amd_get_debug(lvt_handle h, long long out[32]);

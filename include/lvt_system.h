@@ -244,12 +244,17 @@ class lvt_system {
         lvt_destroy(s->m_handle);
         delete s;
     }
-    void reset() { lvt_amd_reset(m_handle); } /* lvt_system.cpp:44-68 */
+    void reset() { lvt_amd_reset(m_handle); m_state = -1; } /* lvt_system.cpp:44-68 */
 
     /* stereo: two rectified 8-bit gray images; RGB-D: gray + 32-bit float depth in metres (lvt_system.cpp:157-207).
      * Returns the camera-to-world pose of the left camera in the first frame's left-camera frame; after LOST, the last pose. */
     lvt_pose track(const lvt_image_view &img1, const lvt_image_view &img2) {
         double R[3][3], t[3];
+        if (img2.rows != img1.rows || img2.cols != img1.cols || img1.elem_size != 1 || img2.elem_size != (m_sensor == eSensor_STEREO ? 1 : 4)) {
+            /* the C-ABI is told ONE size for both planes: a second plane of another size (or element type) would be read out of bounds.
+               The reference would throw inside OpenCV here and lvt_c.cpp:85-87 swallows that: same outcome, the last pose */
+            return current_pose();
+        }
         const unsigned char *a = static_cast<const unsigned char *>(packed(img1, m_buf1));
         if (m_sensor == eSensor_STEREO) lvt_track(m_handle, const_cast<unsigned char *>(a), const_cast<unsigned char *>(static_cast<const unsigned char *>(packed(img2, m_buf2))), img1.rows, img1.cols, R, t);
         else lvt_amd_track_rgbd(m_handle, a, static_cast<const float *>(packed(img2, m_buf2)), img1.rows, img1.cols, R, t);
@@ -278,7 +283,8 @@ class lvt_system {
 #endif
 
     inline lvt_system::eSensor get_sensor_type() const { return m_sensor; }
-    inline lvt_system::eState get_state() const { return (eState)lvt_get_status(m_handle); }
+    /* the state of the frame track() returned last -- delivered with its pose, no further wait (lvt_get_status collects the whole frame) */
+    inline lvt_system::eState get_state() const { return (eState)(m_state > 0 ? m_state : lvt_get_status(m_handle)); }
     inline bool should_quit() const { return false; } /* (set by the reference's Pangolin viewer only; there is none here) */
     /* additive: the text of the last problem the GPU path reported ("" when none) -- the reference has no error channel */
     inline const char *last_error() const { return lvt_amd_last_error(m_handle); }
@@ -300,13 +306,14 @@ class lvt_system {
         return buf.data();
     }
     /* the pose as the tracker holds it (the quaternion g2o's SBACam hands back, lvt_pnp_solver.cpp:120-122), not one re-derived from R */
-    lvt_pose current_pose() const {
-        double q[4], p[3];
-        lvt_amd_get_pose(m_handle, q, p);
+    lvt_pose current_pose() {
+        double q[4] = {1, 0, 0, 0}, p[3] = {0, 0, 0};
+        m_state = lvt_amd_get_last_pose(m_handle, q, p); /* (does not wait for the frame's tail: the next track() overlaps it) */
         return lvt_pose(lvt_vector3(p[0], p[1], p[2]), lvt_quaternion(q[0], q[1], q[2], q[3]));
     }
 
     lvt_handle m_handle;
+    int m_state = -1;
     eSensor m_sensor;
     lvt_parameters m_params;
     std::vector<unsigned char> m_buf1, m_buf2;

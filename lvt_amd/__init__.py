@@ -27,7 +27,7 @@ ABI_SYMBOLS = [
     "lvt_amd_track_rgbd", "lvt_amd_track_device", "lvt_amd_track_device_async", "lvt_amd_wait",
     "lvt_amd_set_stream", "lvt_amd_last_error", "lvt_amd_get_counts", "lvt_amd_get_features",
     "lvt_amd_get_matches", "lvt_amd_get_row_matches", "lvt_amd_get_map", "lvt_amd_get_staged",
-    "lvt_amd_get_pose", "lvt_amd_get_predicted_pose", "lvt_amd_get_plane", "lvt_amd_pnp", "lvt_amd_pnp_detail",
+    "lvt_amd_get_pose", "lvt_amd_get_last_pose", "lvt_amd_get_predicted_pose", "lvt_amd_get_plane", "lvt_amd_pnp", "lvt_amd_pnp_detail",
     "lvt_amd_hamming_match_batched", "lvt_amd_hamming_match_batched_n", "lvt_amd_rectifier_create", "lvt_amd_rectifier_destroy",
     "lvt_amd_rectify_device", "lvt_amd_rectify", "lvt_amd_rectifier_get_maps",
     "lvt_amd_odometry_create", "lvt_amd_odometry_destroy", "lvt_amd_odometry_reset", "lvt_amd_odometry_push_pose", "lvt_amd_odometry_update", "lvt_amd_profile_enable", "lvt_amd_profile_read", "lvt_amd_get_debug", "lvt_amd_get_timeline", "lvt_amd_get_ordering",
@@ -38,7 +38,7 @@ ABI_SYMBOLS = [
 N_COUNTS = 32
 COUNT_NAMES = ["n_left", "n_right", "map_size", "staged_size", "n_matches", "second_pass", "n_row_matches",
                "n_triangulated", "triangulated", "retry_left", "retry_right", "pnp_iters", "pnp_inliers",
-               "map_size_at_match", "n_staged_erased", "n_staged_promoted", "n_culled", "frame", "overflow", "pnp_borderline"]
+               "map_size_at_match", "n_staged_erased", "n_staged_promoted", "n_culled", "frame", "overflow", "pnp_borderline", "row_fallback"]
 
 eState_NOT_INITIALIZED, eState_TRACKING, eState_LOST = 1, 2, 3
 eSensor_STEREO, eSensor_RGBD = 1, 2
@@ -94,6 +94,7 @@ def load_library():
     L.lvt_amd_get_map.argtypes = [vp, vp, vp, vp, vp, C.c_int]
     L.lvt_amd_get_staged.argtypes = [vp, vp, vp, vp, C.c_int]
     L.lvt_amd_get_pose.argtypes = [vp, vp, vp]
+    L.lvt_amd_get_last_pose.argtypes = [vp, vp, vp]
     L.lvt_amd_get_predicted_pose.argtypes = [vp, vp, vp]
     L.lvt_amd_get_plane.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp]
     L.lvt_amd_pnp.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]

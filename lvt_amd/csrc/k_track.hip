@@ -366,7 +366,17 @@ __global__ __launch_bounds__(256) void k_match_map(SeqArg<BV> sa, int par, seq_t
     if (gated) {
         if (threadIdx.x == 0 && blockIdx.x == 0) ctl.dbg[38] = (long long)wall_clock64();  // (timeline: the wait starts)
         if (blockIdx.x == 0 && prev_rec) deliver_record(ctl, prev_rec, prev_done, seq - 1, 256);
-        if (threadIdx.x == 0) gate_late_poll(ctl, *S.fb[par].fc, seq);
+        // ONE decision per frame: workgroup 0 waits for the early stream and the features, decides whether the frame is skipped and counts
+        // the time-outs; the other workgroups wait for its verdict (they are co-resident: 16 workgroups) -- each polling on its own, two
+        // workgroups could have disagreed about `skip` at the 2-s boundary
+        if (threadIdx.x == 0) {
+            if (blockIdx.x == 0) {
+                gate_late_poll(ctl, *S.fb[par].fc, seq);
+                __hip_atomic_store(&ctl.late_gate_seq, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            } else {
+                while (__hip_atomic_load(&ctl.late_gate_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) __builtin_amdgcn_s_sleep(8);
+            }
+        }
     }
     if (threadIdx.x == 0 && blockIdx.x == 0) ctl.dbg[40] = (long long)wall_clock64();  // (timeline: the frame's work starts)
     __shared__ int s_skip;
@@ -1793,6 +1803,7 @@ __device__ __forceinline__ void pnp_solve(const Params &prm, const Pose &prior, 
 // tail (staged update, triangulation: ~30 us that change the map, not the pose) finishes behind the caller's next upload
 struct PoseRec {
     double R[9], t[3];
+    double q[4], p[3];  // the same pose as the tracker holds it (quaternion w, x, y, z + position): lvt_amd_get_last_pose
     int status, pad;
 };
 template <bool BV>
@@ -1831,6 +1842,8 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(SeqArg<BV> sa, int par, seq
             PoseRec &o = pose_out[blockIdx.z];
             for (int k = 0; k < 9; k++) o.R[k] = ctl.out_R[k];
             for (int k = 0; k < 3; k++) o.t[k] = ctl.out_t[k];
+            for (int k = 0; k < 4; k++) o.q[k] = res.q[k];
+            for (int k = 0; k < 3; k++) o.p[k] = res.p[k];
             o.status = 2;
             __threadfence_system();
             __hip_atomic_store(&pose_done[blockIdx.z], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -2103,8 +2116,8 @@ __global__ __launch_bounds__(1024) void k_triangulate(SeqArg<BV> sa, int par, se
             if (tid == 0) {
                 FeatCtl &fc = *S.fb[par].fc;
                 const unsigned long long t0 = wall_clock64();
-                int fb = 0;
-                while (__hip_atomic_load(&fc.row_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+                int fb = (row_gated == 2) ? 1 : 0;  // (2: tests force the fallback -- it then runs beside the early stream's list kernel)
+                while (!fb && __hip_atomic_load(&fc.row_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
                     __builtin_amdgcn_s_sleep(8);
                     if (wall_clock64() - t0 > 500000ull) {
                         atomicAdd(&ctl.gate_timeouts, 1);
@@ -2112,6 +2125,7 @@ __global__ __launch_bounds__(1024) void k_triangulate(SeqArg<BV> sa, int par, se
                         break;
                     }
                 }
+                if (fb) ctl.counts[C_ROW_FALLBACK] = 1;
                 s_row_fallback = fb;
             }
             __syncthreads();

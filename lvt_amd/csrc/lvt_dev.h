@@ -28,7 +28,8 @@ enum : int { OVF_RAW = 1, OVF_CELL_OUT = 2, OVF_FEATURES = 4, OVF_MAP = 8, OVF_S
 enum : int {
     C_N_LEFT = 0, C_N_RIGHT, C_MAP_SIZE, C_STAGED_SIZE, C_N_MATCHES, C_SECOND_PASS, C_N_ROW_MATCHES,
     C_N_TRIANGULATED, C_TRIANGULATED, C_RETRY_LEFT, C_RETRY_RIGHT, C_PNP_ITERS, C_PNP_INLIERS,
-    C_MAP_SIZE_AT_MATCH, C_N_STAGED_ERASED, C_N_STAGED_PROMOTED, C_N_CULLED, C_FRAME, C_OVERFLOW, C_PNP_BORDERLINE
+    C_MAP_SIZE_AT_MATCH, C_N_STAGED_ERASED, C_N_STAGED_PROMOTED, C_N_CULLED, C_FRAME, C_OVERFLOW, C_PNP_BORDERLINE,
+    C_ROW_FALLBACK  // (HIP path only) k_triangulate built the row-match lists itself: the early stream's were late (or the test knob is set)
 };
 
 // constants of the reference -- lvt/src/lvt_definitions.h:29-34
@@ -89,6 +90,7 @@ struct Ctl {
     // time-out: an early kernel that arrives later finds the claim taken and does nothing)
     seq_t early_state;
     seq_t track_done_seq;  // last frame whose tracking chain has finished with its feature buffer (polled by k_gate_buf)
+    seq_t late_gate_seq;   // k_match_map's folded gate: workgroup 0 ALONE waits, decides (skip / time-outs) and publishes the frame here; the others poll it
     int gate_timeouts;  // a gate gave up waiting and its stream stood down / cancelled (results unaffected)
     int gate_fatal;     // a stream waited 2 s for data it cannot do without: the frame was SKIPPED (last pose returned, state kept)
     int skip;           // set by the tracking stream's gate for the frame it is about to start: its features never arrived; consumed

@@ -151,6 +151,8 @@ struct Context {
     // kernels -- required under tools that serialise the dispatches of all queues (rocprofv3 --pmc): a polling gate then holds
     // the only dispatch slot while what it waits for cannot start.
     bool events_only = false;
+    bool force_row_fallback = false;  // LVT_AMD_TEST_ROW_FALLBACK=1 (tests): k_triangulate does not wait for the early stream's row lists, it builds them itself
+                                      // WHILE the early stream's kernel writes the same words -- the situation its 5-ms time-out leads to
     hipEvent_t ev_feat[NPAR] = {};
     hipEvent_t ev_depth = nullptr;  // RGB-D host-buffer calls: the depth plane is pulled on the early stream beside the feature kernels; k_gather waits for it
     bool depth_wait = false;
@@ -386,6 +388,7 @@ static void reset_state(Context *c) {  // lvt_system::reset (lvt_system.cpp:44-6
         z.pnp_seq = (seq_t)c->enq;  // the next frame's gate waits for this value: nothing is pending
         z.early_state = 4u * (seq_t)c->enq + 3u;
         z.track_done_seq = (seq_t)c->enq;
+        z.late_gate_seq = (seq_t)c->enq;
         HIPCHK(c, hipMemcpyAsync(c->d_ctl[s], &z, sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->h_seqs[s].map_n, 0, sizeof(int), c->stream));
         HIPCHK(c, hipMemsetAsync(c->h_seqs[s].map_cur, 0, sizeof(int), c->stream));
@@ -445,6 +448,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         if (const char *e = std::getenv("LVT_AMD_SYNC_TAIL")) c->early_pose = std::strcmp(e, "wait") != 0;
         c->binned_lists = B > 1;
         if (const char *e = std::getenv("LVT_AMD_BINNED_LISTS")) c->binned_lists = std::atoi(e) != 0;
+        if (const char *e = std::getenv("LVT_AMD_TEST_ROW_FALLBACK")) c->force_row_fallback = std::atoi(e) != 0;
         HIPCHK(c, hipHostMalloc((void **)&c->h_fargs, sizeof(FrameArgs) * B * RING, hipHostMallocDefault));
         c->h_seqs.resize(B);
         c->d_ctl.resize(B);
@@ -689,7 +693,7 @@ static void enqueue_frame(Context *c) {
     if (p.staged_th > 0)  // (a configuration without staging -- EuRoC, TUM -- never has staged points to list)
         LAUNCH_SM(16, st, k_candidates, MODE_STAGED, dim3(64, 1, B), dim3(256), 0, 0, par, (seq_t)0, 0);
     LAUNCH_S(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, par, seq, c->h_ctl_dev + (size_t)slot * B,
-           c->h_done_dev + (size_t)slot * B, evo ? 0 : 1, (evo || c->sync_call) ? 1 : 0);
+           c->h_done_dev + (size_t)slot * B, evo ? 0 : (c->force_row_fallback ? 2 : 1), (evo || c->sync_call) ? 1 : 0);
     if (evo || c->sync_call) c->delivered = c->enq + 1;
     if (evo) (void)hipEventRecord(c->ev_done[slot], st);  // (events-only ordering: the feature stream's barrier needs it)
     c->enq++;
@@ -1309,6 +1313,27 @@ LVT_API int lvt_amd_get_staged(lvt_handle h, double *xyz, int *counter, uint8_t 
         drain(c);
         const Seq &S = c->h_seqs[0];
         return get_points(c, S.staged, S.staged_cur, S.staged_n, xyz, counter, nullptr, desc, cap);
+    } catch (...) {
+    }
+    return -1;
+}
+// pose + state of the frame the last tracking call returned, WITHOUT waiting for that frame's tail: a synchronous call that returned on
+// the pose k_pnp handed over reads it from the same pinned record (quaternion as the tracker holds it, not re-derived from R)
+LVT_API int lvt_amd_get_last_pose(lvt_handle h, double q[4], double p[3]) {
+    Context *c = static_cast<Context *>(h);
+    if (!c) return -1;
+    if (c->early_pending && c->enq > 0) {
+        const PoseRec &r = c->h_pose[(size_t)((c->enq - 1) % RING) * c->B];
+        for (int k = 0; k < 4; k++) q[k] = r.q[k];
+        for (int k = 0; k < 3; k++) p[k] = r.p[k];
+        return r.status;
+    }
+    DeviceGuard guard(c);
+    try {
+        drain(c);
+        for (int k = 0; k < 4; k++) q[k] = last_ctl(c).last_pose.q[k];
+        for (int k = 0; k < 3; k++) p[k] = last_ctl(c).last_pose.p[k];
+        return last_ctl(c).state;
     } catch (...) {
     }
     return -1;

@@ -69,6 +69,22 @@ def test_binned_list_kernel_on_a_single_handle(hip_lib, oracle_lib, monkeypatch,
     assert not bad, f"{name}: first divergence at frame {bad[0][0]}: {bad[0][1][:6]}"
 
 
+@pytest.mark.parametrize("binned", ["0", "1"], ids=["wave_per_query_lists", "binned_list_kernel"])
+def test_row_lists_built_twice_at_once(hip_lib, oracle_lib, monkeypatch, binned):
+    """k_triangulate's fallback for late row-match lists (the early stream's gate stood down: 5-ms time-out) builds the lists itself --
+    possibly WHILE the early stream's kernel, arriving late, writes the same words.  LVT_AMD_TEST_ROW_FALLBACK=1 forces exactly that on every
+    triangulation frame (no wait, both producers run): row pairs, maps and poses must stay the oracle's, with either list kernel on the
+    early stream."""
+    monkeypatch.setenv("LVT_AMD_TEST_ROW_FALLBACK", "1")
+    monkeypatch.setenv("LVT_AMD_BINNED_LISTS", binned)
+    monkeypatch.setenv("LVT_AMD_ORDERING", "polling")
+    world, prm, sensor = make_case("kitti", 15, 1.0, {"triangulation_policy": 2, "staged_threshold": 0})   # triangulate on every frame
+    res, hip, orc = run_sequence(world, prm, sensor, range(10))
+    bad = [(i, m) for i, m, _, _ in res if m]
+    assert not bad, f"first divergence at frame {bad[0][0]}: {bad[0][1][:6]}"
+    assert hip.counts()["row_fallback"] == 1 and hip.counts()["n_row_matches"] > 0
+
+
 def test_second_pass_and_lost_latch(hip_lib, oracle_lib):
     """a scene cut: the doubled-radius pass runs, then tracking is LOST and stays lost (lvt_system.cpp:161-166)"""
     world, prm, sensor = make_case("kitti", 7, 0.5, {"min_num_matches_for_tracking": 60})

@@ -180,7 +180,7 @@ class HipBackend:
         out["tracking_last_frame"] = {"features_left": c["n_left"], "map_size": c["map_size"], "matches": c["n_matches"]}
         legs = [("kernels", self._leg_kernels), ("roofline", self._leg_roofline)]
         if env.world_size == 1:  # reported at N = 1 only (rank 0's host cores / one GPU to itself)
-            legs += [("sync", self._leg_sync), ("batch", self._leg_batch), ("configs", self._leg_configs)]
+            legs += [("sync", self._leg_sync), ("batch", self._leg_batch), ("lists_ab", self._leg_lists_ab), ("configs", self._leg_configs)]
             if not args.no_cpu:
                 legs += [("cpu", lambda a: self._leg_cpu(a, warm, poses))]
         for name, fn in legs:
@@ -360,35 +360,111 @@ class HipBackend:
                        "say which way every plane went); track_device = images already in HBM")
         return {"sync": res}
 
-    def _leg_batch(self, args):
-        """S sequences in lock-step on this GPU (lvt_amd_batch_*)"""
-        S, n = args.batch_seqs, args.batch_frames
-        if S <= 1 or n <= 4:
-            return {}
-        worlds = [self.make_world("kitti", seed=100 + s) for s in range(S)]
-        fr, H, W, pitch = self._render(worlds, n)
+    def _batch_run(self, fr, S, n, H, W, pitch, profile=False):
+        """S sequences in lock-step over frames [0, n) of fr[:S]; returns (seconds of the timed part, frames not TRACKING, error, handle's
+        per-kernel profile or None, counts of the last frame per sequence)"""
         vo = self.lvt.LvtBatch(self.prm, S)
         lp = [[fr[s, i, 0].data_ptr() for s in range(S)] for i in range(n)]
         rp = [[fr[s, i, 1].data_ptr() for s in range(S)] for i in range(n)]
         wm = 4
         for i in range(wm):
             vo.track_device_async(lp[i], rp[i], H, W, pitch); vo.wait()
+        if profile:
+            vo.profile_enable(True)
         self.sync()
         t0 = time.perf_counter()
         inflight, bad = 0, 0
+        depth = 1 if profile else 2
         for i in range(wm, n):
             vo.track_device_async(lp[i], rp[i], H, W, pitch); inflight += 1
-            if inflight >= 2:
+            if inflight >= depth:
                 bad += int((vo.wait()[2] != 2).sum()); inflight -= 1
         while inflight:
             bad += int((vo.wait()[2] != 2).sum()); inflight -= 1
         self.sync()
         dt = time.perf_counter() - t0
+        prof = vo.profile_read() if profile else None
+        cnt = [vo.counts(s) for s in range(S)]
         err = vo.last_error()
         vo.close()
+        return dt, bad, err, prof, cnt
+
+    def _leg_batch(self, args):
+        """S sequences in lock-step on this GPU (lvt_amd_batch_*): the headline batch size, a sweep over batch sizes, and the pipeline's
+        OWN matcher launches (k_hamming_batched_lists, the list-emitting form of the binned matcher) against the HBM roof at 64 sequences"""
+        S0, n = args.batch_seqs, args.batch_frames
+        if S0 <= 1 or n <= 4:
+            return {}
+        sweep_sizes = sorted(set([12, 16, 24, 32, S0]))
+        Smax = max(sweep_sizes + [64])
+        worlds = [self.make_world("kitti", seed=100 + s) for s in range(Smax)]
+        fr, H, W, pitch = self._render(worlds, n)
+        out = {}
+        sweep = []
+        for S in sweep_sizes:
+            dt, bad, err, _, _ = self._batch_run(fr, S, n, H, W, pitch)
+            row = {"seqs": S, "frames_each": n - 4, "fps": round(S * (n - 4) / dt, 1), "ms_per_lockstep_frame": round(1e3 * dt / (n - 4), 4),
+                   "frames_not_tracking": bad, "error": err}
+            sweep.append(row)
+            if S == S0:
+                out["batch"] = row
+        out["batch_sweep"] = sweep
+        # the matcher ON THE PIPELINE'S PATH: per-launch HIP-event time of the list kernels in a 64-sequence lock-step batch (profiling
+        # serialises the frame: one frame in flight), algorithmic bytes from the per-sequence counts of the last frame
+        m = min(n, 16)
+        dt, bad, err, prof, cnt = self._batch_run(fr, 64, m, H, W, pitch, profile=True)
+        rows = {}
+        for name, ms, calls in prof:
+            if "k_hamming_batched_lists" in name and calls:
+                rows[name] = 1e3 * ms / calls
+        b_map = float(sum(bmatch(c["map_size_at_match"], c["n_left"]) for c in cnt))
+        b_row = float(sum(bmatch(c["n_left"], c["n_right"]) for c in cnt))
+        pm = {}
+        for name, us in rows.items():
+            byts = b_row if "(row)" in name else b_map
+            ach = byts / (us * 1e-6) / 1e9
+            pm[name] = {"avg_us": round(us, 2), "algorithmic_bytes_per_launch": round(byts), "achieved": round(ach, 1), "frac": round(ach / HBM_PEAK_GBS, 5)}
+        if pm:
+            dom = max(pm, key=lambda k: pm[k]["avg_us"])
+            out["roofline_pipeline_matcher"] = {
+                "kernel": "lvt::k_hamming_batched_lists<2 (row) / 0 (map), false> -- what a lock-step batch launches for find_match_index / row_match",
+                "bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "sequences": 64, "dominant": dom, "achieved": pm[dom]["achieved"],
+                "frac": pm[dom]["frac"], "traffic": None, "launches": pm, "frames_not_tracking": bad, "error": err,
+                "note": "64 KITTI-shaped problems per launch (one workgroup per sequence, two for the row lists): 64 x ~100 KB is latency-bound "
+                        "work on 64 / 128 of 256 CUs -- the roofline fraction of the batched matcher proper (`roofline`) needs thousands of problems"}
         del fr
-        return {"batch": {"seqs": S, "frames_each": n - wm, "fps": round(S * (n - wm) / dt, 1), "ms_per_lockstep_frame": round(1e3 * dt / (n - wm), 4),
-                          "frames_not_tracking": bad, "error": err}}
+        return out
+
+    def _leg_lists_ab(self, args):
+        """single handle, asynchronous pipeline: the wave-per-query list kernels (default) against the binned list kernel forced onto
+        the handle (LVT_AMD_BINNED_LISTS=1, read at creation) on the same frames"""
+        n = min(self.n_frames, 220)
+        if n < 40:
+            return {}
+        res = {}
+        for tag, env in (("wave_per_query", "0"), ("binned_lists", "1")):
+            os.environ["LVT_AMD_BINNED_LISTS"] = env
+            try:
+                vo = self.lvt.LvtSystem.create(self.prm, 1)
+            finally:
+                os.environ.pop("LVT_AMD_BINNED_LISTS", None)
+            for i in range(10):
+                l, r = self._ptrs(i)
+                vo.track_device(l, r, self.H, self.W, self.pitch)
+            self.sync()
+            t0 = time.perf_counter()
+            inflight, bad = 0, 0
+            for i in range(10, n):
+                l, r = self._ptrs(i)
+                vo.track_device_async(l, r, self.H, self.W, self.pitch); inflight += 1
+                if inflight >= 4:
+                    bad += 0 if vo.wait_status()[2] == 2 else 1; inflight -= 1
+            while inflight:
+                bad += 0 if vo.wait_status()[2] == 2 else 1; inflight -= 1
+            dt = time.perf_counter() - t0
+            res[tag] = {"fps": round((n - 10) / dt, 1), "frames_not_tracking": bad}
+            vo.close()
+        return {"single_handle_list_kernels": res}
 
     def _leg_configs(self, args):
         """BASELINE.json configs[2] / configs[3] shapes, synchronous calls (ms per frame), every frame checked TRACKING"""
@@ -511,7 +587,7 @@ def parse_args(argv=None):
     ap.add_argument("--config-frames", type=int, default=60)
     ap.add_argument("--total-seqs", type=int, default=0, help="track this many sequences in all: ceil(T / gpus) per GPU in lock-step (cfg 5 with T = 8 on fewer than 8 GPUs)")
     ap.add_argument("--backend", default="hip", choices=["hip", "standin"], help="standin: sleeps instead of GPU work (CPU test of the multi-rank launch path)")
-    ap.add_argument("--skip", default="", help="comma-separated side legs to skip: kernels,roofline,sync,batch,configs,cpu")
+    ap.add_argument("--skip", default="", help="comma-separated side legs to skip: kernels,roofline,sync,batch,lists_ab,configs,cpu")
     args = ap.parse_args(argv)
     args.skip = [s for s in args.skip.split(",") if s]
     return args

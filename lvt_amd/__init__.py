@@ -374,6 +374,11 @@ class LvtBatch:
     def last_error(self) -> str:
         return load_library().lvt_amd_last_error(self._h).decode()
 
+    def profile_enable(self, on: bool = True):
+        load_library().lvt_amd_profile_enable(self._h, 1 if on else 0)
+
+    profile_read = LvtSystem.profile_read
+
 
 def pnp(params: LvtParameters, q_in, p_in, pts, obs):
     """stage entry: motion-only BA on caller data (reference lvt_pnp_solver.cpp:60-128)"""

@@ -114,7 +114,20 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par)
     if (BEGIN && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) feat_begin(S, fa, par);
     if (eye == 1 && S.prm.sensor == 2) return;
     const int W = S.prm.W, H = S.prm.H;
-    const int x0 = blockIdx.x * TS_W, y0 = blockIdx.y * TS_H;
+    // workgroups go to the 8 XCDs round-robin by their linear id and every XCD has its own L2: with the plain mapping the four neighbours of a
+    // tile -- which share its halo rows and its 128-byte lines -- sit on other XCDs, and an image was fetched 2.9 times (rocprofv3 FETCH_SIZE
+    // 2.7 MB per stereo pair).  When a plane's tile count is a multiple of 8, XCD x takes the tiles [x n/8, (x + 1) n/8) of the row-major
+    // order: a band of whole tile rows, whose lines are pulled into ONE L2.
+    int bx = blockIdx.x, by = blockIdx.y;
+    {
+        const int n_tiles = gridDim.x * gridDim.y;
+        if ((n_tiles & 7) == 0) {
+            const int lid = blockIdx.x + gridDim.x * blockIdx.y;
+            const int t = (lid & 7) * (n_tiles >> 3) + (lid >> 3);
+            bx = t % gridDim.x, by = t / gridDim.x;
+        }
+    }
+    const int x0 = bx * TS_W, y0 = by * TS_H;
     if (x0 >= W || y0 >= H) return;
     const uint8_t *img = BEGIN ? fa.img[eye] : FB.img[eye];
     const int pitch = BEGIN ? fa.img_pitch : FB.img_pitch;
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par)
         const int incl = row16_incl_scan(nc | (ncl << 8));
         const int excl = (incl & 0xFF) - nc;
         if (gy < H) {
-            const size_t seg = (size_t)gy * gridDim.x + blockIdx.x;
+            const size_t seg = (size_t)gy * gridDim.x + bx;
             uint32_t *dst = FB.seg_keys[eye] + seg * TS_W + excl;
 #pragma unroll
             for (int k = 0; k < 4; k++)
@@ -1608,8 +1621,18 @@ __global__ __launch_bounds__(256) void k_brief(SeqArg<BV> sa, const Seq *seqs, i
         cy = (int)((double)F.by[i] + 0.5), cx = (int)((double)F.bx[i] + 0.5);
     };
     auto inside = [&](int cy, int cx) { return cx - BR_R >= 0 && cx + BR_R < W && cy - BR_R >= 0 && cy + BR_R < H; };
-    const int stride = gridDim.x * wpb;
+    // (a single sequence: 2 planes, so the plane-per-XCD mapping above does not apply and every XCD would sample windows all over both
+    //  planes -- 5.4 MB fetched for 1.9 MB of box sums.  The key points are stored in detection-cell order: XCD x takes the x-th EIGHTH of
+    //  them, i.e. the windows of about one cell and a quarter, and its L2 pulls that part of the plane only.)
+    int stride = gridDim.x * wpb;
     int i = bx * wpb + wave_id();
+    int i_end = n;
+    if ((planes & 7) != 0 && (gridDim.x & 7) == 0) {
+        const int eighth = (n + 7) >> 3, x = bx & 7;   // (planes are whole multiples of gridDim.x workgroups: bx & 7 is this workgroup's XCD)
+        stride = (gridDim.x >> 3) * wpb;
+        i = x * eighth + (bx >> 3) * wpb + wave_id();
+        i_end = min(n, (x + 1) * eighth);
+    }
     uint32_t v[BR_LOADS];
     int cy = 0, cx = 0;
     bool fast = false;
@@ -1620,17 +1643,17 @@ __global__ __launch_bounds__(256) void k_brief(SeqArg<BV> sa, const Seq *seqs, i
 #pragma unroll
         for (int k = 0; k < BR_LOADS; k++) v[k] = src[goff[k]];
     };
-    if (i < n) {
+    if (i < i_end) {
         centre(i, cy, cx);
         fast = inside(cy, cx);
         if (fast) fetch(cy, cx);
     }
-    for (; i < n; i += stride) {
+    for (; i < i_end; i += stride) {
         uint64_t word[4];
         const int inext = i + stride;
         int ncy = 0, ncx = 0;
         bool nfast = false;
-        if (inext < n) {
+        if (inext < i_end) {
             centre(inext, ncy, ncx);
             nfast = inside(ncy, ncx);
         }

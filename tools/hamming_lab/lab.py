@@ -11,7 +11,7 @@ ap.add_argument("B", nargs="?", type=int, default=8192)
 ap.add_argument("--instance", default="k_hamming_batched<0, 3, 1, 2>")
 ap.add_argument("--has-b", action="store_true")
 ap.add_argument("--build-only", action="store_true")
-ap.add_argument("--ref", default=os.path.join(ROOT, "_old", "lvt_amd", "lib", "liblvt_c.so"))
+ap.add_argument("--ref", default=os.path.join(ROOT, "lvt_amd", "lib", "liblvt_c.so"), help="library whose matcher output is the reference (default: the shipped one)")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--stop", type=int, default=0)
 ap.add_argument("--timeline", action="store_true", help="per-workgroup (start, end, CU) records: slot occupancy and gaps")

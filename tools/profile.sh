@@ -7,14 +7,14 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_*
-BENCH="python $ROOT/bench.py --steps 400 --warmup 20 --skip kernels,sync,batch,configs,cpu"
+BENCH="python $ROOT/bench.py --steps 400 --warmup 20 --skip kernels,sync,batch,lists_ab,configs,cpu"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_trace -o bench -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_batch -o bench -- python $ROOT/bench.py --steps 100 --warmup 10 --seqs-per-gpu 16 --depth 2 > $OUT/bench_batch16_under_rocprof.json 2> /dev/null
 # PMC: separate passes, counters only (no trace domains) -- FETCH_SIZE and WRITE_SIZE cannot share a pass
 # (counter collection serialises the dispatches of all queues: the pipeline must not use its polling gates -> LVT_AMD_ORDERING=events;
 #  the timeout only guards the box)
-LVT_AMD_ORDERING=events timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -o bench -- python $ROOT/bench.py --steps 60 --warmup 5 --skip kernels,sync,batch,configs,cpu > $OUT/bench_under_pmc.json 2>&1
-LVT_AMD_ORDERING=events timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -o bench -- python $ROOT/bench.py --steps 60 --warmup 5 --skip kernels,sync,batch,configs,cpu > /dev/null 2>&1
+LVT_AMD_ORDERING=events timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -o bench -- python $ROOT/bench.py --steps 60 --warmup 5 --skip kernels,sync,batch,lists_ab,configs,cpu > $OUT/bench_under_pmc.json 2>&1
+LVT_AMD_ORDERING=events timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -o bench -- python $ROOT/bench.py --steps 60 --warmup 5 --skip kernels,sync,batch,lists_ab,configs,cpu > /dev/null 2>&1
 python - "$OUT" <<'PY'
 import csv, sys, glob, collections
 out = sys.argv[1]

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     int *s_hist = s_scan + 16;
 
     int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int dbg_b = (int)gridDim.x / 2 + ((a.B > 8 * (int)gridDim.x) ? 8 * (int)gridDim.x : 0);  // a problem in the steady state
+    const int dbg_b = (int)gridDim.x / 2 + ((a.B > (int)gridDim.x) ? (int)gridDim.x : 0);  // a problem in the steady state
 #define LVT_STAMP(i) if (dbg_on && tid == 0) a.dbg[i] = clock64();
 
     // coordinates and flags of "my" train features, coordinates of my queries: all in flight at once

@@ -151,6 +151,7 @@ struct Context {
     // kernels -- required under tools that serialise the dispatches of all queues (rocprofv3 --pmc): a polling gate then holds
     // the only dispatch slot while what it waits for cannot start.
     bool events_only = false;
+    int match_blocks_batch = 256;  // workgroups per sequence of a batch's k_match_map (LVT_AMD_MATCH_BLOCKS_BATCH)
     bool force_row_fallback = false;  // LVT_AMD_TEST_ROW_FALLBACK=1 (tests): k_triangulate does not wait for the early stream's row lists, it builds them itself
                                       // WHILE the early stream's kernel writes the same words -- the situation its 5-ms time-out leads to
     hipEvent_t ev_feat[NPAR] = {};
@@ -449,6 +450,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         c->binned_lists = B > 1;
         if (const char *e = std::getenv("LVT_AMD_BINNED_LISTS")) c->binned_lists = std::atoi(e) != 0;
         if (const char *e = std::getenv("LVT_AMD_TEST_ROW_FALLBACK")) c->force_row_fallback = std::atoi(e) != 0;
+        if (const char *e = std::getenv("LVT_AMD_MATCH_BLOCKS_BATCH")) c->match_blocks_batch = std::max(1, std::min(256, std::atoi(e)));
         HIPCHK(c, hipHostMalloc((void **)&c->h_fargs, sizeof(FrameArgs) * B * RING, hipHostMallocDefault));
         c->h_seqs.resize(B);
         c->d_ctl.resize(B);
@@ -681,7 +683,7 @@ static void enqueue_frame(Context *c) {
             LAUNCH_S(8, st, k_match_map, dim3(MATCH_BLOCKS_GATED, 1, 1), dim3(256), 0, par, seq, 1, prec, pdone);
         } else {
             LAUNCH_S(7, st, k_gate_late, dim3(1, 1, B), dim3(64), 0, par, seq, prec, pdone);
-            LAUNCH_S(8, st, k_match_map, dim3(256, 1, B), dim3(256), 0, par, seq, 0, (Ctl *)nullptr, (seq_t *)nullptr);
+            LAUNCH_S(8, st, k_match_map, dim3(B > 1 ? c->match_blocks_batch : 256, 1, B), dim3(256), 0, par, seq, 0, (Ctl *)nullptr, (seq_t *)nullptr);
         }
     }
     LAUNCH_S(12, st, k_track_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, par, seq);

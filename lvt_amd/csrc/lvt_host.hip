@@ -151,7 +151,9 @@ struct Context {
     // kernels -- required under tools that serialise the dispatches of all queues (rocprofv3 --pmc): a polling gate then holds
     // the only dispatch slot while what it waits for cannot start.
     bool events_only = false;
-    int match_blocks_batch = 256;  // workgroups per sequence of a batch's k_match_map (LVT_AMD_MATCH_BLOCKS_BATCH)
+    int match_blocks_batch = 32;   // workgroups per sequence of a batch's k_match_map (it lists the points appended since the early part: none on most frames,
+                                   // and every workgroup's thread 0 recomputes the prediction before it can leave): 256 -> 32 = +6 % frames/s at 16 sequences
+                                   // (LVT_AMD_MATCH_BLOCKS_BATCH overrides)
     bool force_row_fallback = false;  // LVT_AMD_TEST_ROW_FALLBACK=1 (tests): k_triangulate does not wait for the early stream's row lists, it builds them itself
                                       // WHILE the early stream's kernel writes the same words -- the situation its 5-ms time-out leads to
     hipEvent_t ev_feat[NPAR] = {};
@@ -652,7 +654,7 @@ static void enqueue_frame(Context *c) {
         hipStream_t se = c->stream_e;
         LAUNCH_S(1, se, k_gate, dim3(1, 1, B), dim3(64), 0, par, (seq_t)c->enq, seq);  // polls the previous k_pnp and this frame's features
         if (bl) LAUNCH_SM(11, se, k_hamming_batched_lists, MODE_MAP, dim3(1, 1, B), dim3(LS_THREADS), LS_LDS_BYTES, par, seq);
-        LAUNCH_S(9, se, k_early_map, dim3(256, 1, B), dim3(256), 0, par, seq, bl);
+        LAUNCH_S(9, se, k_early_map, dim3((bl && B > 1) ? 32 : 256, 1, B), dim3(256), 0, par, seq, bl);  // (behind the binned list kernel it is the fall-back only)
         LAUNCH_S(10, se, k_early_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, par, seq);
         if (c->sensor == 1) {
             // row-match candidate lists of THIS frame (needed by its k_triangulate, ~70 us from here): they need the two feature

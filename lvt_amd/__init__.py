@@ -378,6 +378,7 @@ class LvtBatch:
         load_library().lvt_amd_profile_enable(self._h, 1 if on else 0)
 
     profile_read = LvtSystem.profile_read
+    timeline = LvtSystem.timeline   # (sequence 0's stamps)
 
 
 def pnp(params: LvtParameters, q_in, p_in, pts, obs):

@@ -169,70 +169,139 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par)
         const uint32_t s3 = s2 - ((w0 >> 16) & 255u) + (w2 >> 24);
         hs[r][j] = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));
     }
-    // ---- corner score of 4 horizontally adjacent pixels per thread, as two packed pairs
+    // ---- corner score.  A thread owns 4 horizontally adjacent pixels = two packed PAIRS.  Round 3: the quick test (four ring pixels) runs
+    // for every pair in place, but the 16-pixel ring ladder (~150 packed instructions) only for the pairs that pass it -- ~15 % on textured
+    // images -- and those are first COMPACTED into a list the workgroup's threads share out: before, a wave ran the ladder for both of its
+    // pairs as soon as ONE of its 64 lanes passed the test, i.e. always (the kernel is VALU-bound: 88 us for a batch of 16).
     const int tx = tid & 15, ty = tid >> 4;
     const int gy = y0 + ty;
     const int cs = S.prm.cell_size;
     const int t_low = S.prm.agast_th_low;
-    uint32_t packed = 0;
-    // raw corners of pass 0 (score >= agast_th), as cell-local keys: k_cells gathers them per (row, tile) segment instead of
-    // re-reading the score map with one CU per cell
     const int t_hi = S.prm.agast_th;
     const int cell_x0 = x0 / cs;  // cell of the tile's first pixel; at most one cell boundary inside a tile when cs >= 64
-    uint32_t ckey[4] = {0, 0, 0, 0};
-    uint32_t cvalid = 0;  // bit k: pixel k of this thread is a pass-0 corner
-    int ncl = 0;
-    if (gy < H) {
-        const int cy = gy / cs, ly = gy - cy * cs, ch = min(cs, H - cy * cs);
-        const bool vy = (ly >= 3) && (ly <= ch - 4);
+    __shared__ uint16_t s_item[2 * 256];                                    // passing pairs: thread << 1 | pair
+    __shared__ __attribute__((aligned(4))) uint8_t s_sc[TS_H][TS_W];        // thresholded scores of the tile
+    __shared__ int s_wcnt[4];
+    const s16x2 T = (s16x2)((short)t_low);
+#define LVT_RING_AT(W_, c_, dy, dx) (seg_pair(W_[3 + (dy)][0], W_[3 + (dy)][1], W_[3 + (dy)][2], (c_) + (dx)) - P)
+    bool pass_q[2] = {false, false};
+    {
         const int gx0 = x0 + 4 * tx;
-        if (vy && gx0 < W) {
-            const int cx0 = gx0 / cs, lx0 = gx0 - cx0 * cs;
-            uint32_t w[7][3];  // rows r0-3 .. r0+3, byte columns 4 tx .. 4 tx + 11 of the tile (pixel k's centre is byte 4 + k)
+        bool row_ok = false;
+        if (gy < H) {
+            const int cy = gy / cs, ly = gy - cy * cs, ch = min(cs, H - cy * cs);
+            row_ok = (ly >= 3) && (ly <= ch - 4) && gx0 < W;
+        }
+        if (row_ok) {
+            uint32_t w[7][3];  // only rows -3, 0, +3 are needed here (the others are never read: dead after unrolling)
 #pragma unroll
-            for (int dy = 0; dy < 7; dy++) {
+            for (int dy = 0; dy < 7; dy += 3) {
                 w[dy][0] = tile[ty + HALO - 3 + dy][tx];
                 w[dy][1] = tile[ty + HALO - 3 + dy][tx + 1];
                 w[dy][2] = tile[ty + HALO - 3 + dy][tx + 2];
             }
-            const s16x2 T = (s16x2)((short)t_low);
 #pragma unroll
             for (int q = 0; q < 2; q++) {
                 const int c = 4 + 2 * q;  // segment byte of the pair's first centre
-#define LVT_RING(dy, dx) (seg_pair(w[3 + (dy)][0], w[3 + (dy)][1], w[3 + (dy)][2], c + (dx)) - P)
                 const s16x2 P = seg_pair(w[3][0], w[3][1], w[3][2], c);
-                s16x2 d[16];
-                d[0] = LVT_RING(0, -3), d[8] = LVT_RING(0, 3), d[4] = LVT_RING(-3, 0), d[12] = LVT_RING(3, 0);
+                const s16x2 d0 = LVT_RING_AT(w, c, 0, -3), d8 = LVT_RING_AT(w, c, 0, 3), d4 = LVT_RING_AT(w, c, -3, 0), d12 = LVT_RING_AT(w, c, 3, 0);
                 // quick reject: every 9-arc contains one pixel of each opposite pair
-                const s16x2 e1 = pk_min(pk_max(d[0], d[8]), pk_max(d[4], d[12]));   // > t_low: could be a bright corner
-                const s16x2 e2 = pk_max(pk_min(d[0], d[8]), pk_min(d[4], d[12]));   // < -t_low: could be a dark corner
+                const s16x2 e1 = pk_min(pk_max(d0, d8), pk_max(d4, d12));   // > t_low: could be a bright corner
+                const s16x2 e2 = pk_max(pk_min(d0, d8), pk_min(d4, d12));   // < -t_low: could be a dark corner
                 const s16x2 pass = pk_max(e1, -e2) - T;
-                if (pass.x > 0 || pass.y > 0) {  // (a pixel that fails the test alone scores below t_low: same outcome as skipping it)
-                    d[1] = LVT_RING(-1, -3), d[2] = LVT_RING(-2, -2), d[3] = LVT_RING(-3, -1), d[5] = LVT_RING(-3, 1);
-                    d[6] = LVT_RING(-2, 2), d[7] = LVT_RING(-1, 3), d[9] = LVT_RING(1, 3), d[10] = LVT_RING(2, 2);
-                    d[11] = LVT_RING(3, 1), d[13] = LVT_RING(3, -1), d[14] = LVT_RING(2, -2), d[15] = LVT_RING(1, -3);
-                    const s16x2 s2 = oast9_score2(d);
+                pass_q[q] = pass.x > 0 || pass.y > 0;  // (a pixel that fails the test alone scores below t_low: same outcome as skipping it)
+            }
+        }
+    }
+    *reinterpret_cast<uint32_t *>(&s_sc[ty][4 * tx]) = 0u;
+    {   // compaction: wave ballots give the rank inside the wave, four wave counts the base
+        const int lane = tid & 63, wv = tid >> 6;
+        const uint64_t m0 = __ballot(pass_q[0]), m1 = __ballot(pass_q[1]);
+        const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        const int n0 = __popcll(m0), n1 = __popcll(m1);
+        if (lane == 0) s_wcnt[wv] = n0 + n1;
+        __syncthreads();
+        int base = 0;
 #pragma unroll
-                    for (int h = 0; h < 2; h++) {
-                        const int k = 2 * q + h, s = h ? (int)s2.y : (int)s2.x;
-                        int cx = cx0, lx = lx0 + k;
-                        if (lx >= cs) {
-                            const int qq = lx / cs;
-                            cx += qq;
-                            lx -= qq * cs;
-                        }
-                        const int cw = min(cs, W - cx * cs);
-                        if (gx0 + k < W && lx >= 3 && lx <= cw - 4) {
-                            packed |= (uint32_t)((s >= t_low) ? s : 0) << (8 * k);
-                            if (s >= t_hi) {
-                                ckey[k] = mk_key(ly, lx, s);
-                                cvalid |= 1u << k;
-                                ncl += (cx == cell_x0) ? 1 : 0;
-                            }
-                        }
-                    }
+        for (int k = 0; k < 4; k++) base += (k < wv) ? s_wcnt[k] : 0;
+        if (pass_q[0]) s_item[base + __popcll(m0 & lt)] = (uint16_t)(tid << 1);
+        if (pass_q[1]) s_item[base + n0 + __popcll(m1 & lt)] = (uint16_t)((tid << 1) | 1);
+    }
+    __syncthreads();
+    const int n_items = s_wcnt[0] + s_wcnt[1] + s_wcnt[2] + s_wcnt[3];
+    for (int e = tid; e < n_items; e += 256) {
+        const int it = s_item[e], t = it >> 1, q = it & 1;
+        const int itx = t & 15, ity = t >> 4;
+        const int igy = y0 + ity, gx0 = x0 + 4 * itx;
+        const int cx0 = gx0 / cs, lx0 = gx0 - cx0 * cs;
+        uint32_t w[7][3];  // rows r0-3 .. r0+3, byte columns 4 tx .. 4 tx + 11 of the tile (pixel k's centre is byte 4 + k)
+#pragma unroll
+        for (int dy = 0; dy < 7; dy++) {
+            w[dy][0] = tile[ity + HALO - 3 + dy][itx];
+            w[dy][1] = tile[ity + HALO - 3 + dy][itx + 1];
+            w[dy][2] = tile[ity + HALO - 3 + dy][itx + 2];
+        }
+        // the second pair's centres sit two bytes further right: its rows are shifted down by 16 bits (one v_alignbit per word, shift
+        // amount 16 q), and ONE ladder with compile-time byte selectors serves both kinds of item -- no divergence inside a wave
+        const uint32_t sh = 16u * (uint32_t)q;
+#pragma unroll
+        for (int dy = 0; dy < 7; dy++) {
+            w[dy][0] = __builtin_amdgcn_alignbit(w[dy][1], w[dy][0], sh);
+            w[dy][1] = __builtin_amdgcn_alignbit(w[dy][2], w[dy][1], sh);
+            w[dy][2] = w[dy][2] >> sh;
+        }
+        s16x2 s2;
+        {
+            const int c = 4;
+            const s16x2 P = seg_pair(w[3][0], w[3][1], w[3][2], c);
+            s16x2 d[16];
+            d[0] = LVT_RING_AT(w, c, 0, -3), d[8] = LVT_RING_AT(w, c, 0, 3), d[4] = LVT_RING_AT(w, c, -3, 0), d[12] = LVT_RING_AT(w, c, 3, 0);
+            d[1] = LVT_RING_AT(w, c, -1, -3), d[2] = LVT_RING_AT(w, c, -2, -2), d[3] = LVT_RING_AT(w, c, -3, -1), d[5] = LVT_RING_AT(w, c, -3, 1);
+            d[6] = LVT_RING_AT(w, c, -2, 2), d[7] = LVT_RING_AT(w, c, -1, 3), d[9] = LVT_RING_AT(w, c, 1, 3), d[10] = LVT_RING_AT(w, c, 2, 2);
+            d[11] = LVT_RING_AT(w, c, 3, 1), d[13] = LVT_RING_AT(w, c, 3, -1), d[14] = LVT_RING_AT(w, c, 2, -2), d[15] = LVT_RING_AT(w, c, 1, -3);
+            s2 = oast9_score2(d);
+        }
+        uint32_t two = 0;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int k = 2 * q + h, sv = h ? (int)s2.y : (int)s2.x;
+            int cx = cx0, lx = lx0 + k;
+            if (lx >= cs) {
+                const int qq = lx / cs;
+                cx += qq;
+                lx -= qq * cs;
+            }
+            const int cw = min(cs, W - cx * cs);
+            if (gx0 + k < W && lx >= 3 && lx <= cw - 4 && sv >= t_low) two |= (uint32_t)sv << (8 * h);
+        }
+        (void)igy;
+        *reinterpret_cast<uint16_t *>(&s_sc[ity][4 * itx + 2 * q]) = (uint16_t)two;
+    }
+#undef LVT_RING_AT
+    __syncthreads();
+    // back in place: the thread's four thresholded scores; raw corners of pass 0 (score >= agast_th) as cell-local keys -- k_cells gathers
+    // them per (row, tile) segment instead of re-reading the score map with one CU per cell
+    const uint32_t packed = *reinterpret_cast<const uint32_t *>(&s_sc[ty][4 * tx]);
+    uint32_t ckey[4] = {0, 0, 0, 0};
+    uint32_t cvalid = 0;  // bit k: pixel k of this thread is a pass-0 corner
+    int ncl = 0;
+    if (gy < H && packed != 0) {
+        const int cy = gy / cs, ly = gy - cy * cs;
+        const int gx0 = x0 + 4 * tx;
+        const int cx0 = gx0 / cs, lx0 = gx0 - cx0 * cs;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int sv = (int)((packed >> (8 * k)) & 255u);
+            if (sv >= t_hi) {
+                int cx = cx0, lx = lx0 + k;
+                if (lx >= cs) {
+                    const int qq = lx / cs;
+                    cx += qq;
+                    lx -= qq * cs;
                 }
-#undef LVT_RING
+                ckey[k] = mk_key(ly, lx, sv);
+                cvalid |= 1u << k;
+                ncl += (cx == cell_x0) ? 1 : 0;
             }
         }
     }

@@ -360,7 +360,7 @@ class HipBackend:
                        "say which way every plane went); track_device = images already in HBM")
         return {"sync": res}
 
-    def _batch_run(self, fr, S, n, H, W, pitch, profile=False):
+    def _batch_run(self, fr, S, n, H, W, pitch, profile=False, depth=3):
         """S sequences in lock-step over frames [0, n) of fr[:S]; returns (seconds of the timed part, frames not TRACKING, error, handle's
         per-kernel profile or None, counts of the last frame per sequence)"""
         vo = self.lvt.LvtBatch(self.prm, S)
@@ -374,7 +374,7 @@ class HipBackend:
         self.sync()
         t0 = time.perf_counter()
         inflight, bad = 0, 0
-        depth = 1 if profile else 2
+        depth = 1 if profile else depth   # lock-step frames in flight (3: the feature stage of frame t+2 is already queued when frame t ends)
         for i in range(wm, n):
             vo.track_device_async(lp[i], rp[i], H, W, pitch); inflight += 1
             if inflight >= depth:
@@ -402,8 +402,8 @@ class HipBackend:
         out = {}
         sweep = []
         for S in sweep_sizes:
-            dt, bad, err, _, _ = self._batch_run(fr, S, n, H, W, pitch)
-            row = {"seqs": S, "frames_each": n - 4, "fps": round(S * (n - 4) / dt, 1), "ms_per_lockstep_frame": round(1e3 * dt / (n - 4), 4),
+            dt, bad, err, _, _ = self._batch_run(fr, S, n, H, W, pitch, depth=args.batch_depth)
+            row = {"seqs": S, "frames_each": n - 4, "frames_in_flight": args.batch_depth, "fps": round(S * (n - 4) / dt, 1), "ms_per_lockstep_frame": round(1e3 * dt / (n - 4), 4),
                    "frames_not_tracking": bad, "error": err}
             sweep.append(row)
             if S == S0:
@@ -584,6 +584,7 @@ def parse_args(argv=None):
     ap.add_argument("--sync-frames", type=int, default=160)
     ap.add_argument("--batch-seqs", type=int, default=16)
     ap.add_argument("--batch-frames", type=int, default=44)
+    ap.add_argument("--batch-depth", type=int, default=3, help="lock-step frames in flight in the batch leg")
     ap.add_argument("--config-frames", type=int, default=60)
     ap.add_argument("--total-seqs", type=int, default=0, help="track this many sequences in all: ceil(T / gpus) per GPU in lock-step (cfg 5 with T = 8 on fewer than 8 GPUs)")
     ap.add_argument("--backend", default="hip", choices=["hip", "standin"], help="standin: sleeps instead of GPU work (CPU test of the multi-rank launch path)")

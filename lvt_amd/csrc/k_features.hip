@@ -1325,10 +1325,24 @@ __device__ __forceinline__ void cells_work(const Seq &S, const FrameBuf &FB, int
 }
 
 // pass 0 of the detection (the <200-corner retry, handler.cpp:161-169, runs inside k_gather)
+// A lock-step batch launches its cells as ONE row of workgroups, the cells with the largest area first (CellOrder, filled by the host): with more
+// workgroups than CUs (16 sequences x 20 cells on 256) the workgroups that start late -- on the CUs the first small cells leave -- are then small
+// cells too, and the launch ends with the first round's 250 x 250 cells instead of a second round of them (KITTI, 16 sequences: 112 -> 7x us).
+struct CellOrder {
+    uint8_t v[CELLS_MAX];
+};
 template <bool BV>  // (a single sequence's descriptor travels in the kernel arguments: one dependent memory hop less at the head of the longest kernel)
-__global__ __launch_bounds__(1024) void k_cells(SeqArg<BV> sa, int pass, int par) {
-    const Seq &S = sa.get();
-    const int eye = blockIdx.y, cell = blockIdx.x;
+__global__ __launch_bounds__(1024) void k_cells(SeqArg<BV> sa, int pass, int par, CellOrder ord, int lanes) {
+    int eye = blockIdx.y, cell = blockIdx.x;
+    const Seq *Sp;
+    if constexpr (BV) {
+        Sp = &sa.v;
+    } else {  // lanes = 2 x sequences: workgroup L is (cell ord[L / lanes], eye L & 1, sequence (L % lanes) >> 1)
+        const int slot = (int)blockIdx.x / lanes, r = (int)blockIdx.x - slot * lanes;
+        cell = ord.v[slot], eye = r & 1;
+        Sp = sa.p + (r >> 1);
+    }
+    const Seq &S = *Sp;
     const FrameBuf &FB = S.fb[par];
     if (threadIdx.x == 0 && cell < CELLS_MAX) S.cell_big[eye][cell] = 0;  // (nobody reads it before this launch is over)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];

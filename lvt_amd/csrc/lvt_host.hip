@@ -151,6 +151,7 @@ struct Context {
     // kernels -- required under tools that serialise the dispatches of all queues (rocprofv3 --pmc): a polling gate then holds
     // the only dispatch slot while what it waits for cannot start.
     bool events_only = false;
+    CellOrder cell_order;   // detection cells by decreasing area: the order a batch's k_cells workgroups start in
     int match_blocks_batch = 32;   // workgroups per sequence of a batch's k_match_map (it lists the points appended since the early part: none on most frames,
                                    // and every workgroup's thread 0 recomputes the prediction before it can leave): 256 -> 32 = +6 % frames/s at 16 sequences
                                    // (LVT_AMD_MATCH_BLOCKS_BATCH overrides)
@@ -452,6 +453,16 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         c->binned_lists = B > 1;
         if (const char *e = std::getenv("LVT_AMD_BINNED_LISTS")) c->binned_lists = std::atoi(e) != 0;
         if (const char *e = std::getenv("LVT_AMD_TEST_ROW_FALLBACK")) c->force_row_fallback = std::atoi(e) != 0;
+        {   // cells by decreasing area (stable): see k_cells
+            int idx[CELLS_MAX], area[CELLS_MAX];
+            for (int cc = 0; cc < prm.n_cells; cc++) {
+                const int cx = cc % prm.cells_x, cy = cc / prm.cells_x;
+                idx[cc] = cc;
+                area[cc] = std::min(prm.cell_size, prm.W - cx * prm.cell_size) * std::min(prm.cell_size, prm.H - cy * prm.cell_size);
+            }
+            std::stable_sort(idx, idx + prm.n_cells, [&](int a, int b) { return area[a] > area[b]; });
+            for (int cc = 0; cc < CELLS_MAX; cc++) c->cell_order.v[cc] = (uint8_t)(cc < prm.n_cells ? idx[cc] : 0);
+        }
         if (const char *e = std::getenv("LVT_AMD_MATCH_BLOCKS_BATCH")) c->match_blocks_batch = std::max(1, std::min(256, std::atoi(e)));
         HIPCHK(c, hipHostMalloc((void **)&c->h_fargs, sizeof(FrameArgs) * B * RING, hipHostMallocDefault));
         c->h_seqs.resize(B);
@@ -620,7 +631,7 @@ static void enqueue_frame(Context *c) {
     if (!ext) {
         {
             const int pass = 0;  // (the <200-corner retry pass runs inside k_gather: it is almost never taken)
-            LAUNCH_S(3, sf, k_cells, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, pass, par);
+            LAUNCH_S(3, sf, k_cells, (B == 1 ? dim3(p.n_cells, 2, 1) : dim3(p.n_cells * 2 * B, 1, 1)), dim3(1024), CELLS_LDS_BYTES, pass, par, c->cell_order, 2 * B);
             if (p.big_cell_strips) {  // oversized cells: NMS as row strips on several CUs, then ANMS of the merged survivors in three launches
                 hipLaunchKernelGGL(k_cells_strip, dim3(p.n_cells * STRIPS, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
                 hipLaunchKernelGGL(k_cells_big, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);

@@ -9,7 +9,7 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/prof_*
 BENCH="python $ROOT/bench.py --steps 400 --warmup 20 --skip kernels,sync,batch,lists_ab,configs,cpu"
 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_trace -o bench -- $BENCH > $OUT/bench_under_rocprof.json 2> $OUT/bench_under_rocprof.err
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_batch -o bench -- python $ROOT/bench.py --steps 100 --warmup 10 --seqs-per-gpu 16 --depth 2 > $OUT/bench_batch16_under_rocprof.json 2> /dev/null
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_batch -o bench -- python $ROOT/bench.py --steps 100 --warmup 10 --seqs-per-gpu 16 --depth 3 > $OUT/bench_batch16_under_rocprof.json 2> /dev/null
 # PMC: separate passes, counters only (no trace domains) -- FETCH_SIZE and WRITE_SIZE cannot share a pass
 # (counter collection serialises the dispatches of all queues: the pipeline must not use its polling gates -> LVT_AMD_ORDERING=events;
 #  the timeout only guards the box)

@@ -256,3 +256,113 @@ def test_euroc_cli_matches_the_oracle_and_the_binding(tmp_path):
         assert abs(traj[i, 0] - stamp / 1e9) < 1e-5
         assert np.allclose(traj[i, 1:4], Bm[:3, 3], atol=2e-7) and np.allclose(traj[i, 4:8], q, atol=2e-7), f"frame {i}"
         lost = ref.get_state() == 3
+
+
+FACADE_SRC = r'''
+#include "lvt_system.h"
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+// argv: config.yaml frames.bin sensor(1|2).  frames.bin = int32 n, H, W, then n x (left u8 H*W, right u8 H*W | depth f32 H*W)
+int main(int argc, char **argv) {
+    if (argc < 4) return 2;
+    lvt_parameters params;
+    if (!params.init_from_file(argv[1])) return 3;
+    const int sensor = std::atoi(argv[3]);
+    FILE *f = std::fopen(argv[2], "rb");
+    int hdr[3];
+    if (!f || std::fread(hdr, 4, 3, f) != 3) return 4;
+    const int n = hdr[0], H = hdr[1], W = hdr[2];
+    lvt_system *vo = lvt_system::create(params, sensor == 2 ? lvt_system::eSensor_RGBD : lvt_system::eSensor_STEREO);
+    if (!vo) return 5;
+    if ((int)vo->get_sensor_type() != sensor || vo->get_state() != lvt_system::eState_NOT_INITIALIZED) return 6;
+    const size_t pad = 7;                                           // rows are NOT tightly packed: the facade has to repack them (cv::Mat::step)
+    std::vector<unsigned char> L((size_t)H * (W + pad)), R((size_t)H * (W + pad));
+    std::vector<float> D((size_t)H * (W + pad));
+    auto show = [&](const char *tag, const lvt_pose &p) {
+        const lvt_quaternion q = p.get_orientation_quaternion();
+        const lvt_vector3 t = p.get_position();
+        const lvt_matrix33 M = p.get_orientation_matrix();
+        std::printf("%s %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %.17g %d\n", tag, q.w(), q.x(), q.y(), q.z(), t.x(), t.y(), t.z(), M(0, 1), M(2, 0), (int)vo->get_state());
+    };
+    for (int pass = 0; pass < 2; pass++) {
+        std::fseek(f, 12, SEEK_SET);
+        for (int i = 0; i < (pass == 0 ? n : 2); i++) {
+            for (int y = 0; y < H; y++)
+                if (std::fread(&L[(size_t)y * (W + pad)], 1, W, f) != (size_t)W) return 7;
+            lvt_pose p;
+            if (sensor == 2) {
+                for (int y = 0; y < H; y++)
+                    if (std::fread(&D[(size_t)y * (W + pad)], 4, W, f) != (size_t)W) return 7;
+                p = vo->track(lvt_image_view(L.data(), H, W, W + pad), lvt_image_view(D.data(), H, W, sizeof(float) * (W + pad)));
+            } else {
+                for (int y = 0; y < H; y++)
+                    if (std::fread(&R[(size_t)y * (W + pad)], 1, W, f) != (size_t)W) return 7;
+                p = vo->track(lvt_image_view(L.data(), H, W, W + pad), lvt_image_view(R.data(), H, W, W + pad));
+            }
+            show(pass == 0 ? "pose" : "again", p);
+            if (pass == 0 && i == 2) {                               // a frame of the wrong size: refused, the state and the pose stay what they were
+                const lvt_pose q = vo->track(lvt_image_view(L.data(), H - 1, W, W + pad), lvt_image_view(R.data(), H - 1, W, W + pad));
+                show("bad", q);
+            }
+        }
+        if (pass == 0) {
+            vo->reset();                                              // lvt_system.cpp:44-68: back to NOT_INITIALIZED, the next frame founds a new map
+            if (vo->get_state() != lvt_system::eState_NOT_INITIALIZED) return 8;
+        }
+    }
+    std::printf("quit %d\n", (int)vo->should_quit());
+    lvt_system::destroy(vo);
+    return 0;
+}
+'''
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["kitti", "tum"])
+def test_lvt_system_facade_tracks_like_the_oracle(tmp_path, kind):
+    """include/lvt_system.h ON the GPU box (SURVEY 8b C++ API / 8f row 4): a caller written against the reference's class names -- create, track with
+    row-padded image views (stereo u8 pairs, RGB-D gray + f32 depth), get_state, reset, destroy -- gets the ORACLE's poses frame by frame; a frame of
+    the wrong size is refused without touching the state; after reset() the first frame founds a new map at the identity, as lvt_system.cpp:44-68 does"""
+    import lvt_amd
+    from parity_util import make_case
+    from oracle import pyoracle as O
+    world, prm, sensor = make_case(kind, seed=5, scale=0.5)
+    n = 6
+    frames = [(world.render_rgbd(i) if sensor == 2 else world.render_stereo(i)) for i in range(n)]
+    prm.write_yaml(str(tmp_path / "vo_config.yaml"))
+    with open(tmp_path / "frames.bin", "wb") as f:
+        f.write(struct.pack("<iii", n, world.H, world.W))
+        for a, b in frames:
+            f.write(np.ascontiguousarray(a, np.uint8).tobytes())
+            f.write(np.ascontiguousarray(b, np.float32 if sensor == 2 else np.uint8).tobytes())
+    src = tmp_path / "facade.cpp"
+    src.write_text(FACADE_SRC)
+    exe = tmp_path / "facade"
+    libdir = os.path.dirname(lvt_amd.LIB_PATH)
+    subprocess.check_call(["g++", "-std=c++11", "-O1", "-Wall", "-Werror", "-DLVT_SYSTEM_NO_OPENCV", "-DLVT_SYSTEM_NO_EIGEN", "-I", os.path.join(ROOT, "include"), "-o", str(exe),
+                           str(src), "-L", libdir, "-llvt_c", "-Wl,-rpath," + libdir])
+    out = subprocess.run([str(exe), str(tmp_path / "vo_config.yaml"), str(tmp_path / "frames.bin"), str(sensor)], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, (out.returncode, out.stdout[-400:], out.stderr[-400:])
+    rows = [ln.split() for ln in out.stdout.strip().splitlines()]
+    poses = [r for r in rows if r[0] == "pose"]
+    again = [r for r in rows if r[0] == "again"]
+    bad = [r for r in rows if r[0] == "bad"]
+    assert len(poses) == n and len(again) == 2 and len(bad) == 1 and rows[-1] == ["quit", "0"]
+
+    def unpack(r):
+        v = [float(x) for x in r[1:10]]
+        w, x, y, z = v[0:4]
+        return _quat_xyzw_to_R((x, y, z, w)), np.array(v[4:7]), v[7], v[8], int(r[10])
+
+    def check(orc, rows_, tag):
+        for i, r in enumerate(rows_):
+            Rm, t, m01, m20, st = unpack(r)
+            Ro, to = (orc.track_rgbd if sensor == 2 else orc.track)(*frames[i])
+            assert st == orc.status == 2, (tag, i, st, orc.status)
+            _se3_close(Rm, t, Ro, to, f"{tag} frame {i}")
+            assert abs(Rm[0, 1] - m01) < 1e-12 and abs(Rm[2, 0] - m20) < 1e-12, "get_orientation_matrix and get_orientation_quaternion describe different rotations"
+    prm_file = lvt_amd.LvtParameters.from_file(str(tmp_path / "vo_config.yaml"))
+    check(O.Oracle(prm_file, sensor), poses, "facade")
+    check(O.Oracle(prm_file, sensor), again, "facade after reset()")          # a NEW oracle: reset() founds a new map on the next frame
+    assert bad[0][1:] == poses[2][1:], "a frame of the wrong size changed the pose or the state"

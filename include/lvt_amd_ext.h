@@ -13,7 +13,8 @@
  *  - Environment, read by lvt_create: LVT_AMD_ORDERING=events orders the library's three streams with event barriers instead of
  *    polling gate kernels (needed under tools that serialise kernel dispatches, e.g. rocprofv3 --pmc; ~15 % slower).
  *    Unset, the first live handle of a process polls and single-sequence handles created beside it use events
- *    (lvt_amd_get_ordering); LVT_AMD_ORDERING=polling forces the gates.
+ *    (lvt_amd_get_ordering); LVT_AMD_ORDERING=polling forces the gates.  A polling handle whose gate runs into its time limit (the streams
+ *    do not run side by side) reports it through lvt_amd_last_error and orders with events from the next frame on, unless polling was forced.
  *  - lvt_amd_last_error reports capacity overflows, gate time-outs and "a stream waited 2 s" failures (which set LOST).
  */
 #ifndef LVT_AMD_EXT_H__

@@ -465,13 +465,16 @@ __global__ void k_row_done(Seq *seqs, int par, seq_t seq) {
 }
 
 template <bool BV>
-__global__ __launch_bounds__(64) void k_gate(SeqArg<BV> sa, int par, seq_t want, seq_t seq) {
+__global__ __launch_bounds__(64) void k_gate(SeqArg<BV> sa, int par, seq_t want, seq_t seq, int test_timeout) {
     if (threadIdx.x == 0 && blockIdx.x == 0) sa.get().ctl->dbg[32] = (long long)wall_clock64();
     Ctl &ctl = *sa.get().ctl;
     FeatCtl &fc = *sa.get().fb[par].fc;
     if (threadIdx.x != 0) return;
     bool ok = true;
-    {
+    if (test_timeout) {  // (tests: behave as if the wait had run into its limit -- LVT_AMD_TEST_GATE_TIMEOUT)
+        atomicAdd(&ctl.gate_timeouts, 1);
+        ok = false;
+    } else {
         // both conditions are polled: a stream parked on an event barrier stalls the other queues of its hardware pipe until
         // a time slice expires (the feature stream did not advance while this stream waited for the NEXT frame's features).
         // After 20 ms of wall clock (100 MHz) on either, the early kernels stand down and the late ones do all the work --

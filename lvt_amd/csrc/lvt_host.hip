@@ -118,6 +118,11 @@ struct Context {
     double host_enq_us = 0, host_wait_us = 0;  // host time spent enqueueing / blocking (LVT_AMD_HOST_TIMING=1 prints it at destroy)
     long host_enq_n = 0, host_wait_n = 0;
     int gate_timeouts_seen = 0, gate_fatal_seen = 0;
+    // a gate that ran into its time limit means that the streams do not run side by side (a tool serialises the dispatches, or the streams share a
+    // hardware queue): the handle then moves to event ordering by itself, once, at the next frame it enqueues (unless LVT_AMD_ORDERING=polling insists)
+    bool want_events = false, ordering_forced = false;
+    hipEvent_t ev_switch = nullptr;
+    long test_gate_timeout = 0, switched_at = -1;  // LVT_AMD_TEST_GATE_TIMEOUT=n: the early gate of frame n reports a time-out
     long long planes_in_place = 0, planes_staged = 0;  // host-buffer entry points: image / depth planes read in place (page-locked caller buffers) / copied through the staging buffer
     int device = 0;            // the HIP device that owns every allocation, stream and event of this handle (recorded at creation)
     int B = 1;                 // sequences advanced in lock-step by one launch chain
@@ -214,6 +219,7 @@ struct Context {
         for (auto &x : ev_done) if (x) (void)hipEventDestroy(x);
         for (auto &x : ev_feat) if (x) (void)hipEventDestroy(x);
         if (ev_depth) (void)hipEventDestroy(ev_depth);
+        if (ev_switch) (void)hipEventDestroy(ev_switch);
         for (auto &x : h_stage) if (x) (void)hipHostFree(x);
         if (h_ctl) (void)hipHostFree(h_ctl);
         if (h_done) (void)hipHostFree(h_done);
@@ -428,6 +434,8 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         for (auto &e : c->ev_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         for (auto &e : c->ev_feat) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_depth, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_switch, hipEventDisableTiming));
+        if (const char *e = std::getenv("LVT_AMD_TEST_GATE_TIMEOUT")) c->test_gate_timeout = std::atol(e);
         {
             // "events": barrier-only ordering; "polling": the polling gates + early stream; unset: polling for the first live
             // handle of the process, events for the ones created beside it -- the gates of several independent handles share
@@ -435,7 +443,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
             // polling gates, 9 200 with events); several sequences on one GPU belong in one lock-step batch anyway
             const char *o = std::getenv("LVT_AMD_ORDERING");
             if (o && std::strcmp(o, "events") == 0) c->events_only = true;
-            else if (o && std::strcmp(o, "polling") == 0) c->events_only = false;
+            else if (o && std::strcmp(o, "polling") == 0) c->events_only = false, c->ordering_forced = true;
             else c->events_only = B == 1 && c->live_on_device() > 1;
         }
         c->pitch = ((prm.W + 63) / 64) * 64;
@@ -610,6 +618,21 @@ static void enqueue_frame(Context *c) {
     const Params &p = c->prm;
     Seq *S = c->d_seqs;
     const int slot = (int)(c->enq % RING), par = (int)(c->enq % NPAR);
+    if (c->want_events && !c->events_only) {
+        // polling -> events, between two frames.  The frames already enqueued were ordered by the gates: (i) the last of them expects THIS frame's
+        // gate to deliver its record -- deliver it now; (ii) their ev_done events were never recorded, so this frame's feature stage waits for
+        // everything the tracking stream holds instead (the frames after it are behind it on the same stream; from frame + NPAR on the events exist).
+        if (c->enq > 0 && c->delivered < c->enq) {
+            const int pslot = (int)((c->enq - 1) % RING);
+            hipLaunchKernelGGL(k_deliver, dim3(1, 1, B), dim3(64), 0, c->stream, S, c->h_ctl_dev + (size_t)pslot * B, c->h_done_dev + (size_t)pslot * B, (seq_t)c->enq);
+            c->delivered = c->enq;
+        }
+        (void)hipEventRecord(c->ev_switch, c->stream);
+        (void)hipStreamWaitEvent(c->stream_f, c->ev_switch, 0);
+        c->events_only = true;
+        c->want_events = false;
+        c->switched_at = (long)c->enq;
+    }
     const FrameArgs *fa = c->h_fargs + (size_t)slot * B;
     const int ext = fa[0].ext_corners;
     hipStream_t sf = c->stream_f, st = c->stream;
@@ -619,7 +642,7 @@ static void enqueue_frame(Context *c) {
     if (c->enq >= NPAR) {
         if (!evo)
             hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, B), dim3(64), 0, sf, S, (seq_t)(c->enq + 1 - NPAR), par);  // polls; see k_gate_buf
-        else
+        else if (c->switched_at < 0 || (long)c->enq - NPAR >= c->switched_at)  // (frames from before a switch of the ordering: covered by ev_switch)
             (void)hipStreamWaitEvent(sf, c->ev_done[(int)((c->enq - NPAR) % RING)], 0);
     }
     if (B == 1) {  // the frame's inputs travel as a kernel argument: no separate "begin" launch, no device read of pinned host memory
@@ -663,7 +686,7 @@ static void enqueue_frame(Context *c) {
     const seq_t seq = (seq_t)(c->enq + 1);  // this frame's sequence number; the previous frame's is enq (0: none)
     if (!evo) {
         hipStream_t se = c->stream_e;
-        LAUNCH_S(1, se, k_gate, dim3(1, 1, B), dim3(64), 0, par, (seq_t)c->enq, seq);  // polls the previous k_pnp and this frame's features
+        LAUNCH_S(1, se, k_gate, dim3(1, 1, B), dim3(64), 0, par, (seq_t)c->enq, seq, (c->test_gate_timeout && (long)seq == c->test_gate_timeout) ? 1 : 0);  // polls the previous k_pnp and this frame's features
         if (bl) LAUNCH_SM(11, se, k_hamming_batched_lists, MODE_MAP, dim3(1, 1, B), dim3(LS_THREADS), LS_LDS_BYTES, par, seq);
         LAUNCH_S(9, se, k_early_map, dim3((bl && B > 1) ? 32 : 256, 1, B), dim3(256), 0, par, seq, bl);  // (behind the binned list kernel it is the fall-back only)
         LAUNCH_S(10, se, k_early_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, par, seq);
@@ -777,12 +800,16 @@ static void collect_oldest(Context *c) {
         if (r.gate_fatal != c->gate_fatal_seen) {
             c->gate_fatal_seen = r.gate_fatal;
             c->set_error("a stream waited 2 s for another one (features / buffer hand-over): a frame was SKIPPED (its pose is the previous frame's, the "
-                         "tracking state is unchanged); under a tool that serialises kernel dispatches (rocprofv3 --pmc) set LVT_AMD_ORDERING=events");
+                         "tracking state is unchanged); under a tool that serialises kernel dispatches (rocprofv3 --pmc) set LVT_AMD_ORDERING=events"
+                         + std::string(c->ordering_forced || c->events_only ? "" : " -- the handle moves to event ordering from the next frame on"));
+            if (!c->ordering_forced && !c->events_only) c->want_events = true;
         } else if (r.gate_timeouts != c->gate_timeouts_seen) {
             c->gate_timeouts_seen = r.gate_timeouts;
             // not a wrong result (the frame was tracked without the early stream / with row lists built on the tracking stream), but
             // milliseconds were lost: the streams do not run concurrently (shared hardware queue, or a tool that serialises the dispatches)
-            c->set_error("a stream gate timed out (results unaffected; the streams do not run concurrently: LVT_AMD_ORDERING=events avoids the waits)");
+            c->set_error(std::string("a stream gate timed out (results unaffected; the streams do not run concurrently: LVT_AMD_ORDERING=events avoids the waits)")
+                         + (c->ordering_forced || c->events_only ? "" : " -- the handle moves to event ordering from the next frame on"));
+            if (!c->ordering_forced && !c->events_only) c->want_events = true;
         }
     }
 }

@@ -273,6 +273,59 @@ def test_async_pipeline_equals_synchronous(hip_lib):
     assert b.get_state() == 2 and b.last_error() == ""
 
 
+@pytest.mark.parametrize("depth", [1, 3], ids=["one_in_flight", "three_in_flight"])
+def test_a_gate_time_out_moves_the_handle_to_event_ordering(hip_lib, monkeypatch, depth):
+    """the polling gates are a bet on streams that run side by side; when one runs into its time limit (a tool serialising the dispatches,
+    streams sharing a hardware queue) the frame is still tracked -- the late kernels do the early stream's share -- and the handle moves to
+    event ordering by itself, between two frames, with frames of both kinds in flight.  LVT_AMD_TEST_GATE_TIMEOUT=6 makes the early gate of
+    frame 6 report a time-out: every pose must equal the untouched pipeline's, the change-over must be visible (ordering(), last_error())."""
+    import torch
+    world, prm, sensor = make_case("kitti", 16, 0.5)
+    n = 20
+    pitch = ((world.W + 63) // 64) * 64
+    dev = torch.zeros((n, 2, world.H, pitch), dtype=torch.uint8, device="cuda")
+    for i in range(n):
+        L, R = world.render_stereo(i)
+        dev[i, 0, :, :world.W] = torch.from_numpy(L).cuda(); dev[i, 1, :, :world.W] = torch.from_numpy(R).cuda()
+    torch.cuda.synchronize()
+    monkeypatch.setenv("LVT_AMD_ORDERING", "polling")
+    a = hip_lib.LvtSystem.create(prm, 1)
+    ref = [a.track_device(dev[i].data_ptr(), dev[i].data_ptr() + world.H * pitch, world.H, world.W, pitch) for i in range(n)]
+    monkeypatch.delenv("LVT_AMD_ORDERING")
+    a.close()
+    monkeypatch.setenv("LVT_AMD_TEST_GATE_TIMEOUT", "6")
+    b = hip_lib.LvtSystem.create(prm, 1)
+    assert b.ordering() == "polling"
+    got, inflight, seen_switch, said = [], 0, None, []
+    for i in range(n):
+        p = dev[i].data_ptr()
+        b.track_device_async(p, p + world.H * pitch, world.H, world.W, pitch); inflight += 1
+        if seen_switch is None and b.ordering() == "events":
+            seen_switch = i
+        if inflight >= depth:
+            got.append(b.wait()); inflight -= 1
+            said.append(b.last_error())
+    while inflight:
+        got.append(b.wait()); inflight -= 1
+        said.append(b.last_error())
+    for i, ((Ra, ta), (Rb, tb)) in enumerate(zip(ref, got)):
+        assert np.array_equal(ta, tb) and np.array_equal(Ra, Rb), f"frame {i} (ordering changed at frame {seen_switch})"
+    # frame 6 (1-based) is collected after `depth` more frames were enqueued; the frame enqueued next is the first one under event ordering
+    assert seen_switch is not None and 6 <= seen_switch <= 6 + depth, seen_switch
+    assert b.ordering() == "events" and any("moves to event ordering" in e for e in said), said
+    assert b.counts() == a_counts_of(hip_lib, prm, dev, n, world, pitch)
+    assert b.get_state() == 2
+
+
+def a_counts_of(hip_lib, prm, dev, n, world, pitch):
+    v = hip_lib.LvtSystem.create(prm, 1)
+    for i in range(n):
+        v.track_device(dev[i].data_ptr(), dev[i].data_ptr() + world.H * pitch, world.H, world.W, pitch)
+    c = v.counts()
+    v.close()
+    return c
+
+
 def test_event_ordering_mode_equals_gated_pipeline(hip_lib, monkeypatch):
     """LVT_AMD_ORDERING=events (event barriers only, no early stream, no polling gates: the mode for tools that serialise
     kernel dispatches) tracks exactly like the default three-stream pipeline, several frames in flight"""

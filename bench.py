@@ -45,6 +45,43 @@ def pose_errors(Rh, th, Ro, to):
     return e_t, e_R
 
 
+def live_hamming_traffic(B, M, N, timeout=240):
+    """HBM counters of the matcher launch, collected NOW: one `rocprofv3 --pmc <counter>` child per counter (FETCH_SIZE and WRITE_SIZE cannot share
+    a pass; counters only, no trace domain) over tools/hamming_bench.py with the same B, M, N.  Returns {counter: KB per dispatch, n_counter: dispatches}
+    or None (no rocprofv3, this process is itself under a profiler, or the tool failed) -- the caller then falls back to the committed passes."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3"):
+        return None
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in (os.environ.get("LD_PRELOAD", "") + os.environ.get("HSA_TOOLS_LIB", "")):
+        return None
+    out = {}
+    tmp = tempfile.gettempdir()
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        d = tempfile.mkdtemp(prefix="lvt_pmc_")
+        try:
+            env = dict(os.environ, TMPDIR=tmp)
+            cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "h", "--", sys.executable, os.path.join(HERE, "tools", "hamming_bench.py"),
+                   str(B), str(M), str(N), "0"]
+            subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
+            vals = []
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "k_hamming_batched<0" in r.get("Kernel_Name", "") and r.get("Counter_Name") == ctr:
+                        vals.append(float(r["Counter_Value"]))
+            if not vals:
+                return None
+            out[ctr], out["n_" + ctr] = float(np.mean(vals)), len(vals)
+        except Exception:  # noqa: BLE001
+            return None
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+    return out
+
+
 def pct(a, q):
     return float(np.percentile(np.asarray(a, dtype=np.float64), q))
 
@@ -280,12 +317,19 @@ class HipBackend:
         # inside this process).  FETCH_SIZE counts the 16-B-per-lane loads of this kernel at one half on gfx950
         # (MI355X_MICROARCH.md, HBM section): corrected bytes = 2 * FETCH_SIZE + WRITE_SIZE.
         traffic, traffic_src = None, None
+        live = None if "pmc" in args.skip else live_hamming_traffic(B, M, N)
+        if live is not None:
+            traffic = round(2.0 * live["FETCH_SIZE"] * 1024.0 + live["WRITE_SIZE"] * 1024.0, 1)
+            traffic_src = ("measured by THIS run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (two separate passes, counters only) over "
+                           "`python tools/hamming_bench.py %d %d %d 0` = the same launch, mean of %d + %d dispatches: FETCH_SIZE %.1f KB, WRITE_SIZE %.1f KB"
+                           % (B, M, N, live["n_FETCH_SIZE"], live["n_WRITE_SIZE"], live["FETCH_SIZE"], live["WRITE_SIZE"]))
         try:
-            with open(os.path.join(HERE, "profiles", "hamming_pmc.json")) as f:
-                pm = json.load(f)
-            if pm.get("launch") == {"B": B, "M": M, "N": N}:
-                traffic = round(2.0 * pm["FETCH_SIZE_KB_per_launch"] * 1024.0 + pm["WRITE_SIZE_KB_per_launch"] * 1024.0, 1)
-                traffic_src = "profiles/hamming_pmc.json (%s)" % pm.get("source", "rocprofv3 --pmc")
+            if traffic is None:
+                with open(os.path.join(HERE, "profiles", "hamming_pmc.json")) as f:
+                    pm = json.load(f)
+                if pm.get("launch") == {"B": B, "M": M, "N": N}:
+                    traffic = round(2.0 * pm["FETCH_SIZE_KB_per_launch"] * 1024.0 + pm["WRITE_SIZE_KB_per_launch"] * 1024.0, 1)
+                    traffic_src = "profiles/hamming_pmc.json (%s)" % pm.get("source", "rocprofv3 --pmc")
         except Exception:  # noqa: BLE001
             pass
         copy_gbs = None
@@ -314,7 +358,9 @@ class HipBackend:
             "note": "B independent KITTI-nominal problems per launch; algorithmic bytes 40(M+N)+N+16M each (SURVEY 8d); MEAN of 35 launches "
                     "(7 x 5 back to back between two HIP events on the launch stream) after 80 warm-up launches of the kernel's row-mode "
                     "instance; the rocprofv3 --stats average of this kernel over the same command is the same statistic (profiles/); "
-                    "traffic = 2*FETCH_SIZE + WRITE_SIZE of the same launch from the committed rocprofv3 PMC passes"}}
+                    "traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950 counts this kernel's 16-B-per-lane loads at one half) of the same launch: "
+                    "collected by this run through rocprofv3 when the tool is there and this process is not itself being profiled, else the "
+                    "committed passes of tools/profile.sh (traffic_source says which)"}}
 
     def _leg_sync(self, args):
         """one frame at a time, nothing overlapped: what a caller of the reference's lvt_track gets (lvt_c.cpp:63-88); mean of the
@@ -588,7 +634,7 @@ def parse_args(argv=None):
     ap.add_argument("--config-frames", type=int, default=60)
     ap.add_argument("--total-seqs", type=int, default=0, help="track this many sequences in all: ceil(T / gpus) per GPU in lock-step (cfg 5 with T = 8 on fewer than 8 GPUs)")
     ap.add_argument("--backend", default="hip", choices=["hip", "standin"], help="standin: sleeps instead of GPU work (CPU test of the multi-rank launch path)")
-    ap.add_argument("--skip", default="", help="comma-separated side legs to skip: kernels,roofline,sync,batch,lists_ab,configs,cpu")
+    ap.add_argument("--skip", default="", help="comma-separated side legs to skip: kernels,roofline,pmc (the live counter passes of the roofline leg),sync,batch,lists_ab,configs,cpu")
     args = ap.parse_args(argv)
     args.skip = [s for s in args.skip.split(",") if s]
     return args

@@ -1155,16 +1155,22 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
     const uint8_t *s0 = device_view(left, 1), *s1 = device_view(second, rgbd ? sizeof(float) : 1);
     c->planes_in_place += (s0 != nullptr) + (s1 != nullptr);
     c->planes_staged += (s0 == nullptr) + (s1 == nullptr);
+    // The pulls are launched BEFORE the previous frame is collected: this frame's image planes (parity `par`) and staging buffer were last used NPAR
+    // frames ago, and what may still be running -- the tail of the previous synchronous call, which returned on its early pose -- reads neither.
+    // Two pageable images: the left one is pulled while the CPU still copies the right one.
+    const bool split = !rgbd && !s0 && !s1;
     if (!s0) {
         std::memcpy(c->h_stage[par], left, nbytes);
         s0 = c->h_stage_dev[par];
     }
+    if (split) hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sf, s0, s0, c->d_img[par][0], c->d_img[par][0], n_cols, n_rows, c->pitch);
     if (!s1 && !rgbd) {
         std::memcpy(c->h_stage[par] + c->stage_img, second, nbytes);
         s1 = c->h_stage_dev[par] + c->stage_img;
     }
+    if (split) hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sf, s1, s1, c->d_img[par][1], c->d_img[par][1], n_cols, n_rows, c->pitch);
+    else hipLaunchKernelGGL(k_stage_in, dim3(128, rgbd ? 1 : 2), dim3(256), 0, sf, s0, s1, c->d_img[par][0], c->d_img[par][1], n_cols, n_rows, c->pitch);
     drain(c);
-    hipLaunchKernelGGL(k_stage_in, dim3(128, rgbd ? 1 : 2), dim3(256), 0, sf, s0, s1, c->d_img[par][0], c->d_img[par][1], n_cols, n_rows, c->pitch);
     FrameArgs &f = c->h_fargs[(size_t)(c->enq % RING) * c->B];
     f.img[0] = c->d_img[par][0];
     f.img[1] = c->d_img[par][1];

@@ -433,6 +433,41 @@ def test_lockstep_batch_equals_independent_handles(hip_lib):
     assert batch.last_error() == ""
 
 
+def test_lockstep_batch_survives_a_gate_time_out(hip_lib, monkeypatch):
+    """the change-over to event ordering (test_a_gate_time_out_moves_the_handle_to_event_ordering) in a lock-step batch with three frames in flight:
+    poses of every sequence equal those of an untouched batch"""
+    import torch
+    B, n = 3, 14
+    worlds = [make_case("kitti", 30 + s, 0.5)[0] for s in range(B)]
+    prm = make_case("kitti", 30, 0.5)[1]
+    W, H = worlds[0].W, worlds[0].H
+    pitch = ((W + 63) // 64) * 64
+    dev = torch.zeros((B, n, 2, H, pitch), dtype=torch.uint8, device="cuda")
+    for s in range(B):
+        for i in range(n):
+            L, R = worlds[s].render_stereo(i)
+            dev[s, i, 0, :, :W] = torch.from_numpy(L).cuda(); dev[s, i, 1, :, :W] = torch.from_numpy(R).cuda()
+    torch.cuda.synchronize()
+
+    def run(batch):
+        out, inflight = [], 0
+        for i in range(n):
+            lp = [dev[s, i, 0].data_ptr() for s in range(B)]; rp = [dev[s, i, 1].data_ptr() for s in range(B)]
+            batch.track_device_async(lp, rp, H, W, pitch); inflight += 1
+            if inflight >= 3:
+                out.append(batch.wait()); inflight -= 1
+        while inflight:
+            out.append(batch.wait()); inflight -= 1
+        return out
+    ref = run(hip_lib.LvtBatch(prm, B))
+    monkeypatch.setenv("LVT_AMD_TEST_GATE_TIMEOUT", "5")
+    b = hip_lib.LvtBatch(prm, B)
+    got = run(b)
+    for i, ((Ra, ta, sa), (Rb, tb, sb)) in enumerate(zip(ref, got)):
+        assert np.array_equal(ta, tb) and np.array_equal(Ra, Rb) and np.array_equal(sa, sb), f"lock-step frame {i}"
+    assert hip_lib.load_library().lvt_amd_get_ordering(b._h) == 1
+
+
 def test_odometry_update_follows_the_tracker(hip_lib):
     """lvt_amd_odometry_update = lvt_track + the node's pose handling: compared with the same arithmetic applied to the poses
     of a second, plain handle; a LOST frame (40-frame jump with a tiny search radius) resets the tracker and publishes nothing"""

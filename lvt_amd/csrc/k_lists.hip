@@ -32,7 +32,6 @@ typedef unsigned int ls_u32x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE, bool BV>
 __global__ __launch_bounds__(LS_THREADS) void k_hamming_batched_lists(SeqArg<BV> sa, int par, seq_t seq) {
-    if (MODE != MODE_ROW) LVT_CHAIN_PRIO();  // (the row lists are needed a whole frame later)
     const Seq &S = sa.get();
     Ctl &ctl = *S.ctl;
     const int tid = threadIdx.x;

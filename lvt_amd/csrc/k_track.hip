@@ -330,7 +330,6 @@ __device__ __forceinline__ void candidates_body(const Seq &S, int pass2, int par
 // only_fb: the binned list kernel (k_lists.hip) ran in front of this one -- build the lists only where it stood down
 template <int MODE, bool BV>
 __global__ __launch_bounds__(256) void k_candidates(SeqArg<BV> sa, int pass2, int par, seq_t need_seq, int only_fb) {
-    LVT_CHAIN_PRIO();
     const Seq &S = sa.get();
     if (only_fb && !S.lists_fb[MODE == MODE_ROW ? 1 : 0]) return;
     if (MODE != MODE_ROW) {
@@ -380,7 +379,6 @@ __global__ __launch_bounds__(256) void k_match_map(SeqArg<BV> sa, int par, seq_t
         }
     }
     if (threadIdx.x == 0 && blockIdx.x == 0) ctl.dbg[40] = (long long)wall_clock64();  // (timeline: the frame's work starts)
-    LVT_CHAIN_PRIO();
     __shared__ int s_skip;
     if (threadIdx.x == 0) s_state = ctl.state, s_skip = ctl.skip;  // state: persistent, not written by this kernel; skip: set by this frame's gate (above / k_gate_late)
     __syncthreads();
@@ -522,7 +520,6 @@ __global__ __launch_bounds__(64) void k_gate(SeqArg<BV> sa, int par, seq_t want,
 template <bool BV>
 __global__ __launch_bounds__(256) void k_early_map(SeqArg<BV> sa, int par, seq_t seq, int only_fb) {
     if (threadIdx.x == 0 && blockIdx.x == 0) sa.get().ctl->dbg[34] = (long long)wall_clock64();
-    LVT_CHAIN_PRIO();
     const Seq &S = sa.get();
     if (only_fb && !S.lists_fb[0]) return;  // (k_hamming_batched_lists<MODE_MAP> has projected and listed these points)
     Ctl &ctl = *S.ctl;
@@ -1166,7 +1163,6 @@ __device__ __forceinline__ bool bookkeep_cull_small(const Seq &S, Ctl &ctl, int 
 template <bool BV>
 __global__ __launch_bounds__(RES_THREADS) void k_track_mid(SeqArg<BV> sa, int par, seq_t seq) {
     if (threadIdx.x == 0 && blockIdx.x == 0) sa.get().ctl->dbg[42] = (long long)wall_clock64();
-    LVT_CHAIN_PRIO();
     const Seq &S = sa.get();
     Ctl &ctl = *S.ctl;
     if (!ctl.active) return;
@@ -1212,7 +1208,6 @@ __global__ __launch_bounds__(RES_THREADS) void k_track_mid(SeqArg<BV> sa, int pa
 template <bool BV>
 __global__ __launch_bounds__(RES_THREADS) void k_early_mid(SeqArg<BV> sa, int par, seq_t seq) {
     if (threadIdx.x == 0 && blockIdx.x == 0) sa.get().ctl->dbg[36] = (long long)wall_clock64();
-    LVT_CHAIN_PRIO();
     const Seq &S = sa.get();
     Ctl &ctl = *S.ctl;
     const int n_early = (ctl.gate_ok == seq) ? ctl.early_done : 0;
@@ -1817,7 +1812,6 @@ struct PoseRec {
 template <bool BV>
 __global__ __launch_bounds__(PNP_THREADS) void k_pnp(SeqArg<BV> sa, int par, seq_t seq, PoseRec *pose_out, seq_t *pose_done) {
     if (threadIdx.x == 0 && blockIdx.x == 0) sa.get().ctl->dbg[44] = (long long)wall_clock64();
-    LVT_CHAIN_PRIO();
     const Seq &S = sa.get();
     Ctl &ctl = *S.ctl;
     if (!ctl.active || ctl.first_frame || ctl.lost_now) {
@@ -2103,7 +2097,6 @@ __global__ __launch_bounds__(1024) void k_triangulate(SeqArg<BV> sa, int par, se
     __shared__ int scan[32];
     const int tid = threadIdx.x;
     const long long tq0 = clock64();
-    LVT_CHAIN_PRIO();
     long long tq1 = tq0, tq2 = tq0;
     RESOLVE_LDS_DECL
     if (ctl.active && !ctl.lost_now) {  // update_staged_map_points + the triangulation policy (block-uniform condition)

@@ -250,14 +250,6 @@ __device__ __forceinline__ int block_excl_scan(int v, int *scratch, int *total) 
 // kernel arguments, fetched with the kernel's own argument load) or as an element of the device array (lock-step batch: one more
 // dependent memory hop at every kernel head).  These kernels never read the per-frame mutable fields of Seq (FrameBuf::img ...),
 // which only the feature stage writes and reads.
-// the kernels of the tracking and early chains are short, latency-bound and mostly ONE workgroup per sequence; the feature stage of the next frame
-// (k_score: thousands of VALU-bound workgroups on every CU) runs beside them.  Their wavefronts ask the issue arbiter for precedence over the waves
-// they share a SIMD with (in a lock-step batch of 16 k_pnp took 113 us beside k_score and 61 us alone, k_match_map 74 against 12).
-#ifndef LVT_NO_CHAIN_PRIO
-#define LVT_CHAIN_PRIO() __builtin_amdgcn_s_setprio(3)
-#else
-#define LVT_CHAIN_PRIO() ((void)0)
-#endif
 template <bool BYVAL>
 struct SeqArg;
 template <>

@@ -106,8 +106,8 @@ __device__ __forceinline__ void feat_begin(Seq &S, const FrameArgs &f, int par) 
 
 // BEGIN = single sequence: `fa` carries the frame's inputs, block (0, 0, 0) publishes them for the later kernels
 template <bool BEGIN>
-__global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par) {
-    const int seq = blockIdx.z >> 1, eye = blockIdx.z & 1;
+__global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par, int z0) {  // z0: first image of this launch (a batch's images may come in several launches)
+    const int seq = (blockIdx.z + z0) >> 1, eye = (blockIdx.z + z0) & 1;
     Seq &S = seqs[seq];
     FrameBuf &FB = S.fb[par];
     if (FB.fc->poison) return;

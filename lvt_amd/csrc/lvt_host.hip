@@ -157,6 +157,14 @@ struct Context {
     // the only dispatch slot while what it waits for cannot start.
     bool events_only = false;
     CellOrder cell_order;   // detection cells by decreasing area: the order a batch's k_cells workgroups start in
+    // A batch's k_score is thousands of small workgroups: while its grid is being dispatched, every CU slot that frees up goes to the next of them, and the
+    // tracking / early chains' workgroups (56 - 133 KB of LDS each) wait until it is through (rocprofv3 timeline: k_match_map 57 - 64 us beside it, 12 alone).
+    // In TWO launches the chip drains once in the middle and they get in: +4 .. 8 % for 8 - 24 KITTI-shaped sequences, -6 % from 28 on, where the feature
+    // stage is the longer chain and the drain is pure loss.  Which side a batch is on shows in its own early gate (Ctl::dbg[32 / 35 / 33]: start, features
+    // seen, pose seen): a gate that mostly waits for the previous pose says the feature stream is ahead.  LVT_AMD_SCORE_PIECES=1 / 2 fixes the choice.
+    int score_pieces = 1;
+    bool score_pieces_auto = true;
+    double gate_balance_us = 0;  // running mean of (wait for the pose) - (wait for the features)
     int match_blocks_batch = 32;   // workgroups per sequence of a batch's k_match_map (it lists the points appended since the early part: none on most frames,
                                    // and every workgroup's thread 0 recomputes the prediction before it can leave): 256 -> 32 = +6 % frames/s at 16 sequences
                                    // (LVT_AMD_MATCH_BLOCKS_BATCH overrides)
@@ -483,6 +491,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
             std::stable_sort(idx, idx + prm.n_cells, [&](int a, int b) { return area[a] > area[b]; });
             for (int cc = 0; cc < CELLS_MAX; cc++) c->cell_order.v[cc] = (uint8_t)(cc < prm.n_cells ? idx[cc] : 0);
         }
+        if (const char *e = std::getenv("LVT_AMD_SCORE_PIECES")) c->score_pieces = std::max(1, std::min(8, std::atoi(e))), c->score_pieces_auto = false;
         if (const char *e = std::getenv("LVT_AMD_MATCH_BLOCKS_BATCH")) c->match_blocks_batch = std::max(1, std::min(256, std::atoi(e)));
         HIPCHK(c, hipHostMalloc((void **)&c->h_fargs, sizeof(FrameArgs) * B * RING, hipHostMallocDefault));
         c->h_seqs.resize(B);
@@ -658,10 +667,17 @@ static void enqueue_frame(Context *c) {
             (void)hipStreamWaitEvent(sf, c->ev_done[(int)((c->enq - NPAR) % RING)], 0);
     }
     if (B == 1) {  // the frame's inputs travel as a kernel argument: no separate "begin" launch, no device read of pinned host memory
-        LAUNCH(2, sf, k_score<true>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2), dim3(256), 0, S, c->h_fargs[slot], par);
+        LAUNCH(2, sf, k_score<true>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2), dim3(256), 0, S, c->h_fargs[slot], par, 0);
     } else {
         LAUNCH(0, sf, k_feat_begin, dim3(B), dim3(64), 0, S, fa, par);
-        LAUNCH(2, sf, k_score<false>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2 * B), dim3(256), 0, S, FrameArgs{}, par);
+        {   // the batch's images in score_pieces launches: see Context::score_pieces
+            const int P = std::max(1, std::min(c->score_pieces, B));
+            for (int q = 0; q < P; q++) {
+                const int z0 = 2 * (int)((long)B * q / P), z1 = 2 * (int)((long)B * (q + 1) / P);
+                if (q == 0) LAUNCH(2, sf, k_score<false>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, z1 - z0), dim3(256), 0, S, FrameArgs{}, par, z0);
+                else hipLaunchKernelGGL(k_score<false>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, z1 - z0), dim3(256), 0, sf, S, FrameArgs{}, par, z0);
+            }
+        }
     }
     if (!ext) {
         {
@@ -806,6 +822,16 @@ static void collect_oldest(Context *c) {
             std::snprintf(buf, sizeof(buf), "capacity overflow mask 0x%x in sequence %d", c->h_ctl[(size_t)slot * c->B + s].overflow, s);
             c->set_error(buf);
         }
+    if (c->B > 1 && c->score_pieces_auto && !c->events_only) {  // see Context::score_pieces
+        const Ctl &r0 = c->h_ctl[(size_t)slot * c->B];
+        const long long t0 = r0.dbg[32], t1 = r0.dbg[35], t2 = r0.dbg[33];
+        if (t0 > 0 && t0 <= t1 && t1 <= t2 && t2 - t0 < 1000000) {  // (a consistent triple of one gate, < 10 ms)
+            const double d = 0.01 * (double)((t2 - t1) - (t1 - t0));
+            c->gate_balance_us = 0.8 * c->gate_balance_us + 0.2 * d;
+            if (c->gate_balance_us > 15.0) c->score_pieces = 2;
+            else if (c->gate_balance_us < -15.0) c->score_pieces = 1;
+        }
+    }
     for (int s = 0; s < c->B; s++)
     {
         const Ctl &r = c->h_ctl[(size_t)slot * c->B + s];

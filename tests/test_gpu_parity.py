@@ -404,9 +404,13 @@ def test_fewer_hardware_queues_than_streams(hip_lib, queues):
     assert runs["fewer"]["t"] == runs["default"]["t"] and runs["fewer"]["R"] == runs["default"]["R"]
 
 
-def test_lockstep_batch_equals_independent_handles(hip_lib):
-    """B sequences through ONE launch chain (lvt_amd_batch_*) == B independent handles, pose for pose"""
+@pytest.mark.parametrize("pieces", ["auto", "1", "2", "3"])
+def test_lockstep_batch_equals_independent_handles(hip_lib, monkeypatch, pieces):
+    """B sequences through ONE launch chain (lvt_amd_batch_*) == B independent handles, pose for pose -- whether the batch's k_score goes out as
+    one launch or as several (LVT_AMD_SCORE_PIECES; unset, the handle chooses by itself from its early gate's waits)"""
     import torch
+    if pieces != "auto":
+        monkeypatch.setenv("LVT_AMD_SCORE_PIECES", pieces)
     B, n = 3, 10
     worlds = [make_case("kitti", 20 + s, 0.5)[0] for s in range(B)]
     prm = make_case("kitti", 20, 0.5)[1]

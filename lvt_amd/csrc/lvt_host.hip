@@ -436,19 +436,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         c->sensor = sensor;
         c->prm = prm;
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        {
-            // LVT_AMD_FEATURE_CUS=n (tuning, batches only, default off): the feature stream may use the LAST n CU-mask bits only -- the CUs it leaves alone
-            // always have room for the tracking / early chains' workgroups (k_pnp: 133 KB of LDS).  n = 240 is worth +4 .. 6 % at 16 - 20 KITTI-shaped
-            // sequences and costs 7 % at 28 and more, where the feature stage is the longer chain (Batches).
-            int keep = 0;
-            if (const char *e = std::getenv("LVT_AMD_FEATURE_CUS")) keep = std::atoi(e);
-            if (keep > 0 && keep < 256 && B > 1) {
-                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-                for (int i = 256 - keep; i < 256; i++) mask[i >> 5] |= 1u << (i & 31);
-                HIPCHK(c, hipExtStreamCreateWithCUMask(&c->stream_f, 8, mask));
-            } else
-                HIPCHK(c, hipStreamCreateWithFlags(&c->stream_f, hipStreamNonBlocking));
-        }
+        HIPCHK(c, hipStreamCreateWithFlags(&c->stream_f, hipStreamNonBlocking));
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream_e, hipStreamNonBlocking));
         c->own_stream = true;
         for (auto &e : c->ev_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));

@@ -503,7 +503,9 @@ __device__ __forceinline__ void wave_introsort_segment(uint32_t *arr, int first,
 }
 
 // LDS carve (bytes): keys 4*RAW | uf 4*RAW | root 2*RAW | abv 2*RAW | nms 2*RAW | row_first/row_end | misc
-constexpr int CELLS_LDS_BYTES = RAW_CAP * 15 + 2 * 1024 * 4 + 64 * 4 + 3 * 64 * 4 + 64;
+constexpr int cells_lds_bytes(int raw_cap) { return raw_cap * 15 + 2 * 1024 * 4 + 64 * 4 + 3 * 64 * 4 + 64; }
+constexpr int CELLS_LDS_BYTES = cells_lds_bytes(RAW_CAP);
+constexpr int RAW_CAP_SMALL = 4700;  // 80 KB: two k_cells workgroups per CU (lvt_host.hip, Context::cells_raw_cap)
 
 __device__ __forceinline__ int uf_find(volatile uint32_t *parent, int i) {
     while (true) {
@@ -901,6 +903,7 @@ __device__ __forceinline__ int cell_anms(const Seq &S, const CellGeom &g, uint32
             int *q = reinterpret_cast<int *>(nms);
             constexpr int DFS_AT = 64;  // (also bounds the queues: a level never holds more than 2 * DFS_AT segments)
             constexpr int qcap = 2 * DFS_AT;  // per level (a level is handed over to the depth-first part at DFS_AT segments)
+            static_assert((6 * qcap + 16 * 96) * sizeof(int) <= (size_t)RAW_CAP_SMALL * sizeof(uint16_t), "queues + stacks must fit the nms[] array of the smallest LDS instance");
             int *qa = q, *qb = q + 3 * qcap;
             int *stacks = q + 6 * qcap;  // [16 wavefronts][3 * 32]
             const int nw = blockDim.x >> 6;
@@ -962,7 +965,8 @@ __device__ __forceinline__ int cell_anms(const Seq &S, const CellGeom &g, uint32
         int *hist = row_first;    // [256] (row tables are dead)
         int *gtab = row_end;      // [256] #elements with a strictly greater response
         const int nwv = blockDim.x >> 6;
-        const bool par_rank = n_kp > 512;
+        // (the per-wavefront histograms live in the dead nms[] array: [nwv][256] ints -- with the small LDS instance of a batch, RAW_CAP_SMALL, that array is too short)
+        const bool par_rank = n_kp > 512 && (size_t)n_cap * sizeof(I) >= (size_t)nwv * 256 * sizeof(int);
         const int blk = par_rank ? (((n_kp + nwv - 1) / nwv + 63) & ~63) : n_kp;  // elements per wavefront (a multiple of 64)
         int *hw = par_rank ? reinterpret_cast<int *>(nms) : hist;                  // [nwv][256] | [256]
         if (par_rank) {
@@ -1228,14 +1232,14 @@ struct CellLds {
     int *row_first, *row_end, *scan, *stack, *misc;
     uint8_t *tie8;
 };
-__device__ __forceinline__ CellLds carve_cell_lds(uint8_t *smem) {
+__device__ __forceinline__ CellLds carve_cell_lds(uint8_t *smem, int raw_cap = RAW_CAP) {  // raw_cap even
     CellLds L;
     L.keys = reinterpret_cast<uint32_t *>(smem);
-    L.uf = L.keys + RAW_CAP;
-    L.root16 = reinterpret_cast<uint16_t *>(L.uf + RAW_CAP);
-    L.abv16 = L.root16 + RAW_CAP;
-    L.nms16 = L.abv16 + RAW_CAP;
-    L.row_first = reinterpret_cast<int *>(L.nms16 + RAW_CAP);  // [1024]
+    L.uf = L.keys + raw_cap;
+    L.root16 = reinterpret_cast<uint16_t *>(L.uf + raw_cap);
+    L.abv16 = L.root16 + raw_cap;
+    L.nms16 = L.abv16 + raw_cap;
+    L.row_first = reinterpret_cast<int *>(L.nms16 + raw_cap);  // [1024]
     L.row_end = L.row_first + 1024;                            // [1024]
     L.scan = L.row_end + 1024;                                 // [64]
     L.stack = L.scan + 64;                                     // [192]
@@ -1289,7 +1293,7 @@ __device__ __forceinline__ int cell_global_path(const Seq &S, const FrameBuf &FB
 }
 
 // one detection cell of one image: AGAST NMS + LVT's ANMS (or the hand-over of an oversized cell to the strip kernels)
-__device__ __forceinline__ void cells_work(const Seq &S, const FrameBuf &FB, int eye, int cell, int pass, const CellLds &L) {
+__device__ __forceinline__ void cells_work(const Seq &S, const FrameBuf &FB, int eye, int cell, int pass, const CellLds &L, int raw_cap = RAW_CAP) {
     FeatCtl &ctl = *FB.fc;
     const int tid = threadIdx.x;
     CellGeom g;
@@ -1306,11 +1310,11 @@ __device__ __forceinline__ void cells_work(const Seq &S, const FrameBuf &FB, int
     } else if (g.cw >= 7 && g.ch >= 7) {
         // pass 0 with cells of at least one tile width: gather k_score's segments; otherwise compact the score map here
         const bool segs = (pass == 0) && (cs >= TS_W);
-        const int n_raw = segs ? cell_gather_segments(FB, eye, g, cs, cxi, (S.prm.W + TS_W - 1) / TS_W, L.keys, RAW_CAP, L.scan)
-                               : cell_compact(g, L.keys, RAW_CAP, L.scan, dbg);
+        const int n_raw = segs ? cell_gather_segments(FB, eye, g, cs, cxi, (S.prm.W + TS_W - 1) / TS_W, L.keys, raw_cap, L.scan)
+                               : cell_compact(g, L.keys, raw_cap, L.scan, dbg);
         if (dbg && tid == 0) dbg[1] = clock64();
-        if (n_raw <= RAW_CAP) {
-            n_out = cell_nms_anms<uint16_t>(S, g, L.keys, L.uf, L.root16, L.abv16, L.nms16, L.tie8, n_raw, RAW_CAP, L.row_first, L.row_end, L.scan, L.stack, L.misc, out, dbg);
+        if (n_raw <= raw_cap) {
+            n_out = cell_nms_anms<uint16_t>(S, g, L.keys, L.uf, L.root16, L.abv16, L.nms16, L.tie8, n_raw, raw_cap, L.row_first, L.row_end, L.scan, L.stack, L.misc, out, dbg);
         } else if (S.prm.big_cell_strips && pass == 0) {
             // more raw corners than this workgroup's LDS holds, in a cell tall enough to cut: k_cells_strip (NMS of row strips on several
             // CUs) and the kernels behind it take over; they also write cell_n / n_detected
@@ -1332,7 +1336,7 @@ struct CellOrder {
     uint8_t v[CELLS_MAX];
 };
 template <bool BV>  // (a single sequence's descriptor travels in the kernel arguments: one dependent memory hop less at the head of the longest kernel)
-__global__ __launch_bounds__(1024) void k_cells(SeqArg<BV> sa, int pass, int par, CellOrder ord, int lanes) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_cells(SeqArg<BV> sa, int pass, int par, CellOrder ord, int lanes, int raw_cap) {
     int eye = blockIdx.y, cell = blockIdx.x;
     const Seq *Sp;
     if constexpr (BV) {
@@ -1346,8 +1350,8 @@ __global__ __launch_bounds__(1024) void k_cells(SeqArg<BV> sa, int pass, int par
     const FrameBuf &FB = S.fb[par];
     if (threadIdx.x == 0 && cell < CELLS_MAX) S.cell_big[eye][cell] = 0;  // (nobody reads it before this launch is over)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    const CellLds L = carve_cell_lds(smem);
-    cells_work(S, FB, eye, cell, pass, L);
+    const CellLds L = carve_cell_lds(smem, raw_cap);
+    cells_work(S, FB, eye, cell, pass, L, raw_cap);
 }
 
 // ---- an oversized cell as row strips --------------------------------------------------------------------------------------------

@@ -165,6 +165,10 @@ struct Context {
     int score_pieces = 1;
     bool score_pieces_auto = true;
     double gate_balance_us = 0;  // running mean of (wait for the pose) - (wait for the features)
+    // raw corners a k_cells workgroup holds in LDS.  A batch with more cell workgroups than CUs (16 KITTI-shaped sequences: 320 on 256) runs them with room for
+    // RAW_CAP_SMALL corners -- 80 KB of LDS instead of 159, TWO workgroups per CU (k_cells is held to 64 VGPRs for that: at 66 it ran one per CU whatever its LDS) --
+    // and a cell with more raw corners than that takes the exact global-memory path, as one beyond RAW_CAP does (LVT_AMD_CELLS_RAW_CAP overrides)
+    int cells_raw_cap = RAW_CAP;
     int match_blocks_batch = 32;   // workgroups per sequence of a batch's k_match_map (it lists the points appended since the early part: none on most frames,
                                    // and every workgroup's thread 0 recomputes the prediction before it can leave): 256 -> 32 = +6 % frames/s at 16 sequences
                                    // (LVT_AMD_MATCH_BLOCKS_BATCH overrides)
@@ -480,6 +484,12 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
             for (int cc = 0; cc < CELLS_MAX; cc++) c->cell_order.v[cc] = (uint8_t)(cc < prm.n_cells ? idx[cc] : 0);
         }
         if (const char *e = std::getenv("LVT_AMD_SCORE_PIECES")) c->score_pieces = std::max(1, std::min(8, std::atoi(e))), c->score_pieces_auto = false;
+        {
+            int n_cu = 256;
+            (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
+            if (!prm.big_cell_strips && prm.n_cells * 2 * B > n_cu) c->cells_raw_cap = RAW_CAP_SMALL;
+        }
+        if (const char *e = std::getenv("LVT_AMD_CELLS_RAW_CAP")) c->cells_raw_cap = std::max(RAW_CAP_SMALL, std::min(RAW_CAP, std::atoi(e) & ~1));
         if (const char *e = std::getenv("LVT_AMD_MATCH_BLOCKS_BATCH")) c->match_blocks_batch = std::max(1, std::min(256, std::atoi(e)));
         HIPCHK(c, hipHostMalloc((void **)&c->h_fargs, sizeof(FrameArgs) * B * RING, hipHostMallocDefault));
         c->h_seqs.resize(B);
@@ -670,7 +680,7 @@ static void enqueue_frame(Context *c) {
     if (!ext) {
         {
             const int pass = 0;  // (the <200-corner retry pass runs inside k_gather: it is almost never taken)
-            LAUNCH_S(3, sf, k_cells, (B == 1 ? dim3(p.n_cells, 2, 1) : dim3(p.n_cells * 2 * B, 1, 1)), dim3(1024), CELLS_LDS_BYTES, pass, par, c->cell_order, 2 * B);
+            LAUNCH_S(3, sf, k_cells, (B == 1 ? dim3(p.n_cells, 2, 1) : dim3(p.n_cells * 2 * B, 1, 1)), dim3(1024), cells_lds_bytes(c->cells_raw_cap), pass, par, c->cell_order, 2 * B, c->cells_raw_cap);
             if (p.big_cell_strips) {  // oversized cells: NMS as row strips on several CUs, then ANMS of the merged survivors in three launches
                 hipLaunchKernelGGL(k_cells_strip, dim3(p.n_cells * STRIPS, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
                 hipLaunchKernelGGL(k_cells_big, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);

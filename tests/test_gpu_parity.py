@@ -472,6 +472,43 @@ def test_lockstep_batch_survives_a_gate_time_out(hip_lib, monkeypatch):
     assert hip_lib.load_library().lvt_amd_get_ordering(b._h) == 1
 
 
+def test_batch_cells_with_the_small_lds_instance(hip_lib, monkeypatch):
+    """a batch with more cell workgroups than CUs runs k_cells with room for 4 700 raw corners (two workgroups per CU) and sends a cell beyond that down
+    the exact global-memory path.  Forced here on a small batch (LVT_AMD_CELLS_RAW_CAP) over full-size frames whose texture contrast grows from frame to
+    frame, so that cells cross 4 700 (and 10 240) raw corners on the way: features, counts and poses must equal those of independent handles, which
+    run the full-size instance."""
+    import torch
+    B, n = 2, 9
+    world, prm, _ = make_case("kitti", 40, 1.0)
+    W, H = world.W, world.H
+    pitch = ((W + 63) // 64) * 64
+    rng = np.random.default_rng(5)
+    base = [rng.integers(0, 256, (H, W)).astype(np.float32) for _ in range(B)]
+    dev = torch.zeros((B, n, 2, H, pitch), dtype=torch.uint8, device="cuda")
+    for s in range(B):
+        for i in range(n):
+            amp = 0.30 + 0.07 * i + 0.02 * s                   # contrast of the noise texture around mid-gray: ~1 400 ... 11 000 raw corners in a 250 x 250 cell
+            L = np.clip(128.0 + amp * (base[s] - 128.0), 0, 255).astype(np.uint8)
+            R = np.roll(L, -8, axis=1)
+            dev[s, i, 0, :, :W] = torch.from_numpy(L).cuda(); dev[s, i, 1, :, :W] = torch.from_numpy(R).cuda()
+    torch.cuda.synchronize()
+    singles = [hip_lib.LvtSystem.create(prm, 1) for _ in range(B)]
+    monkeypatch.setenv("LVT_AMD_CELLS_RAW_CAP", "4700")
+    batch = hip_lib.LvtBatch(prm, B)
+    raw_seen = []
+    for i in range(n):
+        lp = [dev[s, i, 0].data_ptr() for s in range(B)]; rp = [dev[s, i, 1].data_ptr() for s in range(B)]
+        batch.track_device_async(lp, rp, H, W, pitch)
+        Rb, tb, st = batch.wait()
+        for s in range(B):
+            Rs, ts = singles[s].track_device(lp[s], rp[s], H, W, pitch)
+            assert np.array_equal(ts, tb[s]) and np.array_equal(Rs, Rb[s]) and st[s] == singles[s].get_state(), f"sequence {s} frame {i}"
+            assert batch.counts(s) == singles[s].counts(), f"sequence {s} frame {i}: {batch.counts(s)} != {singles[s].counts()}"
+        raw_seen.append(int(singles[0].timeline()[7]) & 0xFFFF)   # raw corners of cell 0 / left image of sequence 0
+    assert min(raw_seen) < 4700 and any(4700 < r <= 10240 for r in raw_seen) and max(raw_seen) > 10240, raw_seen
+    assert batch.last_error() == ""
+
+
 def test_odometry_update_follows_the_tracker(hip_lib):
     """lvt_amd_odometry_update = lvt_track + the node's pose handling: compared with the same arithmetic applied to the poses
     of a second, plain handle; a LOST frame (40-frame jump with a tiny search radius) resets the tracker and publishes nothing"""

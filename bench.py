@@ -620,7 +620,7 @@ def parse_args(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--depth", type=int, default=4, help="poses outstanding in the async pipeline (1 = synchronous)")
+    ap.add_argument("--depth", type=int, default=0, help="poses outstanding in the async pipeline (1 = synchronous; default: 4 for one sequence per GPU, 3 for a lock-step batch)")
     ap.add_argument("--seqs-per-gpu", type=int, default=1, help="independent sequences advanced in lock-step on each GPU (cfg 5 on G < 8 GPUs: ceil(8 / G))")
     ap.add_argument("--profile-steps", type=int, default=40, help="extra frames run with per-kernel HIP events")
     ap.add_argument("--cpu-frames", type=int, default=600, help="upper bound of frames run through the CPU oracle (baseline + SE3 check)")
@@ -637,6 +637,9 @@ def parse_args(argv=None):
     ap.add_argument("--skip", default="", help="comma-separated side legs to skip: kernels,roofline,pmc (the live counter passes of the roofline leg),sync,batch,lists_ab,configs,cpu")
     args = ap.parse_args(argv)
     args.skip = [s for s in args.skip.split(",") if s]
+    args.depth_auto = args.depth <= 0
+    if args.depth_auto:
+        args.depth = 4 if args.seqs_per_gpu == 1 else 3
     return args
 
 
@@ -696,6 +699,8 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {env.world_size}")
     if args.total_seqs > 0:  # cfg 5 on G < 8 GPUs: ceil(total / G) sequences per GPU in lock-step
         args.seqs_per_gpu = -(-args.total_seqs // env.world_size)
+        if args.depth_auto:
+            args.depth = 4 if args.seqs_per_gpu == 1 else 3
     standin = args.backend == "standin"
     backend = StandInBackend(args, env) if standin else HipBackend(args, env)
     dist = None

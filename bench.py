@@ -26,7 +26,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, HERE)
 
-from lvt_amd.shard import aggregate_fps, rank_env, sum_over_ranks, timed_region  # noqa: E402  (no HIP, no torch at import)
+from lvt_amd.shard import aggregate_fps, gpu_cpu_affinity, rank_env, sum_over_ranks, timed_region  # noqa: E402  (no HIP, no torch at import)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6300 GB/s is achievable
 POSE_TOL = 1e-4        # BASELINE.json: per-frame SE3 within 1e-4 rel of the CPU reference
@@ -45,7 +45,7 @@ def pose_errors(Rh, th, Ro, to):
     return e_t, e_R
 
 
-def live_hamming_traffic(B, M, N, timeout=240):
+def live_hamming_traffic(B, M, N, timeout=120):
     """HBM counters of the matcher launch, collected NOW: one `rocprofv3 --pmc <counter>` child per counter (FETCH_SIZE and WRITE_SIZE cannot share
     a pass; counters only, no trace domain) over tools/hamming_bench.py with the same B, M, N.  Returns {counter: KB per dispatch, n_counter: dispatches}
     or None (no rocprofv3, this process is itself under a profiler, or the tool failed) -- the caller then falls back to the committed passes."""
@@ -95,8 +95,9 @@ def run_rank(args, env, dist, backend):
     K, Wm = args.steps, args.warmup
     backend.prepare(Wm + K)
     warm = backend.warmup(Wm)
-    dt, (poses, not_tracking) = timed_region(lambda: backend.timed(Wm, K, args.depth), dist=dist, sync=backend.sync, device=backend.device)
-    lost = sum_over_ranks(not_tracking, dist, backend.device)
+    dt, (poses, not_tracking), tstats = timed_region(lambda: backend.timed(Wm, K, args.depth), dist=dist, sync=backend.sync, device=None,
+                                                     tail=getattr(backend, "tail", None))
+    lost = sum_over_ranks(not_tracking, dist, None)
     if env.rank != 0:
         return None
     S = backend.sequences_per_gpu
@@ -106,8 +107,13 @@ def run_rank(args, env, dist, backend):
         "ms_per_step": round(1e3 * dt / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8/f64", "data": "synthetic",
         "config": {"workload": backend.workload, "sequences_per_gpu": S, "frames_in_flight": args.depth,
+                   "total_sequences": S * env.world_size, "total_sequences_requested": (getattr(args, "total_seqs", 0) or None),
                    "parallelism": f"{env.world_size * S} independent sequences, one process per GPU, no collective"},
         "tracking": {"frames_not_tracking": lost, "checked": "lvt_amd_wait_status == 2 on every timed frame of every rank"},
+        "timing": {"window": "per rank: device sync, barrier, K steps, device sync -- no collective inside; value = all ranks' frames / MAX of the rank-local durations "
+                             "(reduced afterwards on gloo)",
+                   "per_rank_fps": [round(K * S / t, 2) for t in tstats["per_rank"]], "sum_of_rank_rates": round(sum(K * S / t for t in tstats["per_rank"]), 2),
+                   "ms_per_step_min_rank": round(1e3 * tstats["min"] / K, 4), "cpu_affinity_rank0": (lambda a: None if not a else f"{len(a)} CPUs of the GPU's NUMA node ({a[0]}..{a[-1]})")(getattr(backend, "affinity", None))},
     }
     result.update(backend.extras(args, env, warm, poses))
     return result
@@ -126,11 +132,18 @@ class HipBackend:
         self.torch, self.lvt, self.make_world = torch, lvt_amd, make_world
         torch.cuda.set_device(env.local_rank)
         self.device = torch.device("cuda", env.local_rank)
+        self.affinity = gpu_cpu_affinity(env.local_rank) if env.world_size > 1 else None   # (a single rank keeps the scheduler's choice)
         self.env = env
         self.sequences_per_gpu = args.seqs_per_gpu
+        self.depth = args.depth
         S = self.sequences_per_gpu
-        self.workload = ("KITTI seq 00-shaped synthetic stereo sequence (1241x376, examples/kitti/vo_config.yaml + calib/00.yml), one sequence per "
-                         "GPU; a step = lvt_amd_track_device_async on a frame resident in HBM + lvt_amd_wait_status") if S == 1 else \
+        self.host_frames = S == 1 and not args.device_frames
+        self.workload = ("KITTI seq 00-shaped synthetic stereo sequence (1241x376, examples/kitti/vo_config.yaml + calib/00.yml), one sequence per GPU; "
+                         + ("frames pre-rendered into PINNED HOST memory (tightly packed, as lvt_track takes them; SURVEY 8d); a step = lvt_amd_track_async "
+                            "(the pull of frame t+1 over PCIe overlaps the kernels of frame t) + lvt_amd_wait_status; warm-up runs through the same "
+                            "asynchronous entry; K enqueues + K collects inside the timed window, which starts and ends with an idle device"
+                            if self.host_frames else
+                            "a step = lvt_amd_track_device_async on a frame resident in HBM + lvt_amd_wait_status")) if S == 1 else \
                         (f"{S} independent KITTI seq 00-shaped synthetic stereo sequences per GPU advanced in lock-step (lvt_amd_batch_*; one step = "
                          "one stereo pair of EVERY sequence), frames resident in HBM")
 
@@ -156,6 +169,13 @@ class HipBackend:
         self.frames, self.H, self.W, self.pitch = self._render(self.worlds, n_frames)
         if S == 1:
             self.vo = self.lvt.LvtSystem.create(self.prm, self.lvt.eSensor_STEREO)
+            if self.host_frames:  # the same frames, tightly packed, page-locked: what a caller of lvt_track holds
+                torch = self.torch
+                self.host = torch.empty((n_frames, 2, self.H, self.W), dtype=torch.uint8).pin_memory()
+                self.host.copy_(self.frames[0, :, :, :, :self.W])
+                self.sync()
+                base, img = self.host.data_ptr(), self.H * self.W
+                self.hptr = [(base + (2 * i) * img, base + (2 * i + 1) * img) for i in range(n_frames)]
         else:
             self.vo = self.lvt.LvtBatch(self.prm, S)
             self.lp = [[self.frames[s, i, 0].data_ptr() for s in range(S)] for i in range(n_frames)]
@@ -167,6 +187,16 @@ class HipBackend:
 
     def warmup(self, Wm):
         out = []
+        if self.sequences_per_gpu == 1 and self.host_frames:  # through the asynchronous host-buffer entry, like the timed frames
+            inflight = 0
+            for i in range(Wm):
+                assert self.vo.track_async_ptr(self.hptr[i][0], self.hptr[i][1], self.H, self.W) == 0
+                inflight += 1
+                if inflight >= self.depth:
+                    out.append(self.vo.wait()); inflight -= 1
+            while inflight:
+                out.append(self.vo.wait()); inflight -= 1
+            return out
         for i in range(Wm):
             if self.sequences_per_gpu == 1:
                 l, r = self._ptrs(i)
@@ -192,8 +222,11 @@ class HipBackend:
                 R, t, st = vo.wait()
                 bad += int((st != 2).sum())
             poses.append((R, t))
+        host = single and self.host_frames
         for i in range(first, first + K):
-            if single:
+            if host:
+                vo.track_async_ptr(self.hptr[i][0], self.hptr[i][1], H, W)
+            elif single:
                 l, r = self._ptrs(i)
                 vo.track_device_async(l, r, H, W, pitch)
             else:
@@ -215,7 +248,8 @@ class HipBackend:
         out["config_ordering"] = self.vo.ordering()
         c = self.vo.counts()
         out["tracking_last_frame"] = {"features_left": c["n_left"], "map_size": c["map_size"], "matches": c["n_matches"]}
-        legs = [("kernels", self._leg_kernels), ("roofline", self._leg_roofline)]
+        out["host_route"] = self.vo.host_stats()
+        legs = [("device_resident", self._leg_device_resident), ("kernels", self._leg_kernels), ("roofline", self._leg_roofline)]
         if env.world_size == 1:  # reported at N = 1 only (rank 0's host cores / one GPU to itself)
             legs += [("sync", self._leg_sync), ("batch", self._leg_batch), ("lists_ab", self._leg_lists_ab), ("configs", self._leg_configs)]
             if not args.no_cpu:
@@ -230,6 +264,40 @@ class HipBackend:
         out.setdefault("roofline", None)
         out.setdefault("cpu_baseline", None)
         return out
+
+    def _leg_device_resident(self, args):
+        """the same frames already in HBM (lvt_amd_track_device_async): what the PCIe pull costs the pipeline.  Fresh handle, the same number of
+        warm-up and timed frames, the same depth; a side field, never `value`."""
+        if not self.host_frames:
+            return {}
+        n = min(self.n_frames, args.warmup + args.steps)
+        Wm = min(args.warmup, n - 1)
+        vo = self.lvt.LvtSystem.create(self.prm, 1)
+        res = {}
+        for tag in ("first", "second"):   # (twice on the same handle after a reset: the second pass runs with warm clocks)
+            vo.reset()
+            inflight, bad = 0, 0
+            for i in range(Wm):
+                l, r = self._ptrs(i)
+                vo.track_device_async(l, r, self.H, self.W, self.pitch); inflight += 1
+                if inflight >= self.depth:
+                    vo.wait(); inflight -= 1
+            while inflight:
+                vo.wait(); inflight -= 1
+            self.sync()
+            t0 = time.perf_counter()
+            for i in range(Wm, n):
+                l, r = self._ptrs(i)
+                vo.track_device_async(l, r, self.H, self.W, self.pitch); inflight += 1
+                if inflight >= self.depth:
+                    bad += 0 if vo.wait_status()[2] == 2 else 1; inflight -= 1
+            while inflight:
+                bad += 0 if vo.wait_status()[2] == 2 else 1; inflight -= 1
+            self.sync()
+            dt = time.perf_counter() - t0
+            res[tag] = {"fps": round((n - Wm) / dt, 1), "ms_per_step": round(1e3 * dt / (n - Wm), 4), "frames_not_tracking": bad}
+        vo.close()
+        return {"device_resident": {"entry": "lvt_amd_track_device_async (frames already in HBM)", "frames": n - Wm, **res}}
 
     def _leg_kernels(self, args):
         """per-kernel HIP-event times (synchronous mode) over a few frames past the timed ones; the frame's algorithmic bytes"""
@@ -432,6 +500,7 @@ class HipBackend:
         prof = vo.profile_read() if profile else None
         cnt = [vo.counts(s) for s in range(S)]
         err = vo.last_error()
+        self._last_score_pieces = vo.host_stats()["score_pieces"]   # launches the batch's k_score went out in at the end of the run (1 / 2: chosen at run time)
         vo.close()
         return dt, bad, err, prof, cnt
 
@@ -450,7 +519,7 @@ class HipBackend:
         for S in sweep_sizes:
             dt, bad, err, _, _ = self._batch_run(fr, S, n, H, W, pitch, depth=args.batch_depth)
             row = {"seqs": S, "frames_each": n - 4, "frames_in_flight": args.batch_depth, "fps": round(S * (n - 4) / dt, 1), "ms_per_lockstep_frame": round(1e3 * dt / (n - 4), 4),
-                   "frames_not_tracking": bad, "error": err}
+                   "frames_not_tracking": bad, "error": err, "score_pieces_at_end": self._last_score_pieces}
             sweep.append(row)
             if S == S0:
                 out["batch"] = row
@@ -588,7 +657,7 @@ class HipBackend:
         out = {"se3": {"frames": done, "max_e_t": max_et, "max_e_R_rad": max_er, "tol": POSE_TOL, "worst_frame": worst,
                        "pass": bool(max_et <= POSE_TOL and max_er <= POSE_TOL and orc.status == 2),
                        "reference": "oracle/liblvt_oracle.so (CPU restatement of the reference path; parity unpinned, see DESIGN.md section 5) on "
-                                    "the same frames: the warm-up frames through lvt_amd_track_device, the timed ones through the async pipeline"},
+                                    "the same frames: warm-up and timed frames through the asynchronous entry the headline uses"},
                "cpu_baseline": {"value": round(done / tcpu, 2), "unit": "frames/s", "cores": 2, "kind": "port",
                                 "sample": f"first {done} stereo pairs of the rank-0 sequence, oracle/liblvt_oracle.so with the reference's 2-thread "
                                           f"left/right split (the pose comparison runs inside this loop); host has {os.cpu_count()} logical cores"}}
@@ -633,7 +702,10 @@ def parse_args(argv=None):
     ap.add_argument("--batch-depth", type=int, default=3, help="lock-step frames in flight in the batch leg")
     ap.add_argument("--config-frames", type=int, default=60)
     ap.add_argument("--total-seqs", type=int, default=0, help="track this many sequences in all: ceil(T / gpus) per GPU in lock-step (cfg 5 with T = 8 on fewer than 8 GPUs)")
+    ap.add_argument("--device-frames", action="store_true", help="headline on frames already resident in HBM (lvt_amd_track_device_async) instead of pinned host frames")
     ap.add_argument("--backend", default="hip", choices=["hip", "standin"], help="standin: sleeps instead of GPU work (CPU test of the multi-rank launch path)")
+    ap.add_argument("--standin-ms", type=float, default=0.0, help="stand-in backend: every rank's step takes this long (default: rank r takes 1 + r ms)")
+    ap.add_argument("--standin-tail-ms", type=float, default=0.0, help="stand-in backend: rank 1 sleeps this long between its timed window and the reductions")
     ap.add_argument("--skip", default="", help="comma-separated side legs to skip: kernels,roofline,pmc (the live counter passes of the roofline leg),sync,batch,lists_ab,configs,cpu")
     args = ap.parse_args(argv)
     args.skip = [s for s in args.skip.split(",") if s]
@@ -652,6 +724,7 @@ class StandInBackend:
 
     def __init__(self, args, env):
         self.env = env
+        self.args = args
         self.sequences_per_gpu = args.seqs_per_gpu
 
     def sync(self):
@@ -664,9 +737,15 @@ class StandInBackend:
         return [None] * Wm
 
     def timed(self, first, K, depth):
+        ms = self.args.standin_ms if self.args.standin_ms > 0 else (1 + self.env.rank)
         for _ in range(K):
-            time.sleep(0.001 * (1 + self.env.rank))
+            time.sleep(0.001 * ms)
         return [(None, None)] * K, (1 if self.env.rank == 1 else 0)
+
+    def tail(self):
+        """(tests) a rank that dawdles between its timed window and the reductions: must not show in anybody's time"""
+        if self.args.standin_tail_ms > 0 and self.env.rank == 1:
+            time.sleep(0.001 * self.args.standin_tail_ms)
 
     def extras(self, args, env, warm, poses):
         return {"roofline": None, "cpu_baseline": None}
@@ -699,6 +778,7 @@ def main():
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE = {env.world_size}")
     if args.total_seqs > 0:  # cfg 5 on G < 8 GPUs: ceil(total / G) sequences per GPU in lock-step
         args.seqs_per_gpu = -(-args.total_seqs // env.world_size)
+        args.effective_total_seqs = args.seqs_per_gpu * env.world_size   # (rounded UP when total % gpus != 0: reported in config)
         if args.depth_auto:
             args.depth = 4 if args.seqs_per_gpu == 1 else 3
     standin = args.backend == "standin"
@@ -707,10 +787,9 @@ def main():
     if env.world_size > 1:
         import torch.distributed as dist_mod
         dist = dist_mod
-        if standin:
-            dist.init_process_group("gloo")
-        else:
-            dist.init_process_group("nccl", device_id=backend.device)  # RCCL; used for the barrier + the two scalar reductions only
+        # gloo for every backend: the ranks exchange one barrier and a few scalars OUTSIDE the timed window, there is no data-path collective
+        #  -- bringing RCCL up (IPC handles, xGMI topology) would only add a way to fail
+        dist.init_process_group("gloo")
     result = run_rank(args, env, dist, backend)
     if dist:
         dist.barrier()

@@ -73,6 +73,17 @@ LVT_API void lvt_amd_track_device(lvt_handle h, const void *d_left, const void *
  * lvt_amd_wait().  Lets one host thread keep several sequences/GPUs busy. */
 LVT_API void lvt_amd_track_device_async(lvt_handle h, const void *d_left, const void *d_right, int n_rows,
                                         int n_cols, int pitch_bytes);
+/* asynchronous lvt_track / lvt_amd_track_rgbd on HOST buffers (the reference's own boundary hands over borrowed host images, lvt_c.cpp:64-89; its
+ * callers decode frame t+1 while frame t tracks, kitti_example.cpp:113-138): the frame is enqueued and the call returns, the pose comes out of the same
+ * FIFO (lvt_amd_wait / lvt_amd_wait_status), at most 6 frames may be un-collected (a further call first blocks on the oldest one).
+ *  - pageable buffers are copied into a pinned staging ring during the call: they are the caller's again when it returns;
+ *  - page-locked buffers (hipHostMalloc / hipHostRegister) are pulled over PCIe WHERE THEY LIE: they must stay valid and unchanged until that frame
+ *    has been collected (lvt_amd_get_host_stats out[2] / out[3] count the planes that went either way).
+ * The pull of frame t+1 runs on a stream of its own beside the kernels of frame t (LVT_AMD_PULL_STREAM=0: on the feature stream).
+ * Returns 0 when the frame was enqueued; -1 when it was rejected -- wrong image size, NULL buffer, wrong sensor type, a batch handle -- and then
+ * NOTHING was enqueued (frames in flight are unaffected, lvt_amd_last_error says why). */
+LVT_API int lvt_amd_track_async(lvt_handle h, const unsigned char *left, const unsigned char *right, int n_rows, int n_cols);
+LVT_API int lvt_amd_track_rgbd_async(lvt_handle h, const unsigned char *gray, const float *depth, int n_rows, int n_cols);
 LVT_API void lvt_amd_wait(lvt_handle h, double R[3][3], double t[3]);
 /* the same, returning the tracking state after THAT frame (1 not initialised, 2 tracking, 3 lost; -1 error) -- lvt_get_status would
  * drain the whole pipeline first */
@@ -99,7 +110,9 @@ LVT_API const char *lvt_amd_last_error(lvt_handle h);
  * enable=1 resets the accumulators.  lvt_amd_profile_read returns 0 past the last slot. */
 /* host-side counters of a handle: out[0] frames enqueued, out[1] frames collected, out[2] image / depth planes of host-buffer calls
    (lvt_track, lvt_amd_track_rgbd, ...) that were read IN PLACE because the caller's buffer is page-locked, out[3] planes copied through the
-   library's staging buffer; out[4..7] reserved (0) */
+   library's staging buffer; out[4] frames that came through lvt_amd_track_async / _rgbd_async, out[5] 1 when those pulls run on their own stream,
+   out[6] launches a lock-step batch's k_score is currently sent in (1 / 2: chosen from the batch's own gate stamps unless LVT_AMD_SCORE_PIECES fixes it),
+   out[7] 1 when the handle orders its streams with events */
 LVT_API void lvt_amd_get_host_stats(lvt_handle h, long long out[8]);
 
 LVT_API void lvt_amd_profile_enable(lvt_handle h, int enable);
@@ -114,6 +127,8 @@ enum {
     LVT_AMD_C_FRAME, LVT_AMD_C_OVERFLOW /* bitmask of capacity overflows, 0 = none */,
     LVT_AMD_C_PNP_BORDERLINE /* chi2-gate decisions of this frame's pose refinement within 1e-8 of the 5.991 threshold */,
     LVT_AMD_C_ROW_FALLBACK /* 1: the tracking stream built this frame's row-match candidate lists itself (the early stream's were late) */,
+    LVT_AMD_C_PNP_TRIALS /* LM trials of this frame's pose refinement */, LVT_AMD_C_PNP_REJECTIONS /* ... rejected ones */,
+    LVT_AMD_C_PNP_TERMINATES /* passes ended by g2o's Terminate */,
     LVT_AMD_C__COUNT = 32
 };
 LVT_API void lvt_amd_get_counts(lvt_handle h, int out[LVT_AMD_C__COUNT]);
@@ -151,6 +166,13 @@ LVT_API int lvt_amd_pnp(const lvt_amd_params *p, const double q_in[4], const dou
 LVT_API int lvt_amd_pnp_detail(const lvt_amd_params *p, const double q_in[4], const double p_in[3], const double *pts,
                                const float *obs, int n, double q_out[4], double p_out[3], int *n_solve_calls,
                                double *err_out, int *level_out, int *borderline);
+/* ... and the Levenberg-Marquardt bookkeeping laid open (g2o's OptimizationAlgorithmLevenberg as configured at lvt_pnp_solver.cpp:44-53, 105-117): trace =
+ * trace_cap rows x 4 doubles, one row per LM trial {lambda, chi2 at the estimate, chi2 of the trial, rho} (may be NULL); stats = {trials, rejected
+ * trials (rho <= 0 or a non-finite chi2: lambda *= ni, the estimate is popped, the edge errors stay the trial's), passes ended by Terminate (10 trials
+ * in one iteration, or rho == 0)}.  LVT_AMD_C_PNP_TRIALS / _REJECTIONS / _TERMINATES report the same per frame. */
+LVT_API int lvt_amd_pnp_trace(const lvt_amd_params *p, const double q_in[4], const double p_in[3], const double *pts,
+                              const float *obs, int n, double q_out[4], double p_out[3], int *n_solve_calls,
+                              double *err_out, int *level_out, int *borderline, double *trace, int trace_cap, int stats[3]);
 /* batched masked 2-NN Hamming (reference lvt_image_features_struct.cpp:68-120 + cv::BFMatcher knnMatch k=2):
  * B independent problems; per problem M queries (desc 32 B, xy f32) against N train (desc, xy, flag u8);
  * candidate iff !flag && dx*dx+dy*dy < r2 (f32, strict) [mode 0] or |band| row test [mode 1].

@@ -33,12 +33,13 @@ ABI_SYMBOLS = [
     "lvt_amd_odometry_create", "lvt_amd_odometry_destroy", "lvt_amd_odometry_reset", "lvt_amd_odometry_push_pose", "lvt_amd_odometry_update", "lvt_amd_profile_enable", "lvt_amd_profile_read", "lvt_amd_get_debug", "lvt_amd_get_timeline", "lvt_amd_get_ordering",
     "lvt_amd_batch_create", "lvt_amd_batch_size", "lvt_amd_batch_track_device_async", "lvt_amd_batch_wait",
     "lvt_amd_batch_get_counts", "lvt_amd_create_on_device", "lvt_amd_get_device", "lvt_amd_wait_status", "lvt_amd_get_host_stats",
+    "lvt_amd_track_async", "lvt_amd_track_rgbd_async", "lvt_amd_pnp_trace",
 ]
 
 N_COUNTS = 32
 COUNT_NAMES = ["n_left", "n_right", "map_size", "staged_size", "n_matches", "second_pass", "n_row_matches",
                "n_triangulated", "triangulated", "retry_left", "retry_right", "pnp_iters", "pnp_inliers",
-               "map_size_at_match", "n_staged_erased", "n_staged_promoted", "n_culled", "frame", "overflow", "pnp_borderline", "row_fallback"]
+               "map_size_at_match", "n_staged_erased", "n_staged_promoted", "n_culled", "frame", "overflow", "pnp_borderline", "row_fallback", "pnp_trials", "pnp_rejections", "pnp_terminates"]
 
 eState_NOT_INITIALIZED, eState_TRACKING, eState_LOST = 1, 2, 3
 eSensor_STEREO, eSensor_RGBD = 1, 2
@@ -82,6 +83,10 @@ def load_library():
     L.lvt_amd_track_device.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]
     L.lvt_amd_track_device_async.argtypes = [vp, vp, vp, C.c_int, C.c_int, C.c_int]
     L.lvt_amd_wait.argtypes = [vp, vp, vp]
+    L.lvt_amd_track_async.argtypes = [vp, vp, vp, C.c_int, C.c_int]
+    L.lvt_amd_track_async.restype = C.c_int
+    L.lvt_amd_track_rgbd_async.argtypes = [vp, vp, vp, C.c_int, C.c_int]
+    L.lvt_amd_track_rgbd_async.restype = C.c_int
     L.lvt_amd_wait_status.argtypes = [vp, vp, vp]
     L.lvt_amd_wait_status.restype = C.c_int
     L.lvt_amd_set_stream.argtypes = [vp, vp]
@@ -99,6 +104,7 @@ def load_library():
     L.lvt_amd_get_plane.argtypes = [vp, C.c_int, C.c_int, vp, C.c_int, vp]
     L.lvt_amd_pnp.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp]
     L.lvt_amd_pnp_detail.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]
+    L.lvt_amd_pnp_trace.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, C.c_int, vp]
     L.lvt_amd_hamming_match_batched.restype = C.c_float
     L.lvt_amd_hamming_match_batched.argtypes = [vp, vp, vp, vp, vp, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_int, vp, vp]
     L.lvt_amd_get_timeline.argtypes = [vp, vp]
@@ -205,7 +211,8 @@ class LvtSystem:
         """host-side counters: frames enqueued / collected, host-buffer planes read in place (page-locked caller buffers) / staged"""
         a = (C.c_longlong * 8)()
         load_library().lvt_amd_get_host_stats(self._h, a)
-        return {"enqueued": int(a[0]), "collected": int(a[1]), "planes_in_place": int(a[2]), "planes_staged": int(a[3])}
+        return {"enqueued": int(a[0]), "collected": int(a[1]), "planes_in_place": int(a[2]), "planes_staged": int(a[3]),
+                "async_host_frames": int(a[4]), "pull_stream": int(a[5]), "score_pieces": int(a[6]), "event_ordering": int(a[7])}
 
     # lvt_system::track(img1, img2)  -- lvt_system.cpp:157-207
     def track(self, img1, img2):
@@ -237,6 +244,20 @@ class LvtSystem:
 
     def track_device_async(self, d_left: int, d_right: int, rows: int, cols: int, pitch: int):
         load_library().lvt_amd_track_device_async(self._h, C.c_void_p(d_left), C.c_void_p(d_right), rows, cols, pitch)
+
+    def track_async(self, img1, img2) -> int:
+        """lvt_amd_track_async / lvt_amd_track_rgbd_async: HOST images, the call returns once the frame is enqueued (0) or rejected (-1).
+        The arrays are used as they are (no copy here): a page-locked one must stay alive and unchanged until the frame is collected."""
+        a = img1 if (isinstance(img1, np.ndarray) and img1.dtype == np.uint8 and img1.flags.c_contiguous) else _u8(img1)
+        if self._sensor == eSensor_STEREO:
+            b = img2 if (isinstance(img2, np.ndarray) and img2.dtype == np.uint8 and img2.flags.c_contiguous) else _u8(img2)
+            return load_library().lvt_amd_track_async(self._h, _p(a), _p(b), a.shape[0], a.shape[1])
+        d = img2 if (isinstance(img2, np.ndarray) and img2.dtype == np.float32 and img2.flags.c_contiguous) else np.ascontiguousarray(img2, dtype=np.float32)
+        return load_library().lvt_amd_track_rgbd_async(self._h, _p(a), _p(d), a.shape[0], a.shape[1])
+
+    def track_async_ptr(self, p_left: int, p_right: int, rows: int, cols: int) -> int:
+        """the same on raw host addresses (stereo; bench.py: no per-call numpy work inside the timed region)"""
+        return load_library().lvt_amd_track_async(self._h, C.c_void_p(p_left), C.c_void_p(p_right), rows, cols)
 
     def wait(self):
         R = np.zeros((3, 3)); t = np.zeros(3)
@@ -379,6 +400,7 @@ class LvtBatch:
 
     profile_read = LvtSystem.profile_read
     timeline = LvtSystem.timeline   # (sequence 0's stamps)
+    host_stats = LvtSystem.host_stats
 
 
 def pnp(params: LvtParameters, q_in, p_in, pts, obs):
@@ -408,6 +430,22 @@ def pnp_detail(params: LvtParameters, q_in, p_in, pts, obs):
     if inl < 0:
         raise RuntimeError("lvt_amd_pnp_detail failed")
     return q, p, inl, calls.value, err, level, border.value
+
+
+def pnp_trace(params: LvtParameters, q_in, p_in, pts, obs, trace_cap=256):
+    """lvt_amd_pnp_trace: (q, p, inliers, solve calls, trace rows (trials x 4: lambda, chi2 at the estimate, chi2 of the trial, rho),
+    (trials, rejections, terminates))"""
+    L = load_library()
+    pod = params.to_pod()
+    q_in = np.ascontiguousarray(q_in, np.float64); p_in = np.ascontiguousarray(p_in, np.float64)
+    pts = np.ascontiguousarray(pts, np.float64); obs = np.ascontiguousarray(obs, np.float32)
+    q = np.zeros(4); p = np.zeros(3); calls = C.c_int(0)
+    tr = np.zeros((trace_cap, 4)); st = np.zeros(3, np.int32)
+    inl = L.lvt_amd_pnp_trace(C.byref(pod), _p(q_in), _p(p_in), _p(pts), _p(obs), len(pts), _p(q), _p(p), C.byref(calls), None, None, None,
+                              _p(tr), trace_cap, _p(st))
+    if inl < 0:
+        raise RuntimeError("lvt_amd_pnp_trace failed")
+    return q, p, inl, calls.value, tr[:min(int(st[0]), trace_cap)].copy(), tuple(int(x) for x in st)
 
 
 def hamming_match_batched(q_desc, q_xy, t_desc, t_xy, t_flag, r2: float, mode: int, img_rows: int, img_cols: int, out, stream: int = 0,

@@ -419,11 +419,14 @@ __global__ __launch_bounds__(256) void k_match_map(SeqArg<BV> sa, int par, seq_t
 // is finished.  Polled: a feature stream parked on an event barrier stalls the queues that share its hardware pipe -- with
 // the barrier, SHORTENING the feature chain made the whole pipeline slower -- and the event record costs the tracking stream
 // 3-4 us per frame.  (LVT_AMD_ORDERING=events uses the barrier instead of this kernel.)
-__global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, seq_t want, int par) {
+// Asynchronous host-buffer calls (lvt_amd_track_async): the frame's images are pulled over PCIe on a stream of their own; the gate also waits until
+// the pull kernels have published this frame's number in *pull_seq (nullptr: the images are resident already).
+__global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, seq_t want, int par, const seq_t *pull_seq, seq_t pull_want) {
     Ctl &ctl = *seqs[blockIdx.z].ctl;
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(&ctl.track_done_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
+    while (__hip_atomic_load(&ctl.track_done_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want ||
+           (pull_seq && __hip_atomic_load(pull_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < pull_want)) {
         __builtin_amdgcn_s_sleep(8);
         if (wall_clock64() - t0 > 200000000ull) {  // 2 s: the tracking stream is wedged, or a tool serialises the dispatches and this
             // kernel holds the slot.  The buffer still belongs to an older frame: this frame's feature kernels leave it alone
@@ -1473,6 +1476,10 @@ struct PnpShared {
     double dx[6];
     double lambda, ni;
     int cont, ok, accepted, ok2;
+    // LM bookkeeping for the tests (the oracle counts the same): trials, rejected trials, passes ended by Terminate; and, stand-alone entry only,
+    // one (lambda, chi2 at the estimate, chi2 of the trial, rho) row per trial
+    int trials, rejections, terminates, trace_cap;
+    double *trace;
 };
 
 // One sweep over the active edges at the camera `cam`: errors (stored), robust chi2 partial in acc[27], and -- when
@@ -1589,6 +1596,7 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
         for (int k = 0; k < 4; k++) sh.r[k] = r[k];
         for (int k = 0; k < 3; k++) sh.t[k] = prior.p[k];
         sh.cur = 0;
+        sh.trials = sh.rejections = sh.terminates = 0;
     }
     __syncthreads();
     CamRegs cam;
@@ -1708,6 +1716,12 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
                     scale += 1e-3;
                     rho /= scale;
                     const bool accept = (rho > 0 && isfinite(tempChi));
+                    if (sh.trace && sh.trials < sh.trace_cap) {
+                        double *row = sh.trace + 4 * sh.trials;
+                        row[0] = lambda, row[1] = currentChi, row[2] = tempChi, row[3] = rho;
+                    }
+                    sh.trials++;
+                    sh.rejections += accept ? 0 : 1;
                     if (accept) {
                         const double tr = 2 * rho - 1;
                         double alpha = 1. - tr * tr * tr;  // g2o: pow(2 rho - 1, 3)
@@ -1727,6 +1741,7 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
                     const int c = (rho < 0 && qmax < 10) ? 1 : 0;
                     sh.cont = c;
                     sh.ok = (!c && (qmax == 10 || rho == 0)) ? 0 : 1;  // Terminate
+                    sh.terminates += sh.ok ? 0 : 1;
                     sh.accepted = accept ? 1 : 0;
                 }
                 t_dec += clock64() - c1;
@@ -1826,6 +1841,7 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(SeqArg<BV> sa, int par, seq
     extern __shared__ __attribute__((aligned(16))) uint8_t pnp_dyn[];
     Pose res;
     int inliers, calls, borderline;
+    if (threadIdx.x == 0) sh.trace = nullptr, sh.trace_cap = 0;
     // err must be defined for every edge before the first gate: all edges are active in pass 1
     pnp_solve(S.prm, ctl.predicted, S.pnp_X, S.pnp_obs, S.pnp_err, S.pnp_level, ctl.n_matches, sh, red, pnp_dyn, res, inliers, calls, borderline, ctl.dbg);
     if (threadIdx.x == 0) {
@@ -1836,6 +1852,7 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(SeqArg<BV> sa, int par, seq
         ctl.counts[C_PNP_ITERS] = calls;
         ctl.counts[C_PNP_INLIERS] = inliers;
         ctl.counts[C_PNP_BORDERLINE] = borderline;
+        ctl.counts[C_PNP_TRIALS] = sh.trials, ctl.counts[C_PNP_REJECTIONS] = sh.rejections, ctl.counts[C_PNP_TERMINATES] = sh.terminates;
         ctl.early_done = *S.map_n;  // the map after clean_untracked_points: the next frame may start on these points now
         ctl.early_accepted = 0;
         ctl.dbg[45] = (long long)wall_clock64();
@@ -1858,11 +1875,12 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(SeqArg<BV> sa, int par, seq
 
 // stand-alone entry for differential tests (lvt_amd_pnp)
 __global__ __launch_bounds__(PNP_THREADS) void k_pnp_standalone(Params prm, Pose prior, const double *X, const float *obs, double *err,
-                                                                int8_t *level, int n, Pose *out, int *info) {
+                                                                int8_t *level, int n, Pose *out, int *info, double *trace, int trace_cap) {
     __shared__ PnpShared sh;
     __shared__ double red[384 + 28 * (PNP_THREADS + 8)];
     extern __shared__ __attribute__((aligned(16))) uint8_t pnp_dyn[];
     for (int i = threadIdx.x; i < n; i += PNP_THREADS) level[i] = 0;
+    if (threadIdx.x == 0) sh.trace = trace, sh.trace_cap = trace_cap;
     __syncthreads();
     Pose res;
     int inliers, calls, borderline;
@@ -1872,6 +1890,7 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp_standalone(Params prm, Pose
         info[0] = calls;
         info[1] = inliers;
         info[2] = borderline;
+        info[3] = sh.trials, info[4] = sh.rejections, info[5] = sh.terminates;
     }
 }
 

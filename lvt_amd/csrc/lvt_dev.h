@@ -29,7 +29,8 @@ enum : int {
     C_N_LEFT = 0, C_N_RIGHT, C_MAP_SIZE, C_STAGED_SIZE, C_N_MATCHES, C_SECOND_PASS, C_N_ROW_MATCHES,
     C_N_TRIANGULATED, C_TRIANGULATED, C_RETRY_LEFT, C_RETRY_RIGHT, C_PNP_ITERS, C_PNP_INLIERS,
     C_MAP_SIZE_AT_MATCH, C_N_STAGED_ERASED, C_N_STAGED_PROMOTED, C_N_CULLED, C_FRAME, C_OVERFLOW, C_PNP_BORDERLINE,
-    C_ROW_FALLBACK  // (HIP path only) k_triangulate built the row-match lists itself: the early stream's were late (or the test knob is set)
+    C_ROW_FALLBACK,  // (HIP path only) k_triangulate built the row-match lists itself: the early stream's were late (or the test knob is set)
+    C_PNP_TRIALS, C_PNP_REJECTIONS, C_PNP_TERMINATES  // LM trials of the frame's pose refinement, rejected ones (rho <= 0: lambda *= ni, pop()), passes ended by Terminate
 };
 
 // constants of the reference -- lvt/src/lvt_definitions.h:29-34

@@ -71,7 +71,25 @@ __device__ __forceinline__ void stage_put(uint8_t *dst, size_t i, int W, int pit
     const size_t y = i / (size_t)W;
     dst[y * pitch + (i - y * W)] = v;
 }
-__global__ __launch_bounds__(256) void k_stage_in(const uint8_t *src0, const uint8_t *src1, uint8_t *dst0, uint8_t *dst1, int W, int H, int pitch) {
+// Asynchronous host-buffer calls run the pulls on a stream of their own: the workgroup that finishes last (counted over `total` workgroups, which
+// may belong to several launches of one frame) publishes the frame's sequence number in *pub, and the feature stream's gate (k_gate_buf) polls it.
+struct PullDone {
+    unsigned *ctr = nullptr;
+    seq_t *pub = nullptr;
+    seq_t seq = 0;
+    unsigned total = 0;
+};
+__device__ __forceinline__ void pull_done(const PullDone &d) {
+    if (!d.pub) return;
+    __threadfence();
+    __syncthreads();
+    if (threadIdx.x == 0 && atomicAdd(d.ctr, 1u) == d.total - 1) {
+        atomicExch(d.ctr, 0u);
+        __threadfence();
+        atomicExch(d.pub, d.seq);
+    }
+}
+__global__ __launch_bounds__(256) void k_stage_in(const uint8_t *src0, const uint8_t *src1, uint8_t *dst0, uint8_t *dst1, int W, int H, int pitch, PullDone done) {
     const uint8_t *src = blockIdx.y ? src1 : src0;
     uint8_t *dst = blockIdx.y ? dst1 : dst0;
     const size_t n = (size_t)W * H;
@@ -91,10 +109,11 @@ __global__ __launch_bounds__(256) void k_stage_in(const uint8_t *src0, const uin
     }
     if (t0 < head) stage_put(dst, t0, W, pitch, src[t0]);
     if (t0 < n - tail0) stage_put(dst, tail0 + t0, W, pitch, src[tail0 + t0]);
+    pull_done(done);
 }
 // the (unpitched) fp32 depth image: 16-byte loads between the first 16-byte boundary of the source and its last whole vector, single
 // floats on either side; the destination is written float by float (it is 16-byte aligned, the source need not be)
-__global__ __launch_bounds__(256) void k_stage_copy(const float *src, float *dst, size_t n) {
+__global__ __launch_bounds__(256) void k_stage_copy(const float *src, float *dst, size_t n, PullDone done) {
     const size_t head = min((size_t)(((16 - ((uintptr_t)src & 15)) & 15) / 4), n);
     const size_t nv = (n - head) / 4, tail0 = head + nv * 4;
     const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
@@ -105,6 +124,7 @@ __global__ __launch_bounds__(256) void k_stage_copy(const float *src, float *dst
     }
     if (t0 < head) dst[t0] = src[t0];
     if (t0 < n - tail0) dst[tail0 + t0] = src[tail0 + t0];
+    pull_done(done);
 }
 
 // handles alive in this process: a handle whose k_match_map polls for its early stream parks 32 workgroups (50 KB of LDS each)
@@ -121,7 +141,7 @@ struct Context {
     // a gate that ran into its time limit means that the streams do not run side by side (a tool serialises the dispatches, or the streams share a
     // hardware queue): the handle then moves to event ordering by itself, once, at the next frame it enqueues (unless LVT_AMD_ORDERING=polling insists)
     bool want_events = false, ordering_forced = false;
-    hipEvent_t ev_switch = nullptr;
+    hipEvent_t ev_switch = nullptr, ev_switch_e = nullptr;
     long test_gate_timeout = 0, switched_at = -1;  // LVT_AMD_TEST_GATE_TIMEOUT=n: the early gate of frame n reports a time-out
     long long planes_in_place = 0, planes_staged = 0;  // host-buffer entry points: image / depth planes read in place (page-locked caller buffers) / copied through the staging buffer
     int device = 0;            // the HIP device that owns every allocation, stream and event of this handle (recorded at creation)
@@ -183,6 +203,20 @@ struct Context {
     uint8_t *h_stage[NPAR] = {}, *h_stage_dev[NPAR] = {};  // pinned staging of host images (lvt_track): [left | right or depth]
     size_t stage_img = 0;                                    // bytes reserved per 8-bit image (16-B multiple)
     float *d_depth[NPAR] = {};
+    // asynchronous host-buffer calls (lvt_amd_track_async / lvt_amd_track_rgbd_async): one image set and one staging buffer per RING slot -- frame t's
+    // slot was last used by frame t - RING, which make_room() has collected, so neither the pull (a write) nor the CPU copy into the staging
+    // buffer needs a device-side hand-over; the pulls run on stream_p beside the previous frames' kernels and publish d_pull[0] (k_gate_buf polls it;
+    // event ordering: ev_pull).  LVT_AMD_PULL_STREAM=0 keeps the pulls on the feature stream (one stream less, the pull then lengthens that chain).
+    hipStream_t stream_p = nullptr;
+    bool pull_own_stream = true;
+    uint8_t *d_img_ring[RING][2] = {};
+    float *d_depth_ring[RING] = {};
+    uint8_t *h_stage_ring[RING] = {}, *h_stage_ring_dev[RING] = {};
+    size_t stage_ring_bytes = 0;
+    seq_t *d_pull = nullptr;          // [0] last frame whose images are complete in HBM, [1] workgroup counter of the pull in flight
+    hipEvent_t ev_pull[RING] = {};
+    seq_t pull_wait = 0;              // set for the frame being enqueued: its feature stage waits for this pull (0: images resident)
+    long long async_frames = 0;
     float *d_ext[NPAR][2] = {};
     int pitch = 0;
     long enq = 0, done = 0;    // frames enqueued / collected
@@ -224,7 +258,11 @@ struct Context {
         if (stream) (void)hipStreamSynchronize(stream);
         if (stream_f) (void)hipStreamSynchronize(stream_f);
         if (stream_e) (void)hipStreamSynchronize(stream_e);
+        if (stream_p) (void)hipStreamSynchronize(stream_p);
         for (void *p : allocs) (void)hipFree(p);
+        for (auto &x : ev_pull) if (x) (void)hipEventDestroy(x);
+        for (auto &x : h_stage_ring) if (x) (void)hipHostFree(x);
+        if (stream_p) (void)hipStreamDestroy(stream_p);
         for (auto &e : ev)
             for (auto &x : e)
                 if (x) (void)hipEventDestroy(x);
@@ -232,6 +270,7 @@ struct Context {
         for (auto &x : ev_feat) if (x) (void)hipEventDestroy(x);
         if (ev_depth) (void)hipEventDestroy(ev_depth);
         if (ev_switch) (void)hipEventDestroy(ev_switch);
+        if (ev_switch_e) (void)hipEventDestroy(ev_switch_e);
         for (auto &x : h_stage) if (x) (void)hipHostFree(x);
         if (h_ctl) (void)hipHostFree(h_ctl);
         if (h_done) (void)hipHostFree(h_done);
@@ -447,6 +486,9 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         for (auto &e : c->ev_feat) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_depth, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_switch, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&c->ev_switch_e, hipEventDisableTiming));
+        c->d_pull = c->dalloc<seq_t>(2);
+        if (const char *e = std::getenv("LVT_AMD_PULL_STREAM")) c->pull_own_stream = std::atoi(e) != 0;
         if (const char *e = std::getenv("LVT_AMD_TEST_GATE_TIMEOUT")) c->test_gate_timeout = std::atol(e);
         {
             // "events": barrier-only ordering; "polling": the polling gates + early stream; unset: polling for the first live
@@ -646,6 +688,12 @@ static void enqueue_frame(Context *c) {
             hipLaunchKernelGGL(k_deliver, dim3(1, 1, B), dim3(64), 0, c->stream, S, c->h_ctl_dev + (size_t)pslot * B, c->h_done_dev + (size_t)pslot * B, (seq_t)c->enq);
             c->delivered = c->enq;
         }
+        // the early stream may still hold kernels of the pre-switch frames (k_gate, k_early_map, k_candidates<ROW>, k_row_done: they write the row lists
+        // and FeatCtl::row_seq of buffers the event-ordered frames reuse) -- exactly when the streams did not run side by side.  Both other streams wait
+        // for it; its gates time out by themselves, so this cannot deadlock.
+        (void)hipEventRecord(c->ev_switch_e, c->stream_e);
+        (void)hipStreamWaitEvent(c->stream, c->ev_switch_e, 0);
+        (void)hipStreamWaitEvent(c->stream_f, c->ev_switch_e, 0);
         (void)hipEventRecord(c->ev_switch, c->stream);
         (void)hipStreamWaitEvent(c->stream_f, c->ev_switch, 0);
         c->events_only = true;
@@ -658,12 +706,18 @@ static void enqueue_frame(Context *c) {
     for (int i = 0; i < Context::PROF_SLOTS; i++) c->ev_used[i] = false;
     // ---- feature stage (stream_f): may start as soon as the tracking chain of frame enq-NPAR released this buffer
     const bool evo = c->events_only;
-    if (c->enq >= NPAR) {
+    const bool pull_gate = c->pull_wait != 0 && c->stream_p != nullptr;  // (pulls on the feature stream itself are ordered by that stream)
+    if (c->enq >= NPAR || pull_gate) {
         if (!evo)
-            hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, B), dim3(64), 0, sf, S, (seq_t)(c->enq + 1 - NPAR), par);  // polls; see k_gate_buf
-        else if (c->switched_at < 0 || (long)c->enq - NPAR >= c->switched_at)  // (frames from before a switch of the ordering: covered by ev_switch)
-            (void)hipStreamWaitEvent(sf, c->ev_done[(int)((c->enq - NPAR) % RING)], 0);
+            hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, B), dim3(64), 0, sf, S, (seq_t)(c->enq >= NPAR ? c->enq + 1 - NPAR : 0), par,
+                               pull_gate ? (const seq_t *)c->d_pull : (const seq_t *)nullptr, c->pull_wait);  // polls; see k_gate_buf
+        else {
+            if (c->enq >= NPAR && (c->switched_at < 0 || (long)c->enq - NPAR >= c->switched_at))  // (frames from before a switch of the ordering: covered by ev_switch)
+                (void)hipStreamWaitEvent(sf, c->ev_done[(int)((c->enq - NPAR) % RING)], 0);
+            if (pull_gate) (void)hipStreamWaitEvent(sf, c->ev_pull[slot], 0);
+        }
     }
+    c->pull_wait = 0;
     if (B == 1) {  // the frame's inputs travel as a kernel argument: no separate "begin" launch, no device read of pinned host memory
         LAUNCH(2, sf, k_score<true>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2), dim3(256), 0, S, c->h_fargs[slot], par, 0);
     } else {
@@ -1006,6 +1060,7 @@ LVT_API void lvt_amd_get_host_stats(lvt_handle h, long long out[8]) {
     for (int i = 0; i < 8; i++) out[i] = 0;
     if (!c) return;
     out[0] = (long long)c->enq, out[1] = (long long)c->done, out[2] = c->planes_in_place, out[3] = c->planes_staged;
+    out[4] = c->async_frames, out[5] = c->stream_p ? 1 : 0, out[6] = c->score_pieces, out[7] = c->events_only ? 1 : 0;
 }
 
 LVT_API void lvt_amd_profile_enable(lvt_handle h, int enable) {
@@ -1199,13 +1254,13 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
         std::memcpy(c->h_stage[par], left, nbytes);
         s0 = c->h_stage_dev[par];
     }
-    if (split) hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sf, s0, s0, c->d_img[par][0], c->d_img[par][0], n_cols, n_rows, c->pitch);
+    if (split) hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sf, s0, s0, c->d_img[par][0], c->d_img[par][0], n_cols, n_rows, c->pitch, PullDone{});
     if (!s1 && !rgbd) {
         std::memcpy(c->h_stage[par] + c->stage_img, second, nbytes);
         s1 = c->h_stage_dev[par] + c->stage_img;
     }
-    if (split) hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sf, s1, s1, c->d_img[par][1], c->d_img[par][1], n_cols, n_rows, c->pitch);
-    else hipLaunchKernelGGL(k_stage_in, dim3(128, rgbd ? 1 : 2), dim3(256), 0, sf, s0, s1, c->d_img[par][0], c->d_img[par][1], n_cols, n_rows, c->pitch);
+    if (split) hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sf, s1, s1, c->d_img[par][1], c->d_img[par][1], n_cols, n_rows, c->pitch, PullDone{});
+    else hipLaunchKernelGGL(k_stage_in, dim3(128, rgbd ? 1 : 2), dim3(256), 0, sf, s0, s1, c->d_img[par][0], c->d_img[par][1], n_cols, n_rows, c->pitch, PullDone{});
     drain(c);
     FrameArgs &f = c->h_fargs[(size_t)(c->enq % RING) * c->B];
     f.img[0] = c->d_img[par][0];
@@ -1227,7 +1282,7 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
                 src = c->h_stage_dev[par] + c->stage_img;
             }
             hipStream_t sd = c->events_only ? sf : c->stream_e;
-            hipLaunchKernelGGL(k_stage_copy, dim3(256), dim3(256), 0, sd, reinterpret_cast<const float *>(src), reinterpret_cast<float *>(c->d_depth[par]), nbytes);
+            hipLaunchKernelGGL(k_stage_copy, dim3(256), dim3(256), 0, sd, reinterpret_cast<const float *>(src), reinterpret_cast<float *>(c->d_depth[par]), nbytes, PullDone{});
             if (sd != sf) {
                 (void)hipEventRecord(c->ev_depth, sd);
                 c->depth_wait = true;
@@ -1245,6 +1300,116 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
     enqueue_frame(c);
     c->sync_call = false;
     if (!wait_pose_or_frame(c, R, t)) result_out(c, 0, R, t);
+}
+
+// Asynchronous counterpart of upload_and_track (lvt_amd_track_async / lvt_amd_track_rgbd_async): borrowed HOST images, the frame is enqueued and the
+// call returns; the pose comes out of the same FIFO as lvt_amd_track_device_async's (lvt_amd_wait / lvt_amd_wait_status).  Pageable buffers are copied
+// into this slot's pinned staging buffer during the call; page-locked ones are pulled where they lie (and must stay valid until the frame is collected).
+// The pull runs on its own stream: the images of frame t + 1 cross PCIe while the kernels of frame t run (SURVEY 8e "pinned H2D staging double-buffered").
+// Returns 0 when the frame was enqueued, -1 when it was rejected (nothing enqueued; lvt_amd_last_error says why).
+static int upload_async(Context *c, const unsigned char *left, const void *second, bool rgbd, int n_rows, int n_cols) {
+    if (c->B != 1 || (rgbd ? c->sensor != 2 : c->sensor != 1)) {
+        c->set_error("lvt_amd_track_async: wrong sensor type for this entry point (or a batch handle)");
+        return -1;
+    }
+    if (!left || !second || !size_ok(c, n_rows, n_cols)) {
+        c->set_error("lvt_amd_track_async: image size differs from the configured img_width/img_height (the frame was NOT enqueued)");
+        return -1;
+    }
+    if (c->early_pending) drain(c);
+    make_room(c);
+    const int slot = (int)(c->enq % RING);
+    const size_t nbytes = (size_t)n_rows * n_cols, plane = (size_t)c->pitch * c->prm.H;
+    if (!c->d_img_ring[0][0]) {  // first asynchronous host-buffer call
+        for (int r = 0; r < RING; r++) {
+            for (int e = 0; e < (rgbd ? 1 : 2); e++) c->d_img_ring[r][e] = c->dalloc<uint8_t>(plane + 64);
+            if (rgbd) c->d_depth_ring[r] = c->dalloc<float>(nbytes + 4);
+            HIPCHK(c, hipEventCreateWithFlags(&c->ev_pull[r], hipEventDisableTiming));
+        }
+        if (c->pull_own_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_p, hipStreamNonBlocking));
+    }
+    auto device_view = [](const void *p, size_t align) -> const uint8_t * {
+        hipPointerAttribute_t a;
+        if (((uintptr_t)p & (align - 1)) == 0 && hipPointerGetAttributes(&a, p) == hipSuccess && a.type == hipMemoryTypeHost && a.devicePointer)
+            return static_cast<const uint8_t *>(a.devicePointer);
+        (void)hipGetLastError();
+        return nullptr;
+    };
+    const uint8_t *s0 = device_view(left, 1), *s1 = device_view(second, rgbd ? sizeof(float) : 1);
+    c->planes_in_place += (s0 != nullptr) + (s1 != nullptr);
+    c->planes_staged += (s0 == nullptr) + (s1 == nullptr);
+    const size_t img_b = (nbytes + 15) & ~(size_t)15, second_b = rgbd ? ((sizeof(float) * nbytes + 15) & ~(size_t)15) : img_b;
+    if ((!s0 || !s1) && !c->h_stage_ring[slot]) {
+        c->stage_ring_bytes = img_b + second_b;
+        HIPCHK(c, hipHostMalloc((void **)&c->h_stage_ring[slot], c->stage_ring_bytes, hipHostMallocDefault));
+        HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_stage_ring_dev[slot], c->h_stage_ring[slot], 0));
+    }
+    hipStream_t sp = c->stream_p ? c->stream_p : c->stream_f;
+    const seq_t seq = (seq_t)(c->enq + 1);
+    PullDone done;
+    if (c->stream_p && !c->events_only) done.ctr = reinterpret_cast<unsigned *>(c->d_pull + 1), done.pub = c->d_pull, done.seq = seq;
+    uint8_t *d0 = c->d_img_ring[slot][0], *d1 = c->d_img_ring[slot][1];
+    if (!rgbd) {
+        done.total = 256;  // two launches of (128, 1) or one of (128, 2)
+        const bool split = !s0 && !s1;  // two pageable images: the left one crosses PCIe while the CPU copies the right one
+        if (!s0) {
+            std::memcpy(c->h_stage_ring[slot], left, nbytes);
+            s0 = c->h_stage_ring_dev[slot];
+        }
+        if (split) hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sp, s0, s0, d0, d0, n_cols, n_rows, c->pitch, done);
+        if (!s1) {
+            std::memcpy(c->h_stage_ring[slot] + img_b, second, nbytes);
+            s1 = c->h_stage_ring_dev[slot] + img_b;
+        }
+        if (split) hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sp, s1, s1, d1, d1, n_cols, n_rows, c->pitch, done);
+        else hipLaunchKernelGGL(k_stage_in, dim3(128, 2), dim3(256), 0, sp, s0, s1, d0, d1, n_cols, n_rows, c->pitch, done);
+    } else {
+        done.total = 128 + 256;
+        if (!s0) {
+            std::memcpy(c->h_stage_ring[slot], left, nbytes);
+            s0 = c->h_stage_ring_dev[slot];
+        }
+        hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sp, s0, s0, d0, d0, n_cols, n_rows, c->pitch, done);
+        if (!s1) {
+            std::memcpy(c->h_stage_ring[slot] + img_b, second, sizeof(float) * nbytes);
+            s1 = c->h_stage_ring_dev[slot] + img_b;
+        }
+        hipLaunchKernelGGL(k_stage_copy, dim3(256), dim3(256), 0, sp, reinterpret_cast<const float *>(s1), c->d_depth_ring[slot], nbytes, done);
+    }
+    if (c->stream_p && c->events_only) (void)hipEventRecord(c->ev_pull[slot], sp);
+    c->pull_wait = seq;
+    FrameArgs &f = c->h_fargs[(size_t)slot * c->B];
+    f.img[0] = d0;
+    f.img[1] = rgbd ? d0 : d1;
+    f.img_pitch = c->pitch;
+    f.depth = rgbd ? c->d_depth_ring[slot] : nullptr;
+    f.depth_pitch = rgbd ? n_cols : 0;
+    f.ext_corners = 0;
+    f.n_ext[0] = f.n_ext[1] = 0;
+    c->async_frames++;
+    enqueue_frame(c);
+    return 0;
+}
+
+LVT_API int lvt_amd_track_async(lvt_handle h, const unsigned char *left, const unsigned char *right, int n_rows, int n_cols) {
+    Context *c = static_cast<Context *>(h);
+    if (!c) return -1;
+    DeviceGuard guard(c);
+    try {
+        return upload_async(c, left, right, false, n_rows, n_cols);
+    } catch (...) {
+    }
+    return -1;
+}
+LVT_API int lvt_amd_track_rgbd_async(lvt_handle h, const unsigned char *gray, const float *depth, int n_rows, int n_cols) {
+    Context *c = static_cast<Context *>(h);
+    if (!c) return -1;
+    DeviceGuard guard(c);
+    try {
+        return upload_async(c, gray, depth, true, n_rows, n_cols);
+    } catch (...) {
+    }
+    return -1;
 }
 
 LVT_API void lvt_track(lvt_handle h, unsigned char *left, unsigned char *right, int n_rows, int n_cols, double R[3][3], double t[3]) {
@@ -1484,8 +1649,11 @@ LVT_API int lvt_amd_get_plane(lvt_handle h, int eye, int what, void *dst, int ca
 // ---- stage entry: motion-only BA on caller data ---------------------------------------------------
 // err_out (2n doubles, may be NULL): the edge errors the second chi2 gate saw; level_out (n ints, may be NULL): 1 = demoted by a gate;
 // *borderline (may be NULL): gate decisions taken within PNP_GATE_MARGIN of the threshold
-LVT_API int lvt_amd_pnp_detail(const lvt_amd_params *pin, const double q_in[4], const double p_in[3], const double *pts, const float *obs, int n,
-                               double q_out[4], double p_out[3], int *n_solve_calls, double *err_out, int *level_out, int *borderline) {
+// trace (trace_cap rows x 4 doubles, may be NULL): one row per LM trial {lambda, chi2 at the estimate, chi2 of the trial, rho}; stats (may be NULL):
+// {trials, rejected trials, passes ended by Terminate}
+LVT_API int lvt_amd_pnp_trace(const lvt_amd_params *pin, const double q_in[4], const double p_in[3], const double *pts, const float *obs, int n,
+                              double q_out[4], double p_out[3], int *n_solve_calls, double *err_out, int *level_out, int *borderline,
+                              double *trace, int trace_cap, int stats[3]) {
     Params prm;
     lvt_amd_params tmp = *pin;
     if (tmp.img_width <= 0) tmp.img_width = 64;
@@ -1496,27 +1664,33 @@ LVT_API int lvt_amd_pnp_detail(const lvt_amd_params *pin, const double q_in[4], 
     int8_t *dLevel = nullptr;
     Pose *dOut = nullptr;
     int *dInfo = nullptr;
+    double *dTrace = nullptr;
+    if (!trace || trace_cap < 0) trace_cap = 0;
     int rc = -1;
     const size_t nn = (size_t)std::max(n, 1);
     if (hipMalloc((void **)&dX, nn * 24) == hipSuccess && hipMalloc((void **)&dErr, nn * 16 + 16) == hipSuccess &&
         hipMalloc((void **)&dObs, nn * 8) == hipSuccess && hipMalloc((void **)&dLevel, nn) == hipSuccess &&
-        hipMalloc((void **)&dOut, sizeof(Pose)) == hipSuccess && hipMalloc((void **)&dInfo, 16) == hipSuccess) {
+        hipMalloc((void **)&dOut, sizeof(Pose)) == hipSuccess && hipMalloc((void **)&dInfo, 32) == hipSuccess &&
+        hipMalloc((void **)&dTrace, (size_t)std::max(trace_cap, 1) * 32) == hipSuccess) {
         (void)hipMemcpy(dX, pts, (size_t)n * 24, hipMemcpyHostToDevice);
         (void)hipMemcpy(dObs, obs, (size_t)n * 8, hipMemcpyHostToDevice);
         Pose prior;
         for (int k = 0; k < 4; k++) prior.q[k] = q_in[k];
         for (int k = 0; k < 3; k++) prior.p[k] = p_in[k];
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&k_pnp_standalone), hipFuncAttributeMaxDynamicSharedMemorySize, PNP_DYN_BYTES);
-        hipLaunchKernelGGL(k_pnp_standalone, dim3(1), dim3(PNP_THREADS), PNP_DYN_BYTES, 0, prm, prior, dX, dObs, dErr, dLevel, n, dOut, dInfo);
+        hipLaunchKernelGGL(k_pnp_standalone, dim3(1), dim3(PNP_THREADS), PNP_DYN_BYTES, 0, prm, prior, dX, dObs, dErr, dLevel, n, dOut, dInfo,
+                           trace_cap ? dTrace : (double *)nullptr, trace_cap);
         Pose out;
-        int info[4] = {0, 0, 0, 0};
+        int info[8] = {0, 0, 0, 0, 0, 0, 0, 0};
         if (hipMemcpy(&out, dOut, sizeof(Pose), hipMemcpyDeviceToHost) == hipSuccess &&
-            hipMemcpy(info, dInfo, 16, hipMemcpyDeviceToHost) == hipSuccess) {
+            hipMemcpy(info, dInfo, 32, hipMemcpyDeviceToHost) == hipSuccess) {
+            if (stats) stats[0] = info[3], stats[1] = info[4], stats[2] = info[5];
+            if (trace_cap && hipMemcpy(trace, dTrace, (size_t)std::min(trace_cap, std::max(info[3], 0)) * 32, hipMemcpyDeviceToHost) != hipSuccess) rc = -2;
             for (int k = 0; k < 4; k++) q_out[k] = out.q[k];
             for (int k = 0; k < 3; k++) p_out[k] = out.p[k];
             if (n_solve_calls) *n_solve_calls = info[0];
             if (borderline) *borderline = info[2];
-            rc = info[1];
+            rc = (rc == -2) ? -1 : info[1];
             if (err_out && hipMemcpy(err_out, dErr, (size_t)n * 16, hipMemcpyDeviceToHost) != hipSuccess) rc = -1;
             if (level_out) {
                 std::vector<int8_t> lv((size_t)std::max(n, 1));
@@ -1525,8 +1699,12 @@ LVT_API int lvt_amd_pnp_detail(const lvt_amd_params *pin, const double q_in[4], 
             }
         }
     }
-    (void)hipFree(dX), (void)hipFree(dErr), (void)hipFree(dObs), (void)hipFree(dLevel), (void)hipFree(dOut), (void)hipFree(dInfo);
+    (void)hipFree(dX), (void)hipFree(dErr), (void)hipFree(dObs), (void)hipFree(dLevel), (void)hipFree(dOut), (void)hipFree(dInfo), (void)hipFree(dTrace);
     return rc;
+}
+LVT_API int lvt_amd_pnp_detail(const lvt_amd_params *pin, const double q_in[4], const double p_in[3], const double *pts, const float *obs, int n,
+                               double q_out[4], double p_out[3], int *n_solve_calls, double *err_out, int *level_out, int *borderline) {
+    return lvt_amd_pnp_trace(pin, q_in, p_in, pts, obs, n, q_out, p_out, n_solve_calls, err_out, level_out, borderline, nullptr, 0, nullptr);
 }
 LVT_API int lvt_amd_pnp(const lvt_amd_params *pin, const double q_in[4], const double p_in[3], const double *pts, const float *obs, int n,
                         double q_out[4], double p_out[3], int *n_solve_calls) {

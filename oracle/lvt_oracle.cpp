@@ -696,6 +696,9 @@ struct PnpResult {
     int inliers = 0;
     int borderline = 0;      // gate decisions (both passes) taken within kGateMargin of the threshold
     double min_margin = 1e300;  // the closest any gate decision came to it
+    // the branches of A.6 a benign scene never takes: LM trials (solve + update + chi2 per trial), trials REJECTED (rho <= 0 or a non-finite
+    // chi2: lambda *= ni, pop()), passes ended by Terminate (qmax == 10 or rho == 0)
+    int trials = 0, rejections = 0, terminates = 0;
 };
 // the last pnp_compute_pose of this thread: errors the gates saw (pass 2's), for tests that compare them edge by edge
 static thread_local std::vector<double> g_last_pnp_err;
@@ -817,6 +820,8 @@ PnpResult pnp_compute_pose(const lvto_params &prm, const Pose &prior, const std:
                     trace->push_back(tempChi);
                     trace->push_back(rho);
                 }
+                res.trials++;
+                if (!(rho > 0 && std::isfinite(tempChi))) res.rejections++;
                 if (rho > 0 && std::isfinite(tempChi)) {
                     double alpha = 1. - std::pow((2 * rho - 1), 3);
                     alpha = (std::min)(alpha, 2.0 / 3.0);
@@ -832,6 +837,7 @@ PnpResult pnp_compute_pose(const lvto_params &prm, const Pose &prior, const std:
                 qmax++;
             } while (rho < 0 && qmax < 10);
             if (qmax == 10 || rho == 0) ok = false;  // Terminate
+            if (!ok) res.terminates++;
         }
         // chi2 gate on the errors of the last computeActiveErrors() (pnp_solver.cpp:109-116)
         for (int k = 0; k < n; k++) {
@@ -1224,6 +1230,9 @@ struct System {
         counts[LVTO_C_PNP_ITERS] = pr.solve_calls;
         counts[LVTO_C_PNP_INLIERS] = pr.inliers;
         counts[LVTO_C_PNP_BORDERLINE] = pr.borderline;
+        counts[LVTO_C_PNP_TRIALS] = pr.trials;
+        counts[LVTO_C_PNP_REJECTIONS] = pr.rejections;
+        counts[LVTO_C_PNP_TERMINATES] = pr.terminates;
         const Pose optimized = pr.pose;
         clean_untracked(ls);
         if (prm.staged_threshold > 0) update_staged(optimized, ls);
@@ -1556,6 +1565,9 @@ int lvto_pnp_last_gate(double *err_out, int n, double *min_margin) {
     for (int i = 0; i < std::min(2 * n, (int)g_last_pnp_err.size()); i++) err_out[i] = g_last_pnp_err[i];
     if (min_margin) *min_margin = g_last_pnp.min_margin;
     return g_last_pnp.borderline;
+}
+void lvto_pnp_last_stats(int out[3]) {
+    out[0] = g_last_pnp.trials, out[1] = g_last_pnp.rejections, out[2] = g_last_pnp.terminates;
 }
 int lvto_triangulate_one(const lvto_params *p, const double q[4], const double pos[3], float ulx, float uly, float urx, float ury,
                          double out_xyz[3]) {

@@ -84,6 +84,10 @@ enum {
     LVTO_C_FRAME,
     LVTO_C_OVERFLOW_UNUSED,  /* (slot 18 is the HIP path's capacity-overflow mask; always 0 here) */
     LVTO_C_PNP_BORDERLINE,   /* chi2-gate decisions (both passes) within 1e-8 of the 5.991 threshold */
+    LVTO_C_ROW_FALLBACK_UNUSED, /* (slot 20 is the HIP path's "row lists built on the tracking stream" flag; always 0 here) */
+    LVTO_C_PNP_TRIALS,       /* LM trials of both passes (solve + update + chi2 each) */
+    LVTO_C_PNP_REJECTIONS,   /* ... of which rejected (rho <= 0 or non-finite chi2: lambda *= ni, pop()) */
+    LVTO_C_PNP_TERMINATES,   /* passes ended by Terminate (qmax == 10 or rho == 0) */
     LVTO_C__COUNT = 32
 };
 void lvto_get_counts(lvto_handle h, int out[LVTO_C__COUNT]);
@@ -128,6 +132,8 @@ int lvto_pnp(const lvto_params *p, const double q_in[4], const double p_in[3], c
 /* the gates of the last lvto_pnp / frame on this thread: copies the 2n edge errors they saw, *min_margin = the closest
    |e^2 - 5.991| of any decision; returns the number of decisions within 1e-8 of the threshold */
 int lvto_pnp_last_gate(double *err_out, int n, double *min_margin);
+/* ... and its LM bookkeeping: out = {trials, rejected trials, passes ended by Terminate} */
+void lvto_pnp_last_stats(int out[3]);
 /* linear-LS stereo triangulation of one pair incl. gates (local_map.cpp:276-319); returns 1 if kept */
 int lvto_triangulate_one(const lvto_params *p, const double q[4], const double pos[3], float ulx,
                          float uly, float urx, float ury, double out_xyz[3]);

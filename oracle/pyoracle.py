@@ -13,7 +13,9 @@ _SO = os.path.join(_HERE, "liblvt_oracle.so")
 N_COUNTS = 32
 COUNT_NAMES = ["n_left", "n_right", "map_size", "staged_size", "n_matches", "second_pass", "n_row_matches",
                "n_triangulated", "triangulated", "retry_left", "retry_right", "pnp_iters", "pnp_inliers",
-               "map_size_at_match", "n_staged_erased", "n_staged_promoted", "n_culled", "frame", "overflow", "pnp_borderline"]
+               "map_size_at_match", "n_staged_erased", "n_staged_promoted", "n_culled", "frame", "overflow", "pnp_borderline",
+               None,  # (slot 20: HIP path only)
+               "pnp_trials", "pnp_rejections", "pnp_terminates"]
 
 
 def build(force: bool = False):
@@ -61,6 +63,7 @@ def lib():
         L.lvto_hamming_top2.argtypes = [vp, vp, C.c_int, vp, vp]
         L.lvto_pnp.argtypes = [vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp, C.c_int, vp]
         L.lvto_pnp_last_gate.argtypes = [vp, C.c_int, vp]
+        L.lvto_pnp_last_stats.argtypes = [vp]
         L.lvto_triangulate_one.argtypes = [vp, vp, vp, C.c_float, C.c_float, C.c_float, C.c_float, vp]
         L.lvto_motion_predict.argtypes = [vp, vp, vp, vp, vp]
         _lib = L
@@ -127,7 +130,7 @@ class Oracle:
     def counts(self):
         a = np.zeros(N_COUNTS, dtype=np.int32)
         lib().lvto_get_counts(self.h, _p(a))
-        return {n: int(a[i]) for i, n in enumerate(COUNT_NAMES)}
+        return {n: int(a[i]) for i, n in enumerate(COUNT_NAMES) if n}
 
     def features(self, eye=0, cap=16384):
         xy = np.zeros((cap, 2), np.float32); resp = np.zeros(cap, np.float32); desc = np.zeros((cap, 32), np.uint8)
@@ -246,6 +249,9 @@ def pnp(params, q_in, p_in, pts, obs, trace_cap=256):
     pnp.last_borderline = lib().lvto_pnp_last_gate(_p(err), len(pts), C.byref(mm))   # gate decisions within 1e-8 of the threshold
     pnp.last_min_margin = mm.value
     pnp.last_err = err.reshape(-1, 2)     # the edge errors pass 2's gate saw
+    st = np.zeros(3, np.int32)
+    lib().lvto_pnp_last_stats(_p(st))
+    pnp.last_trials, pnp.last_rejections, pnp.last_terminates = int(st[0]), int(st[1]), int(st[2])
     return q, p, marks, tr[:min(n, trace_cap)].copy()
 
 

@@ -7,6 +7,7 @@ from lvt_amd.synth import make_world
 
 POSE_TOL = 1e-4      # BASELINE.json: per-frame SE3 within 1e-4 rel of the CPU reference
 XYZ_TOL = 1e-7       # map point positions (fp64, different summation order only)
+PRED_TOL = 1e-7      # motion-model prediction (fp64: quaternion w x y z, position) -- it inherits the optimised pose's last digits
 
 
 def make_case(kind="kitti", seed=0, scale=1.0, overrides=None):
@@ -67,6 +68,9 @@ def diff_frame(hip, orc):
     close("map xyz", mh[0], mo[0], XYZ_TOL); eq("map counter", mh[1], mo[1]); eq("map age", mh[2], mo[2]); eq("map desc", mh[3], mo[3])
     so, sh = orc.staged(), hip.staged()
     close("staged xyz", sh[0], so[0], XYZ_TOL); eq("staged counter", sh[1], so[1]); eq("staged desc", sh[2], so[2])
+    # MM row (lvt_motion_model.cpp:42-65): the pose the frame's matching started from
+    qo, po = orc.predicted_pose(); qh, ph = hip.predicted_pose()
+    close("predicted pose q", qh, qo, PRED_TOL); close("predicted pose p", ph, po, PRED_TOL)
     if orc.status != hip.get_state():
         msgs.append(f"status hip={hip.get_state()} oracle={orc.status}")
     return msgs

@@ -266,6 +266,58 @@ def test_pnp_standalone(hip_lib, oracle_lib):
         assert border_h == oracle_lib.pnp.last_borderline == 0, (trial, border_h, oracle_lib.pnp.last_borderline, oracle_lib.pnp.last_min_margin)
 
 
+def _pnp_hard_case(prm, seed, n, off_t, off_deg, outl, big):
+    """prior `off_t` metres / `off_deg` degrees away from the truth (identity), a fraction `outl` of gross outliers up to `big` pixels"""
+    rng = np.random.default_rng(seed)
+    X = np.column_stack([rng.uniform(-20, 20, n), rng.uniform(-5, 5, n), rng.uniform(6, 60, n)])
+    uv = np.column_stack([prm.fx * X[:, 0] / X[:, 2] + prm.cx, prm.fy * X[:, 1] / X[:, 2] + prm.cy])
+    uv = np.rint(uv + rng.normal(0, 0.4, uv.shape)).astype(np.float32)
+    k = rng.random(n) < outl
+    uv[k] += rng.uniform(-big, big, (int(k.sum()), 2)).astype(np.float32)
+    ax = rng.normal(size=3); ax /= np.linalg.norm(ax)
+    a = np.deg2rad(off_deg)
+    q0 = np.array([np.cos(a / 2), *(np.sin(a / 2) * ax)])
+    d = rng.normal(size=3); d /= np.linalg.norm(d)
+    return X, uv, q0, off_t * d
+
+
+# (seed, n, metres off, degrees off, outlier fraction, outlier size): chosen by running the ORACLE over seeds (tools/pnp_hard_cases.py) so that the
+# branches of A.6 a good prior never reaches are taken: rejected trials, Terminate, and a step with |delta| > 1 whose sqrt(1 - |delta|^2) is NaN
+PNP_HARD = [(25, 200, 2.0, 15, 0.3, 200), (12, 60, 5, 60, 0.5, 400), (24, 60, 5, 60, 0.5, 400), (2, 40, 8, 120, 0.5, 400), (11, 40, 8, 120, 0.5, 400),
+            (4, 30, 10, 170, 0.3, 100), (30, 30, 10, 170, 0.3, 100), (31, 30, 10, 170, 0.3, 100), (7, 300, 1.5, 10, 0.3, 25)]
+
+
+def test_pnp_rejected_trials_terminate_and_nan_steps(hip_lib, oracle_lib):
+    """the hardest branch of g2o's Levenberg-Marquardt (lvt_pnp_solver.cpp:105-117): priors 1.5 - 10 m and 10 - 170 degrees off with
+    30 - 50 % gross outliers.  Trial by trial k_pnp must take the oracle's decisions -- same number of trials, the same ones rejected (rho <= 0:
+    lambda *= ni, the estimate popped, the rejected trial's edge errors left in front of the 5.991 gate), Terminate at the same place, NaN steps
+    (|delta| > 1 under sqrt(1 - |delta|^2)) rejected the same way -- with lambda and rho agreeing to rounding."""
+    import lvt_amd
+    prm = lvt_amd.kitti_params()
+    seen_rej = seen_term = seen_nan = 0
+    for case in PNP_HARD:
+        X, uv, q0, p0 = _pnp_hard_case(prm, *case)
+        qo, po, marks, tro = oracle_lib.pnp(prm, q0, p0, X, uv)
+        so = (oracle_lib.pnp.last_trials, oracle_lib.pnp.last_rejections, oracle_lib.pnp.last_terminates)
+        qh, ph, inl, calls, trh, sh = hip_lib.pnp_trace(prm, q0, p0, X, uv)
+        assert sh == so, (case, sh, so)
+        assert calls == oracle_lib.pnp.last_solve_calls and inl == int(marks.sum()), (case, calls, inl)
+        assert trh.shape == tro.shape == (so[0], 4), (case, trh.shape, tro.shape)
+        assert np.array_equal(np.isnan(trh), np.isnan(tro)), case
+        fin = np.isfinite(tro) & np.isfinite(trh)
+        assert np.array_equal(np.isfinite(tro), np.isfinite(trh)), case
+        lam_h, lam_o = trh[:, 0], tro[:, 0]
+        assert np.allclose(lam_h, lam_o, rtol=1e-6, atol=0), (case, lam_h, lam_o)
+        ok = fin[:, 3]
+        # rho = (chi2 - chi2') / scale: compared relative to the chi2 values it is the difference of
+        tol = 1e-9 * (np.abs(tro[ok, 1]) + np.abs(tro[ok, 2]) + 1.0) / np.maximum(np.abs(tro[ok, 1] - tro[ok, 2]), 1e-300) * np.abs(tro[ok, 3]) + 1e-9
+        assert (np.abs(trh[ok, 3] - tro[ok, 3]) <= tol).all(), (case, trh[ok, 3], tro[ok, 3])
+        assert np.array_equal(trh[ok, 3] > 0, tro[ok, 3] > 0), case
+        assert np.allclose(ph, po, rtol=1e-7, atol=1e-7, equal_nan=True) and np.allclose(qh, qo, atol=1e-8, equal_nan=True), (case, ph, po)
+        seen_rej += so[1]; seen_term += so[2]; seen_nan += int(np.isnan(tro).any())
+    assert seen_rej > 0 and seen_term > 0 and seen_nan > 0, (seen_rej, seen_term, seen_nan)
+
+
 def _pnp_case(rng, prm, n):
     X = np.column_stack([rng.uniform(-20, 20, n), rng.uniform(-5, 5, n), rng.uniform(6, 60, n)])
     ang = rng.normal(0, 0.01, 3)

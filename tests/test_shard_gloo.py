@@ -81,6 +81,10 @@ def test_bench_rank_body_on_gloo_world_size_2():
     assert r0["tracking"]["frames_not_tracking"] == 1           # SUM over ranks: rank 1's lost frame shows up in rank 0's line
     for log in (log0, log1):                                    # device sync on both sides of the timed region, warm-up first
         assert log[0] == ("warmup", 3) and log.count("sync") == 2
+    # rank-local windows, reduced afterwards: the line carries every rank's own rate (rank 0: 5 ms per step, rank 1: 10 ms)
+    pr = r0["timing"]["per_rank_fps"]
+    assert len(pr) == 2 and 150 < pr[0] <= 200.5 and 75 < pr[1] <= 100.5, pr
+    assert abs(r0["value"] - 2 * pr[1]) < 0.01 * r0["value"]     # MAX of the durations = the slow rank's
     for k in ("metric", "value", "unit", "config", "vs_baseline", "dtype", "data", "roofline", "cpu_baseline"):
         assert k in r0
 
@@ -109,6 +113,29 @@ def test_plain_bench_command_starts_its_own_ranks():
     assert r["ms_per_step"] >= 2.0                               # the slow rank (2 ms per step) sets the time
     assert abs(r["value"] - 2 * 12 / (r["ms_per_step"] * 12e-3)) < 0.05 * r["value"]
     assert r["tracking"]["frames_not_tracking"] == 1             # rank 1's lost frame, summed into rank 0's line
+
+
+def test_eight_ranks_no_collective_inside_the_window():
+    """cfg 5's launch shape on the stand-in backend: 8 ranks, every rank's step takes the same 5 ms, and rank 1 sleeps 50 ms between its
+    timed window and the reductions.  With rank-local windows that sleep is nobody's time: the whole-job value equals the sum of the
+    ranks' own rates within 1 % (a trailing barrier inside the window would charge the 50 ms -- a quarter of the 200-ms window -- to
+    every rank)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "40", "--warmup", "2", "--backend", "standin",
+                        "--standin-ms", "5", "--standin-tail-ms", "50"], env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    r = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][-1])
+    t = r["timing"]
+    assert r["n_gpus"] == 8 and len(t["per_rank_fps"]) == 8
+    assert abs(r["value"] - t["sum_of_rank_rates"]) <= 0.01 * t["sum_of_rank_rates"], (r["value"], t)
+    assert r["ms_per_step"] < 5.6, r["ms_per_step"]                # 5 ms of sleep per step + its overshoot -- not 5 + 50 / 40
+
+
+def test_cpulist_parser():
+    from lvt_amd.shard import parse_cpulist
+    assert parse_cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11] and parse_cpulist("") == [] and parse_cpulist("5") == [5]
 
 
 def test_total_seqs_spreads_cfg5_over_fewer_gpus():

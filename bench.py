@@ -272,7 +272,11 @@ class HipBackend:
             return {}
         n = min(self.n_frames, args.warmup + args.steps)
         Wm = min(args.warmup, n - 1)
-        vo = self.lvt.LvtSystem.create(self.prm, 1)
+        os.environ["LVT_AMD_ORDERING"] = "polling"   # (a handle created beside a live one would order with events: not the path being compared)
+        try:
+            vo = self.lvt.LvtSystem.create(self.prm, 1)
+        finally:
+            os.environ.pop("LVT_AMD_ORDERING", None)
         res = {}
         for tag in ("first", "second"):   # (twice on the same handle after a reset: the second pass runs with warm clocks)
             vo.reset()

@@ -1336,7 +1336,7 @@ struct CellOrder {
     uint8_t v[CELLS_MAX];
 };
 template <bool BV>  // (a single sequence's descriptor travels in the kernel arguments: one dependent memory hop less at the head of the longest kernel)
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_cells(SeqArg<BV> sa, int pass, int par, CellOrder ord, int lanes, int raw_cap) {
+__device__ __forceinline__ void cells_entry(const SeqArg<BV> &sa, int pass, int par, const CellOrder &ord, int lanes, int raw_cap) {
     int eye = blockIdx.y, cell = blockIdx.x;
     const Seq *Sp;
     if constexpr (BV) {
@@ -1352,6 +1352,17 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const CellLds L = carve_cell_lds(smem, raw_cap);
     cells_work(S, FB, eye, cell, pass, L, raw_cap);
+}
+// A single sequence runs one workgroup per CU with the 159-KB carve: it may use the 128 registers a 1024-thread workgroup can have.  The batch
+// instance is held to 64 so that TWO of its 80-KB workgroups share a CU (at 66 registers it ran one per CU whatever its LDS) -- an occupancy
+// attribute on the template would cap the single-sequence instance too, where a second workgroup can never fit and the cap can only spill.
+template <bool BV>
+__global__ __launch_bounds__(1024) void k_cells(SeqArg<BV> sa, int pass, int par, CellOrder ord, int lanes, int raw_cap) {
+    cells_entry<BV>(sa, pass, par, ord, lanes, raw_cap);
+}
+template <>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_cells<false>(SeqArg<false> sa, int pass, int par, CellOrder ord, int lanes, int raw_cap) {
+    cells_entry<false>(sa, pass, par, ord, lanes, raw_cap);
 }
 
 // ---- an oversized cell as row strips --------------------------------------------------------------------------------------------

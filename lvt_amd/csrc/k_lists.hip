@@ -122,10 +122,14 @@ __global__ __launch_bounds__(LS_THREADS) void k_hamming_batched_lists(SeqArg<BV>
     int *ncand = (MODE == MODE_MAP) ? S.ncand : S.rncand + par * NF_MAX;
     const int radius = S.prm.tracking_radius;
 
-    // (gridDim.x workgroups per sequence share the queries chunk-wise; each stages the train set itself)
-    for (int q0 = blockIdx.x * LS_THREADS; q0 < q_end; q0 += gridDim.x * LS_THREADS) {
+    // gridDim.x workgroups per sequence share the queries in EQUAL contiguous parts (whole wavefronts; each stages the train set itself): a list is one
+    // lane's serial walk, so what a second workgroup buys is issue slots and LDS bandwidth -- 1 000 row lists on one CU are 16 wavefronts on 4 SIMDs
+    // (117 us in a batch of 64 sequences), on eight CUs two wavefronts each
+    const int part = (((q_end + (int)gridDim.x - 1) / (int)gridDim.x) + 63) & ~63;
+    const int q_lo = (int)blockIdx.x * part, q_hi = min(q_end, q_lo + part);
+    for (int q0 = q_lo; q0 < q_hi; q0 += LS_THREADS) {
         const int q = q0 + tid;
-        bool live = q < q_end;
+        bool live = q < q_hi;
         Query Q;
         Q.x = Q.y = Q.r2 = 0.f;
         Q.sy = Q.sx = 0, Q.ey = Q.ex = 0;

@@ -50,6 +50,8 @@ constexpr int ROW_BLOCKS = 32;
 constexpr int MATCH_BLOCKS_GATED = 16;  // k_match_map when it polls for the early stream itself (single sequence): see k_track.hip (8 / 16 / 32: 8 840 / 8 890 / 8 900 frames/s; fewer parked workgroups leave more CUs to other processes on the GPU)
 constexpr int ROW_BLOCKS_BATCH = 16;  // per sequence of a lock-step batch (16 sequences: 8 / 16 / 32 / 64 / 256 -> 30.8k / 36.9k / 35.8k / 35.0k / 31.1k frames/s)
 constexpr int RING = 8;  // frames that may be in flight / un-collected
+// workgroups per sequence of the binned list kernels (k_lists.hip: equal parts of the queries; LVT_AMD_LISTS_WGS=row,map overrides)
+constexpr int LISTS_WGS_ROW = 8, LISTS_WGS_MAP = 1;
 // handles per DEVICE whose k_match_map may poll for the early stream itself: each parks MATCH_BLOCKS_GATED workgroups with 50 KB of LDS;
 // 4 x 16 of them still leave most CUs with the 159 KB a k_cells workgroup needs, more handles use the separate one-wave gate kernel
 constexpr int MAX_FOLDED_GATES = 4;
@@ -189,6 +191,7 @@ struct Context {
     // RAW_CAP_SMALL corners -- 80 KB of LDS instead of 159, TWO workgroups per CU (k_cells is held to 64 VGPRs for that: at 66 it ran one per CU whatever its LDS) --
     // and a cell with more raw corners than that takes the exact global-memory path, as one beyond RAW_CAP does (LVT_AMD_CELLS_RAW_CAP overrides)
     int cells_raw_cap = RAW_CAP;
+    int lists_wgs_row = LISTS_WGS_ROW, lists_wgs_map = LISTS_WGS_MAP;
     int match_blocks_batch = 32;   // workgroups per sequence of a batch's k_match_map (it lists the points appended since the early part: none on most frames,
                                    // and every workgroup's thread 0 recomputes the prediction before it can leave): 256 -> 32 = +6 % frames/s at 16 sequences
                                    // (LVT_AMD_MATCH_BLOCKS_BATCH overrides)
@@ -208,7 +211,10 @@ struct Context {
     // buffer needs a device-side hand-over; the pulls run on stream_p beside the previous frames' kernels and publish d_pull[0] (k_gate_buf polls it;
     // event ordering: ev_pull).  LVT_AMD_PULL_STREAM=0 keeps the pulls on the feature stream (one stream less, the pull then lengthens that chain).
     hipStream_t stream_p = nullptr;
-    bool pull_own_stream = true;
+    int pull_mode = 0;   // LVT_AMD_PULL_STREAM: 0 = the feature stream (default: measured 8 110 frames/s against 4 400 with a fourth stream of the library's own --
+                         // the process's hardware queues are taken, two streams then share one and a polling gate holds up the other), 1 = a stream of its own,
+                         // 2 = the legacy null stream (it has a hardware queue already; the library's streams are non-blocking, so nothing else is ordered by it)
+    bool pull_on_own = false;
     uint8_t *d_img_ring[RING][2] = {};
     float *d_depth_ring[RING] = {};
     uint8_t *h_stage_ring[RING] = {}, *h_stage_ring_dev[RING] = {};
@@ -259,6 +265,7 @@ struct Context {
         if (stream_f) (void)hipStreamSynchronize(stream_f);
         if (stream_e) (void)hipStreamSynchronize(stream_e);
         if (stream_p) (void)hipStreamSynchronize(stream_p);
+        else if (pull_on_own) (void)hipStreamSynchronize(nullptr);
         for (void *p : allocs) (void)hipFree(p);
         for (auto &x : ev_pull) if (x) (void)hipEventDestroy(x);
         for (auto &x : h_stage_ring) if (x) (void)hipHostFree(x);
@@ -488,7 +495,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_switch, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_switch_e, hipEventDisableTiming));
         c->d_pull = c->dalloc<seq_t>(2);
-        if (const char *e = std::getenv("LVT_AMD_PULL_STREAM")) c->pull_own_stream = std::atoi(e) != 0;
+        if (const char *e = std::getenv("LVT_AMD_PULL_STREAM")) c->pull_mode = std::atoi(e);
         if (const char *e = std::getenv("LVT_AMD_TEST_GATE_TIMEOUT")) c->test_gate_timeout = std::atol(e);
         {
             // "events": barrier-only ordering; "polling": the polling gates + early stream; unset: polling for the first live
@@ -532,6 +539,12 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
             if (!prm.big_cell_strips && prm.n_cells * 2 * B > n_cu) c->cells_raw_cap = RAW_CAP_SMALL;
         }
         if (const char *e = std::getenv("LVT_AMD_CELLS_RAW_CAP")) c->cells_raw_cap = std::max(RAW_CAP_SMALL, std::min(RAW_CAP, std::atoi(e) & ~1));
+        if (const char *e = std::getenv("LVT_AMD_LISTS_WGS")) {
+            int r = 0, m = 0;
+            const int got = std::sscanf(e, "%d,%d", &r, &m);
+            if (got >= 1) c->lists_wgs_row = std::max(1, std::min(64, r));
+            if (got >= 2) c->lists_wgs_map = std::max(1, std::min(64, m));
+        }
         if (const char *e = std::getenv("LVT_AMD_MATCH_BLOCKS_BATCH")) c->match_blocks_batch = std::max(1, std::min(256, std::atoi(e)));
         HIPCHK(c, hipHostMalloc((void **)&c->h_fargs, sizeof(FrameArgs) * B * RING, hipHostMallocDefault));
         c->h_seqs.resize(B);
@@ -706,7 +719,7 @@ static void enqueue_frame(Context *c) {
     for (int i = 0; i < Context::PROF_SLOTS; i++) c->ev_used[i] = false;
     // ---- feature stage (stream_f): may start as soon as the tracking chain of frame enq-NPAR released this buffer
     const bool evo = c->events_only;
-    const bool pull_gate = c->pull_wait != 0 && c->stream_p != nullptr;  // (pulls on the feature stream itself are ordered by that stream)
+    const bool pull_gate = c->pull_wait != 0 && c->pull_on_own;  // (pulls on the feature stream itself are ordered by that stream)
     if (c->enq >= NPAR || pull_gate) {
         if (!evo)
             hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, B), dim3(64), 0, sf, S, (seq_t)(c->enq >= NPAR ? c->enq + 1 - NPAR : 0), par,
@@ -757,7 +770,7 @@ static void enqueue_frame(Context *c) {
     LAUNCH_S(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, (const Seq *)S, par, brief_publishes ? (seq_t)(c->enq + 1) : (seq_t)0);
     if (!evo && !brief_publishes) hipLaunchKernelGGL(k_feat_done, dim3(B), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));
     const int bl = c->binned_lists ? 1 : 0;
-    if (evo && bl && c->sensor == 1) LAUNCH_SM(19, sf, k_hamming_batched_lists, MODE_ROW, dim3(2, 1, B), dim3(LS_THREADS), LS_LDS_BYTES, par, (seq_t)0);
+    if (evo && bl && c->sensor == 1) LAUNCH_SM(19, sf, k_hamming_batched_lists, MODE_ROW, dim3(c->lists_wgs_row, 1, B), dim3(LS_THREADS), LS_LDS_BYTES, par, (seq_t)0);
     if (evo) LAUNCH_SM(18, sf, k_candidates, MODE_ROW, dim3(256, 1, B), dim3(256), 0, 0, par, (seq_t)0, bl);  // (normal mode: on the early stream, below)
     if (evo) hipLaunchKernelGGL(k_feat_done, dim3(B), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));
     if (evo) (void)hipEventRecord(c->ev_feat[par], sf);
@@ -767,14 +780,14 @@ static void enqueue_frame(Context *c) {
     if (!evo) {
         hipStream_t se = c->stream_e;
         LAUNCH_S(1, se, k_gate, dim3(1, 1, B), dim3(64), 0, par, (seq_t)c->enq, seq, (c->test_gate_timeout && (long)seq == c->test_gate_timeout) ? 1 : 0);  // polls the previous k_pnp and this frame's features
-        if (bl) LAUNCH_SM(11, se, k_hamming_batched_lists, MODE_MAP, dim3(1, 1, B), dim3(LS_THREADS), LS_LDS_BYTES, par, seq);
+        if (bl) LAUNCH_SM(11, se, k_hamming_batched_lists, MODE_MAP, dim3(c->lists_wgs_map, 1, B), dim3(LS_THREADS), LS_LDS_BYTES, par, seq);
         LAUNCH_S(9, se, k_early_map, dim3((bl && B > 1) ? 32 : 256, 1, B), dim3(256), 0, par, seq, bl);  // (behind the binned list kernel it is the fall-back only)
         LAUNCH_S(10, se, k_early_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, par, seq);
         if (c->sensor == 1) {
             // row-match candidate lists of THIS frame (needed by its k_triangulate, ~70 us from here): they need the two feature
             // sets only, and the feature stream is the longest chain -- here, behind the early part, they lengthen neither it nor
             // the hand-over to the tracking stream.  Few workgroups: the tracking chain's single-workgroup kernels run meanwhile.
-            if (bl) LAUNCH_SM(19, se, k_hamming_batched_lists, MODE_ROW, dim3(2, 1, B), dim3(LS_THREADS), LS_LDS_BYTES, par, seq);
+            if (bl) LAUNCH_SM(19, se, k_hamming_batched_lists, MODE_ROW, dim3(c->lists_wgs_row, 1, B), dim3(LS_THREADS), LS_LDS_BYTES, par, seq);
             LAUNCH_SM(18, se, k_candidates, MODE_ROW, dim3(B == 1 ? ROW_BLOCKS : ROW_BLOCKS_BATCH, 1, B), dim3(256), 0, 0, par, seq, bl);
             hipLaunchKernelGGL(k_row_done, dim3(B), dim3(64), 0, se, S, par, seq);
         }
@@ -1060,7 +1073,7 @@ LVT_API void lvt_amd_get_host_stats(lvt_handle h, long long out[8]) {
     for (int i = 0; i < 8; i++) out[i] = 0;
     if (!c) return;
     out[0] = (long long)c->enq, out[1] = (long long)c->done, out[2] = c->planes_in_place, out[3] = c->planes_staged;
-    out[4] = c->async_frames, out[5] = c->stream_p ? 1 : 0, out[6] = c->score_pieces, out[7] = c->events_only ? 1 : 0;
+    out[4] = c->async_frames, out[5] = c->pull_mode, out[6] = c->score_pieces, out[7] = c->events_only ? 1 : 0;
 }
 
 LVT_API void lvt_amd_profile_enable(lvt_handle h, int enable) {
@@ -1326,7 +1339,13 @@ static int upload_async(Context *c, const unsigned char *left, const void *secon
             if (rgbd) c->d_depth_ring[r] = c->dalloc<float>(nbytes + 4);
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_pull[r], hipEventDisableTiming));
         }
-        if (c->pull_own_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_p, hipStreamNonBlocking));
+        if (c->pull_mode == 1) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_p, hipStreamNonBlocking));
+        if (c->pull_mode == 3 || c->pull_mode == 4) {  // a stream of another PRIORITY: the runtime keeps one pool of hardware queues per priority level
+            int lo = 0, hi = 0;
+            HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));  // (lo = numerically greatest = least urgent)
+            HIPCHK(c, hipStreamCreateWithPriority(&c->stream_p, hipStreamNonBlocking, c->pull_mode == 3 ? lo : hi));
+        }
+        c->pull_on_own = c->pull_mode >= 1 && c->pull_mode <= 4;
     }
     auto device_view = [](const void *p, size_t align) -> const uint8_t * {
         hipPointerAttribute_t a;
@@ -1344,10 +1363,10 @@ static int upload_async(Context *c, const unsigned char *left, const void *secon
         HIPCHK(c, hipHostMalloc((void **)&c->h_stage_ring[slot], c->stage_ring_bytes, hipHostMallocDefault));
         HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_stage_ring_dev[slot], c->h_stage_ring[slot], 0));
     }
-    hipStream_t sp = c->stream_p ? c->stream_p : c->stream_f;
+    hipStream_t sp = c->pull_on_own ? c->stream_p /* (nullptr = the null stream in mode 2) */ : c->stream_f;
     const seq_t seq = (seq_t)(c->enq + 1);
     PullDone done;
-    if (c->stream_p && !c->events_only) done.ctr = reinterpret_cast<unsigned *>(c->d_pull + 1), done.pub = c->d_pull, done.seq = seq;
+    if (c->pull_on_own && !c->events_only) done.ctr = reinterpret_cast<unsigned *>(c->d_pull + 1), done.pub = c->d_pull, done.seq = seq;
     uint8_t *d0 = c->d_img_ring[slot][0], *d1 = c->d_img_ring[slot][1];
     if (!rgbd) {
         done.total = 256;  // two launches of (128, 1) or one of (128, 2)
@@ -1376,7 +1395,7 @@ static int upload_async(Context *c, const unsigned char *left, const void *secon
         }
         hipLaunchKernelGGL(k_stage_copy, dim3(256), dim3(256), 0, sp, reinterpret_cast<const float *>(s1), c->d_depth_ring[slot], nbytes, done);
     }
-    if (c->stream_p && c->events_only) (void)hipEventRecord(c->ev_pull[slot], sp);
+    if (c->pull_on_own && c->events_only) (void)hipEventRecord(c->ev_pull[slot], sp);
     c->pull_wait = seq;
     FrameArgs &f = c->h_fargs[(size_t)slot * c->B];
     f.img[0] = d0;

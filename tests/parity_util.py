@@ -69,8 +69,9 @@ def diff_frame(hip, orc):
     so, sh = orc.staged(), hip.staged()
     close("staged xyz", sh[0], so[0], XYZ_TOL); eq("staged counter", sh[1], so[1]); eq("staged desc", sh[2], so[2])
     # MM row (lvt_motion_model.cpp:42-65): the pose the frame's matching started from
-    qo, po = orc.predicted_pose(); qh, ph = hip.predicted_pose()
-    close("predicted pose q", qh, qo, PRED_TOL); close("predicted pose p", ph, po, PRED_TOL)
+    if co.get("map_size_at_match", 0) > 0:   # (a prediction is only made for a frame that starts in TRACKING: lvt_system.cpp:196-199)
+        qo, po = orc.predicted_pose(); qh, ph = hip.predicted_pose()
+        close("predicted pose q", qh, qo, PRED_TOL); close("predicted pose p", ph, po, PRED_TOL)
     if orc.status != hip.get_state():
         msgs.append(f"status hip={hip.get_state()} oracle={orc.status}")
     return msgs

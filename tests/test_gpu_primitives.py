@@ -281,7 +281,7 @@ def _pnp_hard_case(prm, seed, n, off_t, off_deg, outl, big):
     return X, uv, q0, off_t * d
 
 
-# (seed, n, metres off, degrees off, outlier fraction, outlier size): chosen by running the ORACLE over seeds (tools/pnp_hard_cases.py) so that the
+# (seed, n, metres off, degrees off, outlier fraction, outlier size): chosen by running the ORACLE over seeds (tests/tools/pnp_hard_cases.py) so that the
 # branches of A.6 a good prior never reaches are taken: rejected trials, Terminate, and a step with |delta| > 1 whose sqrt(1 - |delta|^2) is NaN
 PNP_HARD = [(25, 200, 2.0, 15, 0.3, 200), (12, 60, 5, 60, 0.5, 400), (24, 60, 5, 60, 0.5, 400), (2, 40, 8, 120, 0.5, 400), (11, 40, 8, 120, 0.5, 400),
             (4, 30, 10, 170, 0.3, 100), (30, 30, 10, 170, 0.3, 100), (31, 30, 10, 170, 0.3, 100), (7, 300, 1.5, 10, 0.3, 25)]
@@ -294,28 +294,42 @@ def test_pnp_rejected_trials_terminate_and_nan_steps(hip_lib, oracle_lib):
     (|delta| > 1 under sqrt(1 - |delta|^2)) rejected the same way -- with lambda and rho agreeing to rounding."""
     import lvt_amd
     prm = lvt_amd.kitti_params()
-    seen_rej = seen_term = seen_nan = 0
+    seen_rej = seen_term = seen_nan = seen_noise = seen_full = full_rej = full_term = full_nan = 0
     for case in PNP_HARD:
         X, uv, q0, p0 = _pnp_hard_case(prm, *case)
         qo, po, marks, tro = oracle_lib.pnp(prm, q0, p0, X, uv)
         so = (oracle_lib.pnp.last_trials, oracle_lib.pnp.last_rejections, oracle_lib.pnp.last_terminates)
         qh, ph, inl, calls, trh, sh = hip_lib.pnp_trace(prm, q0, p0, X, uv)
-        assert sh == so, (case, sh, so)
-        assert calls == oracle_lib.pnp.last_solve_calls and inl == int(marks.sum()), (case, calls, inl)
-        assert trh.shape == tro.shape == (so[0], 4), (case, trh.shape, tro.shape)
-        assert np.array_equal(np.isnan(trh), np.isnan(tro)), case
-        fin = np.isfinite(tro) & np.isfinite(trh)
-        assert np.array_equal(np.isfinite(tro), np.isfinite(trh)), case
-        lam_h, lam_o = trh[:, 0], tro[:, 0]
-        assert np.allclose(lam_h, lam_o, rtol=1e-6, atol=0), (case, lam_h, lam_o)
+        # A trial whose chi2 equals the estimate's to ~13 digits (LM has converged; g2o keeps iterating to its count of 5) is accepted or rejected on
+        # the LAST BITS of two sums over all edges: rho = (chi2 - chi2') / scale with |chi2 - chi2'| ~ 1e-14 chi2.  No two summation orders -- g2o's,
+        # the oracle's, k_pnp's tree -- agree on that sign; the estimates they lead to differ by ~1e-11 m.  Such a decision ends the trial-by-trial
+        # comparison (the first case of the table has one at its last trial); everything before it, the poses and the inlier set are still held.
+        def noise(tr):
+            d = np.abs(tr[:, 1] - tr[:, 2]) <= 1e-10 * np.abs(tr[:, 1])
+            return int(np.argmax(d)) if d.any() else len(tr)
+        k = min(noise(tro), noise(trh), len(tro), len(trh))
+        if k == len(tro) == len(trh):
+            assert sh == so, (case, sh, so)
+            assert calls == oracle_lib.pnp.last_solve_calls, (case, calls)
+            seen_full += 1
+            full_rej += so[1]; full_term += so[2]; full_nan += int(np.isnan(tro).any())
+        else:
+            seen_noise += 1
+        assert inl == int(marks.sum()), (case, inl)
+        tro_k, trh_k = tro[:k], trh[:k]
+        assert np.array_equal(np.isnan(trh_k), np.isnan(tro_k)) and np.array_equal(np.isfinite(tro_k), np.isfinite(trh_k)), case
+        fin = np.isfinite(tro_k) & np.isfinite(trh_k)
+        assert np.allclose(trh_k[:, 0], tro_k[:, 0], rtol=1e-6, atol=0), (case, trh_k[:, 0], tro_k[:, 0])
         ok = fin[:, 3]
         # rho = (chi2 - chi2') / scale: compared relative to the chi2 values it is the difference of
-        tol = 1e-9 * (np.abs(tro[ok, 1]) + np.abs(tro[ok, 2]) + 1.0) / np.maximum(np.abs(tro[ok, 1] - tro[ok, 2]), 1e-300) * np.abs(tro[ok, 3]) + 1e-9
-        assert (np.abs(trh[ok, 3] - tro[ok, 3]) <= tol).all(), (case, trh[ok, 3], tro[ok, 3])
-        assert np.array_equal(trh[ok, 3] > 0, tro[ok, 3] > 0), case
+        tol = 1e-9 * (np.abs(tro_k[ok, 1]) + np.abs(tro_k[ok, 2]) + 1.0) / np.maximum(np.abs(tro_k[ok, 1] - tro_k[ok, 2]), 1e-300) * np.abs(tro_k[ok, 3]) + 1e-9
+        assert (np.abs(trh_k[ok, 3] - tro_k[ok, 3]) <= tol).all(), (case, trh_k[ok, 3], tro_k[ok, 3])
+        assert np.array_equal(trh_k[ok, 3] > 0, tro_k[ok, 3] > 0), case
         assert np.allclose(ph, po, rtol=1e-7, atol=1e-7, equal_nan=True) and np.allclose(qh, qo, atol=1e-8, equal_nan=True), (case, ph, po)
         seen_rej += so[1]; seen_term += so[2]; seen_nan += int(np.isnan(tro).any())
-    assert seen_rej > 0 and seen_term > 0 and seen_nan > 0, (seen_rej, seen_term, seen_nan)
+    # (the cases compared to their last trial must themselves cover the three branches)
+    assert seen_rej > 0 and seen_term > 0 and seen_nan > 0 and seen_full >= 3 and full_rej > 0 and full_term + full_nan > 0, \
+        (seen_rej, seen_term, seen_nan, seen_noise, seen_full, full_rej, full_term, full_nan)
 
 
 def _pnp_case(rng, prm, n):

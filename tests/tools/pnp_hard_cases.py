@@ -1,5 +1,7 @@
-import sys, numpy as np
-sys.path.insert(0,'/root/repo')
+"""Search (on the CPU oracle) for motion-only-BA inputs that take the branches of g2o's Levenberg-Marquardt a good prior never reaches: rejected
+trials, Terminate, NaN steps.  Its hits are the PNP_HARD table of tests/test_gpu_primitives.py."""
+import os, sys, numpy as np
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import lvt_amd
 from oracle import pyoracle as O
 prm = lvt_amd.kitti_params()

@@ -21,7 +21,15 @@ extern "C" float lab_run(const void *q_desc, const void *q_xy, const void *t_des
         a.dbg = d_dbg;
         hipMemcpy(d_dbg + 15, dbg_host + 15, 8, hipMemcpyHostToDevice);
     }
+#ifdef LAB_BAND
+    BandArgs ba;
+    ba.h = a;
+    if (!hamming_band_setup(ba)) return -3.f;
+    size_t lds = hamming_band_lds_bytes(N, M, ba.nbands * ba.nxb);
+#define a ba
+#else
     size_t lds = hamming_lds_bytes(N, M, a.nbx * a.nby);
+#endif
     if (getenv("LAB_LDS_EXTRA")) lds += atoi(getenv("LAB_LDS_EXTRA"));  // e.g. force one workgroup per CU
     auto kern = LAB_INSTANCE;
     if (hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess) return -1.f;
@@ -39,6 +47,9 @@ extern "C" float lab_run(const void *q_desc, const void *q_xy, const void *t_des
     float ms = 0;
     hipEventElapsedTime(&ms, e0, e1);
     hipEventDestroy(e0), hipEventDestroy(e1);
+#ifdef LAB_BAND
+#undef a
+#endif
     if (d_dbg) {
         hipMemcpy(dbg_host, d_dbg, dbg_bytes, hipMemcpyDeviceToHost);
         hipFree(d_dbg);

@@ -10,12 +10,15 @@ ap.add_argument("kernel")
 ap.add_argument("B", nargs="?", type=int, default=8192)
 ap.add_argument("--instance", default="k_hamming_batched<0, 3, 1, 2>")
 ap.add_argument("--has-b", action="store_true")
+ap.add_argument("--band", action="store_true", help="the kernel takes BandArgs (k_hamming_band.hip)")
 ap.add_argument("--build-only", action="store_true")
 ap.add_argument("--ref", default=os.path.join(ROOT, "lvt_amd", "lib", "liblvt_c.so"), help="library whose matcher output is the reference (default: the shipped one)")
 ap.add_argument("--reps", type=int, default=3)
 ap.add_argument("--stop", type=int, default=0)
 ap.add_argument("--timeline", action="store_true", help="per-workgroup (start, end, CU) records: slot occupancy and gaps")
 ap.add_argument("--pmc", action="store_true", help="one launch only (under rocprofv3 --pmc)")
+ap.add_argument("--coherent", type=int, default=0, help="experiment: 1 = every query of a problem at the same position (all lanes read the same LDS addresses: no bank conflicts, "
+                "perfectly balanced waves), 2 = queries sorted along x (neighbouring lanes read neighbouring list entries)")
 a = ap.parse_args()
 kern = os.path.abspath(a.kernel)
 tag = os.path.splitext(os.path.basename(kern))[0]
@@ -23,7 +26,7 @@ so = os.path.join(HERE, "_lab_%s%s.so" % (tag, "_stop%d" % a.stop if a.stop else
 if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(kern):
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-inline-asm", "-Wno-unused-value", "-shared",
            "-I" + os.path.join(ROOT, "lvt_amd", "csrc"), '-DLAB_KERNEL="%s"' % kern, "-DLAB_INSTANCE=" + a.instance.replace(" ", "")] + \
-          (["-DLAB_HAS_B"] if a.has_b else []) + ["-DLAB_STOP=%d" % a.stop] + ["-o", so, os.path.join(HERE, "lab.hip")]
+          (["-DLAB_HAS_B"] if a.has_b else []) + (["-DLAB_BAND"] if a.band else []) + ["-DLAB_STOP=%d" % a.stop] + ["-o", so, os.path.join(HERE, "lab.hip")]
     subprocess.check_call(cmd)
 if a.build_only:
     sys.exit(0)
@@ -35,6 +38,10 @@ qd = torch.randint(0, 256, (B, M, 32), dtype=torch.uint8, device=dev, generator=
 td = torch.randint(0, 256, (B, N, 32), dtype=torch.uint8, device=dev, generator=g)
 qxy = (torch.rand((B, M, 2), device=dev, generator=g) * torch.tensor([W - 1.0, H - 1.0], device=dev)).contiguous()
 txy = torch.floor(torch.rand((B, N, 2), device=dev, generator=g) * torch.tensor([W - 1.0, H - 1.0], device=dev)).contiguous()
+if a.coherent == 1:
+    qxy = qxy[:, :1, :].expand(B, M, 2).contiguous()
+elif a.coherent == 2:
+    qxy = torch.gather(qxy, 1, torch.argsort(qxy[:, :, 0], dim=1).unsqueeze(-1).expand(B, M, 2)).contiguous()
 tf = (torch.rand((B, N), device=dev, generator=g) < 0.02).to(torch.uint8)   # a few flagged train features
 out = torch.zeros((B, M, 4), dtype=torch.int32, device=dev)
 ref = torch.zeros_like(out)

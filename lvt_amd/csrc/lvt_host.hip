@@ -50,8 +50,10 @@ constexpr int ROW_BLOCKS = 32;
 constexpr int MATCH_BLOCKS_GATED = 16;  // k_match_map when it polls for the early stream itself (single sequence): see k_track.hip (8 / 16 / 32: 8 840 / 8 890 / 8 900 frames/s; fewer parked workgroups leave more CUs to other processes on the GPU)
 constexpr int ROW_BLOCKS_BATCH = 16;  // per sequence of a lock-step batch (16 sequences: 8 / 16 / 32 / 64 / 256 -> 30.8k / 36.9k / 35.8k / 35.0k / 31.1k frames/s)
 constexpr int RING = 8;  // frames that may be in flight / un-collected
-// workgroups per sequence of the binned list kernels (k_lists.hip: equal parts of the queries; LVT_AMD_LISTS_WGS=row,map overrides)
-constexpr int LISTS_WGS_ROW = 8, LISTS_WGS_MAP = 1;
+// workgroups per sequence of the binned list kernels (k_lists.hip: equal parts of the queries; LVT_AMD_LISTS_WGS=row,map overrides).  Measured in round 4
+// (64 sequences, HIP-event time of the row-list launch): 2 / 8 / 16 workgroups per sequence = 113 / 151 / 241 us; lock-step batches of 16 / 32 sequences
+// 68.5k / 88.8k, 68.2k / 82.4k, 59.2k / 77.1k frames/s -- every workgroup stages the whole train set again, and from 32 sequences on the chip is full anyway
+constexpr int LISTS_WGS_ROW = 2, LISTS_WGS_MAP = 1;
 // handles per DEVICE whose k_match_map may poll for the early stream itself: each parks MATCH_BLOCKS_GATED workgroups with 50 KB of LDS;
 // 4 x 16 of them still leave most CUs with the 159 KB a k_cells workgroup needs, more handles use the separate one-wave gate kernel
 constexpr int MAX_FOLDED_GATES = 4;

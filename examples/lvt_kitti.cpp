@@ -111,16 +111,25 @@ int main(int argc, char **argv) {
     std::vector<double> rows;  // 12 per processed frame
     double total_time = 0.0;
     long n = 0;
-    for (long i = 0; i < frame_count; i++) {
-        if (i > 0 && (!load_gray(stem(0, i), left, err) || !load_gray(stem(1, i), right, err))) break;  // unreadable frame
+    // Frame i is enqueued (lvt_system::track_async: its images are the library's when the call returns), frame i + 1 is read and decoded while it
+    // tracks, then frame i's pose is collected: the reference's loop (kitti_example.cpp:113-138) does the two in turn.  Same poses, same file.
+    Gray nleft, nright;
+    bool have = true;
+    for (long i = 0; i < frame_count && have; i++) {
         if (left.w != params.img_width || left.h != params.img_height || right.w != left.w || right.h != left.h) {
             std::cout << "frame " << i << ": image size changed" << std::endl;
             break;
         }
         std::cout << "Frame number: " << i << "\r" << std::flush;
         const auto t0 = std::chrono::steady_clock::now();
-        const lvt_pose pose = vo->track(lvt_image_view(left.px.data(), left.h, left.w), lvt_image_view(right.px.data(), right.h, right.w));
-        total_time += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const bool queued = vo->track_async(lvt_image_view(left.px.data(), left.h, left.w), lvt_image_view(right.px.data(), right.h, right.w));
+        double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (!queued) break;
+        have = i + 1 < frame_count && load_gray(stem(0, i + 1), nleft, err) && load_gray(stem(1, i + 1), nright, err);  // (an unreadable frame ends the run)
+        const auto t1 = std::chrono::steady_clock::now();
+        const lvt_pose pose = vo->wait_pose();
+        dt += std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
+        total_time += dt;  // (time spent inside the tracker's calls, as the reference reports it)
         const lvt_vector3 pos = pose.get_position();  // kitti_example.cpp:40-47
         const lvt_matrix33 R = pose.get_orientation_matrix();
         for (int r = 0; r < 3; r++) {
@@ -129,6 +138,7 @@ int main(int argc, char **argv) {
         }
         n++;
         if (vo->get_state() == lvt_system::eState_LOST) break;
+        if (have) std::swap(left, nleft), std::swap(right, nright);
     }
     std::ofstream file(out_name.c_str());
     file << std::fixed;

@@ -59,6 +59,16 @@ LVT_API lvt_handle lvt_amd_create(const lvt_amd_params *p, int sensor_type);
  * handle per GPU from any of its threads.  lvt_amd_get_device: the owning device, -1 for a NULL handle. */
 LVT_API lvt_handle lvt_amd_create_on_device(const lvt_amd_params *p, int sensor_type, int device);
 LVT_API int lvt_amd_get_device(lvt_handle h);
+/* POOLED handles: independent handles of one device folded into ONE lock-step launch chain by a per-device submission thread (lvt_pool.h).  Independent
+ * handles with a launch chain each share the process's hardware queues badly -- 2 / 4 / 8 of them reach 0.95 x / 1.47 x / 0.65 x of one handle's frame
+ * rate; as seats of a shared chain they reach what a lock-step batch of that size does.  A pooled handle takes lvt_track, lvt_amd_track_device[_async],
+ * lvt_amd_track_async, lvt_amd_wait[_status], lvt_get_status, lvt_amd_reset, lvt_destroy and the per-frame introspection calls, from any thread (one
+ * thread per handle at a time, as for every handle); its results are those of a solo handle fed the same frames.  Stereo only; every handle of a pool has
+ * the same parameters; at most 8 per device; 4 frames outstanding per handle.  Returns NULL when there is no seat or the parameters differ from the pool's.
+ * LVT_AMD_POOL=1 makes lvt_create / lvt_amd_create / lvt_amd_create_on_device hand out pooled handles (falling back to solo ones);
+ * lvt_amd_get_ordering() == 2 says a handle is pooled.  A lone synchronous caller pays two thread hand-overs and a chain launched eight sequences wide:
+ * pooling is for processes that track several sequences at once. */
+LVT_API lvt_handle lvt_amd_create_pooled(const lvt_amd_params *p, int sensor_type, int device /* -1: the current device */);
 /* reference lvt_system::reset (lvt_system.cpp:44-68) */
 LVT_API void lvt_amd_reset(lvt_handle h);
 /* reference lvt_system::track, RGB-D branch (lvt_system.cpp:177-183): gray u8 + depth f32 (metres),
@@ -89,6 +99,8 @@ LVT_API void lvt_amd_wait(lvt_handle h, double R[3][3], double t[3]);
 /* the same, returning the tracking state after THAT frame (1 not initialised, 2 tracking, 3 lost; -1 error) -- lvt_get_status would
  * drain the whole pipeline first */
 LVT_API int lvt_amd_wait_status(lvt_handle h, double R[3][3], double t[3]);
+/* the same with the pose as the tracker holds it (quaternion w x y z + position: what lvt_system::track returns) */
+LVT_API int lvt_amd_wait_pose(lvt_handle h, double q_wxyz[4], double p[3]);
 /* ---- lock-step batch of independent sequences on ONE GPU ----------------------------------------------
  * B sequences (e.g. several KITTI drives) advance frame by frame through a single launch chain (every kernel is
  * launched with gridDim.z = B); the latency-bound serial kernels of the path (pose refinement, greedy resolvers)

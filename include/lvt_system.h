@@ -260,6 +260,22 @@ class lvt_system {
         else lvt_amd_track_rgbd(m_handle, a, static_cast<const float *>(packed(img2, m_buf2)), img1.rows, img1.cols, R, t);
         return current_pose();
     }
+    /* ADDITIVE (not in the reference): the asynchronous form of track().  track_async() enqueues the frame and returns -- pageable images are copied
+     * during the call, page-locked ones must stay valid until wait_pose() has returned that frame -- so the caller can decode frame t + 1 while frame
+     * t tracks (kitti_example.cpp:113-138 does both in turn); wait_pose() returns the poses in the order of the track_async() calls.  false: the
+     * frame was rejected (size / element type), nothing was enqueued. */
+    bool track_async(const lvt_image_view &img1, const lvt_image_view &img2) {
+        if (img2.rows != img1.rows || img2.cols != img1.cols || img1.elem_size != 1 || img2.elem_size != (m_sensor == eSensor_STEREO ? 1 : 4)) return false;
+        const unsigned char *a = static_cast<const unsigned char *>(packed(img1, m_buf1));
+        if (m_sensor == eSensor_STEREO)
+            return lvt_amd_track_async(m_handle, a, static_cast<const unsigned char *>(packed(img2, m_buf2)), img1.rows, img1.cols) == 0;
+        return lvt_amd_track_rgbd_async(m_handle, a, static_cast<const float *>(packed(img2, m_buf2)), img1.rows, img1.cols) == 0;
+    }
+    lvt_pose wait_pose() {
+        double q[4] = {1, 0, 0, 0}, p[3] = {0, 0, 0};
+        m_state = lvt_amd_wait_pose(m_handle, q, p);
+        return lvt_pose(lvt_vector3(p[0], p[1], p[2]), lvt_quaternion(q[0], q[1], q[2], q[3]));
+    }
     /* lvt_system.cpp:209-250: detection skipped, BRIEF at the given corners; Point = anything with float members x, y */
     template <class Point>
     lvt_pose track_with_external_corners(const lvt_image_view &left_image, const lvt_image_view &right_image, std::vector<Point> &corners_locations_left,

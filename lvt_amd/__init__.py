@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "lvt_amd_odometry_create", "lvt_amd_odometry_destroy", "lvt_amd_odometry_reset", "lvt_amd_odometry_push_pose", "lvt_amd_odometry_update", "lvt_amd_profile_enable", "lvt_amd_profile_read", "lvt_amd_get_debug", "lvt_amd_get_timeline", "lvt_amd_get_ordering",
     "lvt_amd_batch_create", "lvt_amd_batch_size", "lvt_amd_batch_track_device_async", "lvt_amd_batch_wait",
     "lvt_amd_batch_get_counts", "lvt_amd_create_on_device", "lvt_amd_get_device", "lvt_amd_wait_status", "lvt_amd_get_host_stats",
-    "lvt_amd_track_async", "lvt_amd_track_rgbd_async", "lvt_amd_pnp_trace",
+    "lvt_amd_track_async", "lvt_amd_track_rgbd_async", "lvt_amd_pnp_trace", "lvt_amd_create_pooled", "lvt_amd_wait_pose",
 ]
 
 N_COUNTS = 32
@@ -72,6 +72,8 @@ def load_library():
     L.lvt_amd_create_on_device.restype = vp
     L.lvt_amd_create_on_device.argtypes = [vp, C.c_int, C.c_int]
     L.lvt_amd_get_device.argtypes = [vp]
+    L.lvt_amd_create_pooled.restype = vp
+    L.lvt_amd_create_pooled.argtypes = [vp, C.c_int, C.c_int]
     L.lvt_destroy.argtypes = [vp]
     L.lvt_amd_reset.argtypes = [vp]
     L.lvt_track.argtypes = [vp, vp, vp, C.c_int, C.c_int, vp, vp]
@@ -159,11 +161,15 @@ class LvtSystem:
 
     # lvt_system::create(const lvt_parameters&, eSensor)  -- lvt_system.cpp:70-127
     @classmethod
-    def create(cls, params: LvtParameters, sensor_type: int = eSensor_STEREO, device: int = -1) -> "LvtSystem":
-        """device >= 0: the handle owns that HIP device whatever the calling thread's current device is (lvt_amd_create_on_device)"""
+    def create(cls, params: LvtParameters, sensor_type: int = eSensor_STEREO, device: int = -1, pooled: bool = False) -> "LvtSystem":
+        """device >= 0: the handle owns that HIP device whatever the calling thread's current device is (lvt_amd_create_on_device);
+        pooled: a seat of the device's shared lock-step chain (lvt_amd_create_pooled)"""
         L = load_library()
         pod = params.to_pod()
-        h = L.lvt_amd_create_on_device(C.byref(pod), sensor_type, device) if device >= 0 else L.lvt_amd_create(C.byref(pod), sensor_type)
+        if pooled:
+            h = L.lvt_amd_create_pooled(C.byref(pod), sensor_type, device)
+        else:
+            h = L.lvt_amd_create_on_device(C.byref(pod), sensor_type, device) if device >= 0 else L.lvt_amd_create(C.byref(pod), sensor_type)
         if not h:
             raise RuntimeError("lvt_amd_create failed (bad parameters, or no usable HIP device -- no CPU fallback)")
         return cls(h, sensor_type)
@@ -330,8 +336,8 @@ class LvtSystem:
         return out
 
     def ordering(self):
-        """'polling' (gates + early stream) or 'events' (barriers only); see lvt_amd_get_ordering"""
-        return "events" if load_library().lvt_amd_get_ordering(self._h) else "polling"
+        """'polling' (gates + early stream), 'events' (barriers only) or 'pooled'; see lvt_amd_get_ordering"""
+        return ("polling", "events", "pooled")[load_library().lvt_amd_get_ordering(self._h)]
 
     def timeline(self):
         a = np.zeros(16, dtype=np.int64)

@@ -84,6 +84,7 @@ struct FrameArgs {
     const float *depth;
     int img_pitch, depth_pitch;
     int ext_corners, n_ext[2];
+    int absent;  // (pooled handles, lvt_host.hip) this sequence has no frame in this lock-step step: every kernel of the step leaves it exactly as it is
 };
 
 // publish this frame's inputs, clear the feature stage's control block
@@ -95,6 +96,7 @@ __device__ __forceinline__ void feat_begin(Seq &S, const FrameArgs &f, int par) 
     FB.img_pitch = f.img_pitch;
     FB.depth_pitch = f.depth_pitch;
     FeatCtl &c = *FB.fc;
+    c.absent = f.absent;
     if (c.poison) return;  // (k_gate_buf: the buffer still belongs to an older frame)
     c.ext_corners = f.ext_corners;
     c.n_ext[0] = f.n_ext[0];
@@ -102,6 +104,10 @@ __device__ __forceinline__ void feat_begin(Seq &S, const FrameArgs &f, int par) 
     c.n_detected[0] = c.n_detected[1] = 0;
     c.retry[0] = c.retry[1] = 0;
     c.overflow = 0;
+    // a sequence without a frame in this step rides the machinery of a frame whose features never arrive: the feature kernels leave the buffer
+    // alone (poison), "no features" is published (skip_seq), the early stream stands down and the tracking chain's prologue finds the frame
+    // skipped -- and, because it was ABSENT rather than late, does not even count it (frame_prologue)
+    if (f.absent) c.poison = 1;
 }
 
 // BEGIN = single sequence: `fa` carries the frame's inputs, block (0, 0, 0) publishes them for the later kernels

@@ -31,9 +31,10 @@ enum : int { MODE_MAP = 0, MODE_STAGED = 1, MODE_ROW = 2 };
 // =================================================================================================
 __device__ __forceinline__ void frame_prologue(const Seq &S, Ctl &c, int par, const Pose &predicted, const double mm_next[14], bool active,
                                                bool first, bool skipped) {
+    const bool absent = skipped && S.fb[par].fc->absent != 0;  // (a pooled handle's idle step: nothing may change, not even the frame counter)
     for (int i = 0; i < N_COUNTS; i++) c.counts[i] = 0;
     c.counts[C_FRAME] = c.frame_number;
-    c.frame_number++;
+    if (!absent) c.frame_number++;
     c.active = active ? 1 : 0;
     c.first_frame = first ? 1 : 0;
     c.do_pass2 = 0;
@@ -2248,7 +2249,8 @@ __global__ __launch_bounds__(1024) void k_triangulate(SeqArg<BV> sa, int par, se
             pose_to_Rt(id, ctl.out_R, ctl.out_t);
             ctl.out_status = 2;
         }
-        if (!ctl.active) *S.fb[par].feat[0].n = *S.fb[par].feat[1].n = 0;  // LOST: no features as far as any caller can see
+        // LOST: no features as far as any caller can see.  (Not for a pooled handle's idle step: the buffer still holds its last real frame's features.)
+        if (!ctl.active && !(ctl.skip && S.fb[par].fc->absent)) *S.fb[par].feat[0].n = *S.fb[par].feat[1].n = 0;
         ctl.counts[C_N_LEFT] = *S.fb[par].feat[0].n;
         ctl.counts[C_N_RIGHT] = *S.fb[par].feat[1].n;
         ctl.counts[C_MAP_SIZE] = *S.map_n;

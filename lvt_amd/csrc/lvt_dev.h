@@ -129,6 +129,7 @@ struct FeatCtl {        // per-frame state of the FEATURE stage (own stream, one
     int overflow;
     seq_t row_seq;    // ... of the frame whose row-match candidate lists it holds (k_row_done; polled by k_triangulate)
     unsigned done_blocks;  // workgroups of the feature stage's last kernel that have finished (the last one publishes feat_seq and resets this)
+    int absent;         // this step has no frame for the sequence (a pooled handle that did not submit one): poison without a report, the frame is not counted
     int poison;         // k_gate_buf gave up waiting for this buffer's previous user: the feature kernels of this frame must not touch it
     seq_t skip_seq;     // ... and this frame (sequence number) has no features: the tracking chain skips it
     seq_t feat_seq;  // sequence number of the frame whose features this buffer holds, published by k_feat_done (polled by k_gate)

@@ -138,7 +138,12 @@ __global__ __launch_bounds__(256) void k_stage_copy(const float *src, float *dst
 constexpr int MAX_DEVICES = 64;
 static std::atomic<int> g_live_contexts[MAX_DEVICES];
 
+// An lvt_handle is either a Context (a sequence, or a lock-step batch, with its own launch chain) or a PoolSlot (lvt_pool.h: one sequence of a
+// lock-step batch SHARED by the pooled handles of a device); the first word tells them apart.
+constexpr uint64_t CTX_MAGIC = 0x4C56545F43545831ull, SLOT_MAGIC = 0x4C56545F534C5431ull;
+
 struct Context {
+    uint64_t magic = CTX_MAGIC;
     double host_enq_us = 0, host_wait_us = 0;  // host time spent enqueueing / blocking (LVT_AMD_HOST_TIMING=1 prints it at destroy)
     long host_enq_n = 0, host_wait_n = 0;
     int gate_timeouts_seen = 0, gate_fatal_seen = 0;
@@ -150,6 +155,8 @@ struct Context {
     long long planes_in_place = 0, planes_staged = 0;  // host-buffer entry points: image / depth planes read in place (page-locked caller buffers) / copied through the staging buffer
     int device = 0;            // the HIP device that owns every allocation, stream and event of this handle (recorded at creation)
     int B = 1;                 // sequences advanced in lock-step by one launch chain
+    int launch_seqs = 0;       // > 0: the NEXT step is launched for the first launch_seqs sequences only (a pool with empty upper seats)
+    int ring_seqs[8] = {};     // ... and what every un-collected step was launched for
     int sensor = 1;
     Params prm{};
     hipStream_t stream = nullptr;    // tracking chain
@@ -218,6 +225,7 @@ struct Context {
                          // 2 = the legacy null stream (it has a hardware queue already; the library's streams are non-blocking, so nothing else is ordered by it)
     bool pull_on_own = false;
     uint8_t *d_img_ring[RING][2] = {};
+    uint8_t *d_pack_ring[RING][2] = {};   // LVT_AMD_PULL_STREAM=5: tightly packed copies made by the copy engine, re-pitched on the device
     float *d_depth_ring[RING] = {};
     uint8_t *h_stage_ring[RING] = {}, *h_stage_ring_dev[RING] = {};
     size_t stage_ring_bytes = 0;
@@ -441,10 +449,11 @@ static void alloc_points(Context *c, MapSoA &P, int cap) {
 
 static void drain(Context *c);
 
-static void reset_state(Context *c) {  // lvt_system::reset (lvt_system.cpp:44-68)
+static void reset_state(Context *c, int only = -1) {  // lvt_system::reset (lvt_system.cpp:44-68); only >= 0: that sequence of a batch alone
     drain(c);
-    c->gate_timeouts_seen = 0, c->gate_fatal_seen = 0;
+    if (only < 0) c->gate_timeouts_seen = 0, c->gate_fatal_seen = 0;
     for (int s = 0; s < c->B; s++) {
+        if (only >= 0 && s != only) continue;
         Ctl z;
         std::memset(&z, 0, sizeof(z));
         z.state = 1;
@@ -459,6 +468,7 @@ static void reset_state(Context *c) {  // lvt_system::reset (lvt_system.cpp:44-6
         z.early_state = 4u * (seq_t)c->enq + 3u;
         z.track_done_seq = (seq_t)c->enq;
         z.late_gate_seq = (seq_t)c->enq;
+        z.gate_timeouts = c->gate_timeouts_seen, z.gate_fatal = c->gate_fatal_seen;  // (the host compares these running counters with what it has seen)
         HIPCHK(c, hipMemcpyAsync(c->d_ctl[s], &z, sizeof(Ctl), hipMemcpyHostToDevice, c->stream));
         HIPCHK(c, hipMemsetAsync(c->h_seqs[s].map_n, 0, sizeof(int), c->stream));
         HIPCHK(c, hipMemsetAsync(c->h_seqs[s].map_cur, 0, sizeof(int), c->stream));
@@ -691,6 +701,10 @@ static void enqueue_frame(Context *c) {
     HostTimer ht(&c->host_enq_us);
     c->host_enq_n++;
     const int B = c->B;
+    // sequences this step's kernels are launched for: all of them -- or, for a pool whose upper seats are empty, the seats in use (lvt_pool.h);
+    // B stays the batch's size: strides of the pinned rings, single-sequence / batch code paths
+    const int Bz = (c->launch_seqs > 0 && c->launch_seqs < B) ? c->launch_seqs : B;
+    c->ring_seqs[(int)(c->enq % RING)] = Bz;
     const Params &p = c->prm;
     Seq *S = c->d_seqs;
     const int slot = (int)(c->enq % RING), par = (int)(c->enq % NPAR);
@@ -700,7 +714,7 @@ static void enqueue_frame(Context *c) {
         // everything the tracking stream holds instead (the frames after it are behind it on the same stream; from frame + NPAR on the events exist).
         if (c->enq > 0 && c->delivered < c->enq) {
             const int pslot = (int)((c->enq - 1) % RING);
-            hipLaunchKernelGGL(k_deliver, dim3(1, 1, B), dim3(64), 0, c->stream, S, c->h_ctl_dev + (size_t)pslot * B, c->h_done_dev + (size_t)pslot * B, (seq_t)c->enq);
+            hipLaunchKernelGGL(k_deliver, dim3(1, 1, Bz), dim3(64), 0, c->stream, S, c->h_ctl_dev + (size_t)pslot * B, c->h_done_dev + (size_t)pslot * B, (seq_t)c->enq);
             c->delivered = c->enq;
         }
         // the early stream may still hold kernels of the pre-switch frames (k_gate, k_early_map, k_candidates<ROW>, k_row_done: they write the row lists
@@ -724,7 +738,7 @@ static void enqueue_frame(Context *c) {
     const bool pull_gate = c->pull_wait != 0 && c->pull_on_own;  // (pulls on the feature stream itself are ordered by that stream)
     if (c->enq >= NPAR || pull_gate) {
         if (!evo)
-            hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, B), dim3(64), 0, sf, S, (seq_t)(c->enq >= NPAR ? c->enq + 1 - NPAR : 0), par,
+            hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, Bz), dim3(64), 0, sf, S, (seq_t)(c->enq >= NPAR ? c->enq + 1 - NPAR : 0), par,
                                pull_gate ? (const seq_t *)c->d_pull : (const seq_t *)nullptr, c->pull_wait);  // polls; see k_gate_buf
         else {
             if (c->enq >= NPAR && (c->switched_at < 0 || (long)c->enq - NPAR >= c->switched_at))  // (frames from before a switch of the ordering: covered by ev_switch)
@@ -736,11 +750,11 @@ static void enqueue_frame(Context *c) {
     if (B == 1) {  // the frame's inputs travel as a kernel argument: no separate "begin" launch, no device read of pinned host memory
         LAUNCH(2, sf, k_score<true>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2), dim3(256), 0, S, c->h_fargs[slot], par, 0);
     } else {
-        LAUNCH(0, sf, k_feat_begin, dim3(B), dim3(64), 0, S, fa, par);
+        LAUNCH(0, sf, k_feat_begin, dim3(Bz), dim3(64), 0, S, fa, par);
         {   // the batch's images in score_pieces launches: see Context::score_pieces
-            const int P = std::max(1, std::min(c->score_pieces, B));
+            const int P = std::max(1, std::min(c->score_pieces, Bz));
             for (int q = 0; q < P; q++) {
-                const int z0 = 2 * (int)((long)B * q / P), z1 = 2 * (int)((long)B * (q + 1) / P);
+                const int z0 = 2 * (int)((long)Bz * q / P), z1 = 2 * (int)((long)Bz * (q + 1) / P);
                 if (q == 0) LAUNCH(2, sf, k_score<false>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, z1 - z0), dim3(256), 0, S, FrameArgs{}, par, z0);
                 else hipLaunchKernelGGL(k_score<false>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, z1 - z0), dim3(256), 0, sf, S, FrameArgs{}, par, z0);
             }
@@ -749,12 +763,12 @@ static void enqueue_frame(Context *c) {
     if (!ext) {
         {
             const int pass = 0;  // (the <200-corner retry pass runs inside k_gather: it is almost never taken)
-            LAUNCH_S(3, sf, k_cells, (B == 1 ? dim3(p.n_cells, 2, 1) : dim3(p.n_cells * 2 * B, 1, 1)), dim3(1024), cells_lds_bytes(c->cells_raw_cap), pass, par, c->cell_order, 2 * B, c->cells_raw_cap);
+            LAUNCH_S(3, sf, k_cells, (B == 1 ? dim3(p.n_cells, 2, 1) : dim3(p.n_cells * 2 * Bz, 1, 1)), dim3(1024), cells_lds_bytes(c->cells_raw_cap), pass, par, c->cell_order, 2 * Bz, c->cells_raw_cap);
             if (p.big_cell_strips) {  // oversized cells: NMS as row strips on several CUs, then ANMS of the merged survivors in three launches
-                hipLaunchKernelGGL(k_cells_strip, dim3(p.n_cells * STRIPS, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
-                hipLaunchKernelGGL(k_cells_big, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
-                hipLaunchKernelGGL(k_cells_radii, dim3(p.n_cells * RADII_WGS, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
-                hipLaunchKernelGGL(k_cells_select, dim3(p.n_cells, 2, B), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
+                hipLaunchKernelGGL(k_cells_strip, dim3(p.n_cells * STRIPS, 2, Bz), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
+                hipLaunchKernelGGL(k_cells_big, dim3(p.n_cells, 2, Bz), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
+                hipLaunchKernelGGL(k_cells_radii, dim3(p.n_cells * RADII_WGS, 2, Bz), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
+                hipLaunchKernelGGL(k_cells_select, dim3(p.n_cells, 2, Bz), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
                 if (c->prof) (void)hipEventRecord(c->ev[3][1], sf);  // (the slot's time covers the five launches)
             }
         }
@@ -767,31 +781,31 @@ static void enqueue_frame(Context *c) {
         (void)hipStreamWaitEvent(sf, c->ev_depth, 0);
         c->depth_wait = false;
     }
-    LAUNCH_S(5, sf, k_gather, dim3(1, 2, B), dim3(1024), CELLS_LDS_BYTES, (const Seq *)S, par);
+    LAUNCH_S(5, sf, k_gather, dim3(1, 2, Bz), dim3(1024), CELLS_LDS_BYTES, (const Seq *)S, par);
     const bool brief_publishes = !evo && B == 1;  // (single sequence: k_brief's last workgroup publishes feat_seq; see k_feat_done)
-    LAUNCH_S(6, sf, k_brief, dim3(64, 2, B), dim3(256), 0, (const Seq *)S, par, brief_publishes ? (seq_t)(c->enq + 1) : (seq_t)0);
-    if (!evo && !brief_publishes) hipLaunchKernelGGL(k_feat_done, dim3(B), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));
+    LAUNCH_S(6, sf, k_brief, dim3(64, 2, Bz), dim3(256), 0, (const Seq *)S, par, brief_publishes ? (seq_t)(c->enq + 1) : (seq_t)0);
+    if (!evo && !brief_publishes) hipLaunchKernelGGL(k_feat_done, dim3(Bz), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));
     const int bl = c->binned_lists ? 1 : 0;
-    if (evo && bl && c->sensor == 1) LAUNCH_SM(19, sf, k_hamming_batched_lists, MODE_ROW, dim3(c->lists_wgs_row, 1, B), dim3(LS_THREADS), LS_LDS_BYTES, par, (seq_t)0);
-    if (evo) LAUNCH_SM(18, sf, k_candidates, MODE_ROW, dim3(256, 1, B), dim3(256), 0, 0, par, (seq_t)0, bl);  // (normal mode: on the early stream, below)
-    if (evo) hipLaunchKernelGGL(k_feat_done, dim3(B), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));
+    if (evo && bl && c->sensor == 1) LAUNCH_SM(19, sf, k_hamming_batched_lists, MODE_ROW, dim3(c->lists_wgs_row, 1, Bz), dim3(LS_THREADS), LS_LDS_BYTES, par, (seq_t)0);
+    if (evo) LAUNCH_SM(18, sf, k_candidates, MODE_ROW, dim3(256, 1, Bz), dim3(256), 0, 0, par, (seq_t)0, bl);  // (normal mode: on the early stream, below)
+    if (evo) hipLaunchKernelGGL(k_feat_done, dim3(Bz), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));
     if (evo) (void)hipEventRecord(c->ev_feat[par], sf);
     // ---- early stream: projection, candidate lists and greedy resolution of the map points that survived the previous frame,
     //      as soon as that frame's pose exists (its k_pnp) -- its k_triangulate only appends behind them
     const seq_t seq = (seq_t)(c->enq + 1);  // this frame's sequence number; the previous frame's is enq (0: none)
     if (!evo) {
         hipStream_t se = c->stream_e;
-        LAUNCH_S(1, se, k_gate, dim3(1, 1, B), dim3(64), 0, par, (seq_t)c->enq, seq, (c->test_gate_timeout && (long)seq == c->test_gate_timeout) ? 1 : 0);  // polls the previous k_pnp and this frame's features
-        if (bl) LAUNCH_SM(11, se, k_hamming_batched_lists, MODE_MAP, dim3(c->lists_wgs_map, 1, B), dim3(LS_THREADS), LS_LDS_BYTES, par, seq);
-        LAUNCH_S(9, se, k_early_map, dim3((bl && B > 1) ? 32 : 256, 1, B), dim3(256), 0, par, seq, bl);  // (behind the binned list kernel it is the fall-back only)
-        LAUNCH_S(10, se, k_early_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, par, seq);
+        LAUNCH_S(1, se, k_gate, dim3(1, 1, Bz), dim3(64), 0, par, (seq_t)c->enq, seq, (c->test_gate_timeout && (long)seq == c->test_gate_timeout) ? 1 : 0);  // polls the previous k_pnp and this frame's features
+        if (bl) LAUNCH_SM(11, se, k_hamming_batched_lists, MODE_MAP, dim3(c->lists_wgs_map, 1, Bz), dim3(LS_THREADS), LS_LDS_BYTES, par, seq);
+        LAUNCH_S(9, se, k_early_map, dim3((bl && B > 1) ? 32 : 256, 1, Bz), dim3(256), 0, par, seq, bl);  // (behind the binned list kernel it is the fall-back only)
+        LAUNCH_S(10, se, k_early_mid, dim3(1, 1, Bz), dim3(RES_THREADS), 0, par, seq);
         if (c->sensor == 1) {
             // row-match candidate lists of THIS frame (needed by its k_triangulate, ~70 us from here): they need the two feature
             // sets only, and the feature stream is the longest chain -- here, behind the early part, they lengthen neither it nor
             // the hand-over to the tracking stream.  Few workgroups: the tracking chain's single-workgroup kernels run meanwhile.
-            if (bl) LAUNCH_SM(19, se, k_hamming_batched_lists, MODE_ROW, dim3(c->lists_wgs_row, 1, B), dim3(LS_THREADS), LS_LDS_BYTES, par, seq);
-            LAUNCH_SM(18, se, k_candidates, MODE_ROW, dim3(B == 1 ? ROW_BLOCKS : ROW_BLOCKS_BATCH, 1, B), dim3(256), 0, 0, par, seq, bl);
-            hipLaunchKernelGGL(k_row_done, dim3(B), dim3(64), 0, se, S, par, seq);
+            if (bl) LAUNCH_SM(19, se, k_hamming_batched_lists, MODE_ROW, dim3(c->lists_wgs_row, 1, Bz), dim3(LS_THREADS), LS_LDS_BYTES, par, seq);
+            LAUNCH_SM(18, se, k_candidates, MODE_ROW, dim3(B == 1 ? ROW_BLOCKS : ROW_BLOCKS_BATCH, 1, Bz), dim3(256), 0, 0, par, seq, bl);
+            hipLaunchKernelGGL(k_row_done, dim3(Bz), dim3(64), 0, se, S, par, seq);
         }
     }
     // ---- tracking chain (stream): strictly ordered frame after frame
@@ -808,24 +822,24 @@ static void enqueue_frame(Context *c) {
         }
         if (evo) {
             (void)hipStreamWaitEvent(st, c->ev_feat[par], 0);  // (the early stream never claims the frame: early_ran_seq stays behind)
-            LAUNCH_S(8, st, k_match_map, dim3(256, 1, B), dim3(256), 0, par, seq, 0, (Ctl *)nullptr, (seq_t *)nullptr);
+            LAUNCH_S(8, st, k_match_map, dim3(256, 1, Bz), dim3(256), 0, par, seq, 0, (Ctl *)nullptr, (seq_t *)nullptr);
         } else if (B == 1 && c->live_on_device() <= MAX_FOLDED_GATES) {
             // one launch: delivers the record, waits for the early stream (polled, no barrier packet), lists the points appended since
             LAUNCH_S(8, st, k_match_map, dim3(MATCH_BLOCKS_GATED, 1, 1), dim3(256), 0, par, seq, 1, prec, pdone);
         } else {
-            LAUNCH_S(7, st, k_gate_late, dim3(1, 1, B), dim3(64), 0, par, seq, prec, pdone);
-            LAUNCH_S(8, st, k_match_map, dim3(B > 1 ? c->match_blocks_batch : 256, 1, B), dim3(256), 0, par, seq, 0, (Ctl *)nullptr, (seq_t *)nullptr);
+            LAUNCH_S(7, st, k_gate_late, dim3(1, 1, Bz), dim3(64), 0, par, seq, prec, pdone);
+            LAUNCH_S(8, st, k_match_map, dim3(B > 1 ? c->match_blocks_batch : 256, 1, Bz), dim3(256), 0, par, seq, 0, (Ctl *)nullptr, (seq_t *)nullptr);
         }
     }
-    LAUNCH_S(12, st, k_track_mid, dim3(1, 1, B), dim3(RES_THREADS), 0, par, seq);
+    LAUNCH_S(12, st, k_track_mid, dim3(1, 1, Bz), dim3(RES_THREADS), 0, par, seq);
     {
         const bool ep = c->sync_call && c->early_pose && !c->prof && B == 1;
-        LAUNCH_S(13, st, k_pnp, dim3(1, 1, B), dim3(PNP_THREADS), PNP_DYN_BYTES, par, seq, ep ? c->h_pose_dev + (size_t)slot * B : (PoseRec *)nullptr,
+        LAUNCH_S(13, st, k_pnp, dim3(1, 1, Bz), dim3(PNP_THREADS), PNP_DYN_BYTES, par, seq, ep ? c->h_pose_dev + (size_t)slot * B : (PoseRec *)nullptr,
                  ep ? c->h_pose_done_dev + (size_t)slot * B : (seq_t *)nullptr);
     }
     if (p.staged_th > 0)  // (a configuration without staging -- EuRoC, TUM -- never has staged points to list)
-        LAUNCH_SM(16, st, k_candidates, MODE_STAGED, dim3(64, 1, B), dim3(256), 0, 0, par, (seq_t)0, 0);
-    LAUNCH_S(20, st, k_triangulate, dim3(1, 1, B), dim3(1024), 0, par, seq, c->h_ctl_dev + (size_t)slot * B,
+        LAUNCH_SM(16, st, k_candidates, MODE_STAGED, dim3(64, 1, Bz), dim3(256), 0, 0, par, (seq_t)0, 0);
+    LAUNCH_S(20, st, k_triangulate, dim3(1, 1, Bz), dim3(1024), 0, par, seq, c->h_ctl_dev + (size_t)slot * B,
            c->h_done_dev + (size_t)slot * B, evo ? 0 : (c->force_row_fallback ? 2 : 1), (evo || c->sync_call) ? 1 : 0);
     if (evo || c->sync_call) c->delivered = c->enq + 1;
     if (evo) (void)hipEventRecord(c->ev_done[slot], st);  // (events-only ordering: the feature stream's barrier needs it)
@@ -838,8 +852,9 @@ static void collect_oldest(Context *c) {
     c->host_wait_n++;
     if (c->done >= c->enq) return;
     const int slot = (int)(c->done % RING);
+    const int Bz = (c->ring_seqs[slot] > 0 && c->ring_seqs[slot] <= c->B) ? c->ring_seqs[slot] : c->B;  // sequences the step was launched for
     if (c->delivered < c->done + 1) {  // the last enqueued frame of an asynchronous run: nobody has been asked to deliver it yet
-        hipLaunchKernelGGL(k_deliver, dim3(1, 1, c->B), dim3(64), 0, c->stream, c->d_seqs, c->h_ctl_dev + (size_t)slot * c->B,
+        hipLaunchKernelGGL(k_deliver, dim3(1, 1, Bz), dim3(64), 0, c->stream, c->d_seqs, c->h_ctl_dev + (size_t)slot * c->B,
                            c->h_done_dev + (size_t)slot * c->B, (seq_t)(c->done + 1));
         c->delivered = c->done + 1;
     }
@@ -847,7 +862,7 @@ static void collect_oldest(Context *c) {
         // release on the device, acquire here)
         const seq_t want = (seq_t)(c->done + 1);
         unsigned spins = 0;
-        for (int s = 0; s < c->B; s++) {
+        for (int s = 0; s < Bz; s++) {
             volatile seq_t *f = c->h_done + (size_t)slot * c->B + s;
             while (__atomic_load_n(f, __ATOMIC_ACQUIRE) != want) {
                 __builtin_ia32_pause();
@@ -883,7 +898,7 @@ static void collect_oldest(Context *c) {
                 }
             }
     }
-    for (int s = 0; s < c->B; s++)
+    for (int s = 0; s < Bz; s++)
         if (c->h_ctl[(size_t)slot * c->B + s].overflow) {
             char buf[128];
             std::snprintf(buf, sizeof(buf), "capacity overflow mask 0x%x in sequence %d", c->h_ctl[(size_t)slot * c->B + s].overflow, s);
@@ -899,7 +914,7 @@ static void collect_oldest(Context *c) {
             else if (c->gate_balance_us < -15.0) c->score_pieces = 1;
         }
     }
-    for (int s = 0; s < c->B; s++)
+    for (int s = 0; s < Bz; s++)
     {
         const Ctl &r = c->h_ctl[(size_t)slot * c->B + s];
         if (r.gate_fatal != c->gate_fatal_seen) {
@@ -984,6 +999,43 @@ static int read_scalar(Context *c, const int *d) {
 
 }  // namespace lvt
 
+#include "lvt_pool.h"
+
+namespace lvt {
+// what the introspection entry points read: a sequence of a context, the feature-buffer parity and the record of its last collected frame.
+// A pooled handle's view holds the pool's lock (no step can start underneath the device reads) after every step in flight has been collected.
+struct View {
+    Context *c = nullptr;
+    int s = 0, par = 0;
+    const Ctl *rec = nullptr;
+    std::unique_lock<std::mutex> lk;
+    DeviceGuard *guard = nullptr;
+    ~View() { delete guard; }
+};
+static bool view_of(lvt_handle h, View &v) {
+    if (is_slot(h)) {
+        PoolSlot *S = static_cast<PoolSlot *>(h);
+        slot_drain(S);
+        v.lk = std::unique_lock<std::mutex>(S->pool->mu);
+        pool_quiesce(S->pool, v.lk);
+        v.c = S->pool->ctx, v.s = S->slot, v.par = S->last.par, v.rec = &S->last.rec;
+    } else if (is_ctx(h)) {
+        Context *c = static_cast<Context *>(h);
+        v.guard = new DeviceGuard(c);
+        drain(c);
+        v.c = c, v.s = 0, v.par = c->last_par, v.rec = &last_ctl(c);
+        return true;
+    } else
+        return false;
+    v.guard = new DeviceGuard(v.c);
+    return true;
+}
+static bool pool_wanted() {
+    const char *e = std::getenv("LVT_AMD_POOL");
+    return e && std::atoi(e) != 0;
+}
+}  // namespace lvt
+
 using namespace lvt;
 
 // =================================================================================================
@@ -994,8 +1046,18 @@ extern "C" {
 LVT_API void lvt_amd_default_params(lvt_amd_params *p) { default_params(p); }
 LVT_API int lvt_amd_params_from_file(const char *f, lvt_amd_params *p) { return params_from_file(f, p) ? 1 : 0; }
 
+LVT_API lvt_handle lvt_amd_create_pooled(const lvt_amd_params *p, int sensor_type, int device) {
+    try {
+        return static_cast<lvt_handle>(pool_join(*p, sensor_type, device));
+    } catch (...) {
+    }
+    return nullptr;
+}
+
 LVT_API lvt_handle lvt_amd_create(const lvt_amd_params *p, int sensor_type) {
     try {
+        if (pool_wanted())
+            if (PoolSlot *S = pool_join(*p, sensor_type, -1)) return static_cast<lvt_handle>(S);
         return static_cast<lvt_handle>(create_context(*p, sensor_type, 1));
     } catch (...) {
     }
@@ -1004,25 +1066,40 @@ LVT_API lvt_handle lvt_amd_create(const lvt_amd_params *p, int sensor_type) {
 
 LVT_API lvt_handle lvt_amd_create_on_device(const lvt_amd_params *p, int sensor_type, int device) {
     try {
+        if (pool_wanted())
+            if (PoolSlot *S = pool_join(*p, sensor_type, device)) return static_cast<lvt_handle>(S);
         return static_cast<lvt_handle>(create_context(*p, sensor_type, 1, device));
     } catch (...) {
     }
     return nullptr;
 }
-LVT_API int lvt_amd_get_device(lvt_handle h) { return h ? static_cast<Context *>(h)->device : -1; }
+LVT_API int lvt_amd_get_device(lvt_handle h) {
+    if (is_slot(h)) return static_cast<PoolSlot *>(h)->pool->device;
+    return h ? static_cast<Context *>(h)->device : -1;
+}
 
 LVT_API lvt_handle lvt_create(const char *config_file_name, int sensor_type) {
     try {
         lvt_amd_params p;
         default_params(&p);
-        if (params_from_file(config_file_name, &p) && (sensor_type == 1 || sensor_type == 2))
+        if (params_from_file(config_file_name, &p) && (sensor_type == 1 || sensor_type == 2)) {
+            if (pool_wanted())
+                if (PoolSlot *S = pool_join(p, sensor_type, -1)) return static_cast<lvt_handle>(S);
             return static_cast<lvt_handle>(create_context(p, sensor_type, 1));
+        }
     } catch (...) {
     }
     return nullptr;
 }
 
 LVT_API void lvt_destroy(lvt_handle h) {
+    if (is_slot(h)) {
+        try {
+            pool_leave(static_cast<PoolSlot *>(h));
+        } catch (...) {
+        }
+        return;
+    }
     if (h && std::getenv("LVT_AMD_HOST_TIMING")) {
         const Context *c = static_cast<Context *>(h);
         if (c->host_enq_n > 0)
@@ -1037,6 +1114,19 @@ LVT_API void lvt_destroy(lvt_handle h) {
 }
 
 LVT_API void lvt_amd_reset(lvt_handle h) {
+    if (is_slot(h)) {
+        try {
+            View v;
+            if (view_of(h, v)) reset_state(v.c, v.s);
+            PoolSlot *S = static_cast<PoolSlot *>(h);
+            std::memset(&S->last.rec, 0, sizeof(Ctl));
+            S->last.rec.state = S->last.rec.out_status = 1;
+            S->last.rec.out_R[0] = S->last.rec.out_R[4] = S->last.rec.out_R[8] = 1.0;
+            S->last.rec.last_pose.q[0] = S->last.rec.predicted.q[0] = 1.0;
+        } catch (...) {
+        }
+        return;
+    }
     try {
         DeviceGuard guard(static_cast<Context *>(h));
         reset_state(static_cast<Context *>(h));
@@ -1045,6 +1135,7 @@ LVT_API void lvt_amd_reset(lvt_handle h) {
 }
 
 LVT_API void lvt_amd_set_stream(lvt_handle h, void *hip_stream) {
+    if (!is_ctx(h)) return;  // (a pooled handle runs on the pool's streams)
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
     try {
@@ -1058,6 +1149,13 @@ LVT_API void lvt_amd_set_stream(lvt_handle h, void *hip_stream) {
 
 LVT_API const char *lvt_amd_last_error(lvt_handle h) {
     if (!h) return "no handle (creation failed: bad parameters, or no HIP device -- there is no CPU fallback)";
+    if (is_slot(h)) {
+        PoolSlot *S = static_cast<PoolSlot *>(h);
+        std::lock_guard<std::mutex> g(S->pool->mu);
+        static thread_local std::string copy;
+        copy = S->err;
+        return copy.c_str();
+    }
     Context *c = static_cast<Context *>(h);
     if (c->early_pending) {  // the last synchronous call returned on its pose: the frame's own reports (capacity overflow, a gate that
                              // timed out, a skipped frame) arrive with its full record -- collect it before answering
@@ -1074,11 +1172,18 @@ LVT_API void lvt_amd_get_host_stats(lvt_handle h, long long out[8]) {
     Context *c = static_cast<Context *>(h);
     for (int i = 0; i < 8; i++) out[i] = 0;
     if (!c) return;
+    if (is_slot(h)) {  // out[0] frames this handle deposited, out[1] lock-step steps the pool launched, out[2] slot frames folded into them, out[3] live handles of the pool
+        PoolSlot *S = static_cast<PoolSlot *>(h);
+        std::lock_guard<std::mutex> g(S->pool->mu);
+        out[0] = S->submitted, out[1] = S->pool->steps, out[2] = S->pool->slot_frames, out[3] = S->pool->live, out[7] = 2;
+        return;
+    }
     out[0] = (long long)c->enq, out[1] = (long long)c->done, out[2] = c->planes_in_place, out[3] = c->planes_staged;
     out[4] = c->async_frames, out[5] = c->pull_mode, out[6] = c->score_pieces, out[7] = c->events_only ? 1 : 0;
 }
 
 LVT_API void lvt_amd_profile_enable(lvt_handle h, int enable) {
+    if (!is_ctx(h)) return;
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
     try {
@@ -1094,6 +1199,7 @@ LVT_API void lvt_amd_profile_enable(lvt_handle h, int enable) {
     }
 }
 LVT_API int lvt_amd_profile_read(lvt_handle h, int slot, char *name, int name_cap, double *total_ms, long *calls) {
+    if (!is_ctx(h)) return 0;
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
     if (slot < 0 || slot >= Context::PROF_SLOTS || !kProfNames[slot][0]) return 0;
@@ -1104,6 +1210,13 @@ LVT_API int lvt_amd_profile_read(lvt_handle h, int slot, char *name, int name_ca
 }
 
 LVT_API void lvt_amd_track_device_async(lvt_handle h, const void *d_left, const void *d_right, int n_rows, int n_cols, int pitch_bytes) {
+    if (is_slot(h)) {
+        try {
+            (void)slot_submit(static_cast<PoolSlot *>(h), static_cast<const uint8_t *>(d_left), static_cast<const uint8_t *>(d_right), n_rows, n_cols, pitch_bytes, false);
+        } catch (...) {
+        }
+        return;
+    }
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
     try {
@@ -1120,6 +1233,7 @@ LVT_API void lvt_amd_track_device_async(lvt_handle h, const void *d_left, const 
         f.img_pitch = pitch_bytes;
         f.depth_pitch = 0;
         f.ext_corners = 0;
+        f.absent = 0;
         f.n_ext[0] = f.n_ext[1] = 0;
         enqueue_frame(c);
     } catch (...) {
@@ -1155,6 +1269,7 @@ LVT_API void lvt_amd_batch_track_device_async(lvt_handle h, const void *const *d
             f.img_pitch = pitch_bytes;
             f.depth_pitch = 0;
             f.ext_corners = 0;
+        f.absent = 0;
             f.n_ext[0] = f.n_ext[1] = 0;
         }
         enqueue_frame(c);
@@ -1188,6 +1303,15 @@ LVT_API void lvt_amd_batch_get_counts(lvt_handle h, int seq, int out[LVT_AMD_C__
 }
 
 LVT_API void lvt_amd_wait(lvt_handle h, double R[3][3], double t[3]) {
+    if (is_slot(h)) {
+        try {
+            PoolSlot *S = static_cast<PoolSlot *>(h);
+            (void)slot_collect(S);
+            slot_result(S, R, t);
+        } catch (...) {
+        }
+        return;
+    }
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
     try {
@@ -1199,6 +1323,16 @@ LVT_API void lvt_amd_wait(lvt_handle h, double R[3][3], double t[3]) {
 }
 
 LVT_API int lvt_amd_wait_status(lvt_handle h, double R[3][3], double t[3]) {  // lvt_amd_wait + the tracking state AFTER that frame (1 / 2 / 3; -1: error)
+    if (is_slot(h)) {
+        try {
+            PoolSlot *S = static_cast<PoolSlot *>(h);
+            (void)slot_collect(S);
+            slot_result(S, R, t);
+            return S->last.rec.state;
+        } catch (...) {
+        }
+        return -1;
+    }
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
     try {
@@ -1211,8 +1345,33 @@ LVT_API int lvt_amd_wait_status(lvt_handle h, double R[3][3], double t[3]) {  //
     return -1;
 }
 
+// lvt_amd_wait_status with the pose as the tracker holds it (quaternion w x y z + position) instead of R, t: what lvt_system::track returns
+LVT_API int lvt_amd_wait_pose(lvt_handle h, double q_wxyz[4], double p[3]) {
+    double R[3][3], t[3];
+    const int st = lvt_amd_wait_status(h, R, t);
+    if (st < 0) return st;
+    const Ctl *rec = nullptr;
+    if (is_slot(h)) rec = &static_cast<PoolSlot *>(h)->last.rec;
+    else if (is_ctx(h)) rec = &last_ctl(static_cast<Context *>(h));
+    if (!rec) return -1;
+    for (int k = 0; k < 4; k++) q_wxyz[k] = rec->last_pose.q[k];
+    for (int k = 0; k < 3; k++) p[k] = rec->last_pose.p[k];
+    return st;
+}
+
 LVT_API void lvt_amd_track_device(lvt_handle h, const void *d_left, const void *d_right, int n_rows, int n_cols, int pitch_bytes,
                                   double R[3][3], double t[3]) {
+    if (is_slot(h)) {
+        try {
+            PoolSlot *S = static_cast<PoolSlot *>(h);
+            slot_drain(S);
+            if (slot_submit(S, static_cast<const uint8_t *>(d_left), static_cast<const uint8_t *>(d_right), n_rows, n_cols, pitch_bytes, false) != 0) return;
+            (void)slot_collect(S);
+            slot_result(S, R, t);
+        } catch (...) {
+        }
+        return;
+    }
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
     if (!size_ok(c, n_rows, n_cols) || (pitch_bytes & 15)) {
@@ -1305,6 +1464,7 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
         };
     }
     f.ext_corners = ext;
+    f.absent = 0;
     f.n_ext[0] = ncl;
     f.n_ext[1] = ncr;
     if (ext) {
@@ -1342,6 +1502,9 @@ static int upload_async(Context *c, const unsigned char *left, const void *secon
             HIPCHK(c, hipEventCreateWithFlags(&c->ev_pull[r], hipEventDisableTiming));
         }
         if (c->pull_mode == 1) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_p, hipStreamNonBlocking));
+        if (c->pull_mode == 5 && !rgbd)
+            for (int r = 0; r < RING; r++)
+                for (int e = 0; e < 2; e++) c->d_pack_ring[r][e] = c->dalloc<uint8_t>(nbytes + 64);
         if (c->pull_mode == 3 || c->pull_mode == 4) {  // a stream of another PRIORITY: the runtime keeps one pool of hardware queues per priority level
             int lo = 0, hi = 0;
             HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));  // (lo = numerically greatest = least urgent)
@@ -1370,7 +1533,15 @@ static int upload_async(Context *c, const unsigned char *left, const void *secon
     PullDone done;
     if (c->pull_on_own && !c->events_only) done.ctr = reinterpret_cast<unsigned *>(c->d_pull + 1), done.pub = c->d_pull, done.seq = seq;
     uint8_t *d0 = c->d_img_ring[slot][0], *d1 = c->d_img_ring[slot][1];
-    if (!rgbd) {
+    if (!rgbd && c->pull_mode == 5) {
+        // copy engine: host -> packed device buffer (pageable sources go through the staging ring first), then one kernel re-pitches both planes
+        const void *h0 = left, *h1 = second;
+        if (!s0) std::memcpy(c->h_stage_ring[slot], left, nbytes), h0 = c->h_stage_ring[slot];
+        if (!s1) std::memcpy(c->h_stage_ring[slot] + img_b, second, nbytes), h1 = c->h_stage_ring[slot] + img_b;
+        HIPCHK(c, hipMemcpyAsync(c->d_pack_ring[slot][0], h0, nbytes, hipMemcpyHostToDevice, sp));
+        HIPCHK(c, hipMemcpyAsync(c->d_pack_ring[slot][1], h1, nbytes, hipMemcpyHostToDevice, sp));
+        hipLaunchKernelGGL(k_stage_in, dim3(128, 2), dim3(256), 0, sp, c->d_pack_ring[slot][0], c->d_pack_ring[slot][1], d0, d1, n_cols, n_rows, c->pitch, PullDone{});
+    } else if (!rgbd) {
         done.total = 256;  // two launches of (128, 1) or one of (128, 2)
         const bool split = !s0 && !s1;  // two pageable images: the left one crosses PCIe while the CPU copies the right one
         if (!s0) {
@@ -1406,6 +1577,7 @@ static int upload_async(Context *c, const unsigned char *left, const void *secon
     f.depth = rgbd ? c->d_depth_ring[slot] : nullptr;
     f.depth_pitch = rgbd ? n_cols : 0;
     f.ext_corners = 0;
+        f.absent = 0;
     f.n_ext[0] = f.n_ext[1] = 0;
     c->async_frames++;
     enqueue_frame(c);
@@ -1413,6 +1585,13 @@ static int upload_async(Context *c, const unsigned char *left, const void *secon
 }
 
 LVT_API int lvt_amd_track_async(lvt_handle h, const unsigned char *left, const unsigned char *right, int n_rows, int n_cols) {
+    if (is_slot(h)) {
+        try {
+            return slot_submit(static_cast<PoolSlot *>(h), left, right, n_rows, n_cols, 0, true);
+        } catch (...) {
+        }
+        return -1;
+    }
     Context *c = static_cast<Context *>(h);
     if (!c) return -1;
     DeviceGuard guard(c);
@@ -1424,7 +1603,7 @@ LVT_API int lvt_amd_track_async(lvt_handle h, const unsigned char *left, const u
 }
 LVT_API int lvt_amd_track_rgbd_async(lvt_handle h, const unsigned char *gray, const float *depth, int n_rows, int n_cols) {
     Context *c = static_cast<Context *>(h);
-    if (!c) return -1;
+    if (!c || !is_ctx(h)) return -1;
     DeviceGuard guard(c);
     try {
         return upload_async(c, gray, depth, true, n_rows, n_cols);
@@ -1434,6 +1613,17 @@ LVT_API int lvt_amd_track_rgbd_async(lvt_handle h, const unsigned char *gray, co
 }
 
 LVT_API void lvt_track(lvt_handle h, unsigned char *left, unsigned char *right, int n_rows, int n_cols, double R[3][3], double t[3]) {
+    if (is_slot(h)) {
+        try {
+            PoolSlot *S = static_cast<PoolSlot *>(h);
+            slot_drain(S);
+            if (slot_submit(S, left, right, n_rows, n_cols, 0, true) != 0) return;  // outputs untouched, like the reference on an exception
+            (void)slot_collect(S);
+            slot_result(S, R, t);
+        } catch (...) {
+        }
+        return;
+    }
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
     try {
@@ -1445,6 +1635,7 @@ LVT_API void lvt_track(lvt_handle h, unsigned char *left, unsigned char *right, 
 
 LVT_API void lvt_amd_track_rgbd(lvt_handle h, const unsigned char *gray, const float *depth, int n_rows, int n_cols, double R[3][3],
                                 double t[3]) {
+    if (!is_ctx(h)) return;
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
     try {
@@ -1457,6 +1648,7 @@ LVT_API void lvt_amd_track_rgbd(lvt_handle h, const unsigned char *gray, const f
 LVT_API void lvt_track_with_external_corners(lvt_handle h, unsigned char *left, unsigned char *right, int n_rows, int n_cols,
                                              double corners_left[][2], int n_corners_left, double corners_right[][2],
                                              int n_corners_right, double R[3][3], double t[3]) {
+    if (!is_ctx(h)) return;  // (not offered on pooled handles)
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
     try {
@@ -1484,6 +1676,15 @@ LVT_API void lvt_track_with_external_corners(lvt_handle h, unsigned char *left, 
 }
 
 LVT_API int lvt_get_status(lvt_handle h) {
+    if (is_slot(h)) {
+        try {
+            PoolSlot *S = static_cast<PoolSlot *>(h);
+            slot_drain(S);
+            return S->last.rec.state;
+        } catch (...) {
+        }
+        return -1;
+    }
     try {
         Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
@@ -1496,21 +1697,20 @@ LVT_API int lvt_get_status(lvt_handle h) {
 
 // ---- introspection (of the most recently COLLECTED frame; drains the pipeline first) -----------------
 LVT_API void lvt_amd_get_counts(lvt_handle h, int out[LVT_AMD_C__COUNT]) {
-    Context *c = static_cast<Context *>(h);
-    DeviceGuard guard(c);
     try {
-        drain(c);
-        for (int i = 0; i < LVT_AMD_C__COUNT; i++) out[i] = last_ctl(c).counts[i];
+        View v;
+        if (!view_of(h, v)) return;
+        for (int i = 0; i < LVT_AMD_C__COUNT; i++) out[i] = v.rec->counts[i];
     } catch (...) {
     }
 }
 
 LVT_API int lvt_amd_get_features(lvt_handle h, int eye, float *xy, float *resp, uint8_t *desc, int cap) {
-    Context *c = static_cast<Context *>(h);
-    DeviceGuard guard(c);
     try {
-        drain(c);
-        const Feat &F = c->h_seqs[0].fb[c->last_par].feat[eye ? 1 : 0];
+        View v;
+        if (!view_of(h, v)) return -1;
+        Context *c = v.c;
+        const Feat &F = c->h_seqs[v.s].fb[v.par].feat[eye ? 1 : 0];
         const int n = read_scalar(c, F.n), m = std::min(n, cap);
         std::vector<float> x(m), y(m);
         d2h(c, x.data(), F.x, m);
@@ -1526,13 +1726,13 @@ LVT_API int lvt_amd_get_features(lvt_handle h, int eye, float *xy, float *resp, 
 }
 
 LVT_API int lvt_amd_get_matches(lvt_handle h, int *feat_idx, double *xyz, int cap) {
-    Context *c = static_cast<Context *>(h);
-    DeviceGuard guard(c);
     try {
-        drain(c);
-        const int n = last_ctl(c).n_matches, m = std::min(n, cap);
-        d2h(c, feat_idx, c->h_seqs[0].pnp_feat, m);
-        d2h(c, xyz, c->h_seqs[0].pnp_X, (size_t)m * 3);
+        View v;
+        if (!view_of(h, v)) return -1;
+        Context *c = v.c;
+        const int n = v.rec->n_matches, m = std::min(n, cap);
+        d2h(c, feat_idx, c->h_seqs[v.s].pnp_feat, m);
+        d2h(c, xyz, c->h_seqs[v.s].pnp_X, (size_t)m * 3);
         return n;
     } catch (...) {
     }
@@ -1540,14 +1740,14 @@ LVT_API int lvt_amd_get_matches(lvt_handle h, int *feat_idx, double *xyz, int ca
 }
 
 LVT_API int lvt_amd_get_row_matches(lvt_handle h, int *pairs, int cap) {
-    Context *c = static_cast<Context *>(h);
-    DeviceGuard guard(c);
     try {
-        drain(c);
-        const int n = last_ctl(c).counts[C_N_ROW_MATCHES], m = std::min(n, cap);
+        View v;
+        if (!view_of(h, v)) return -1;
+        Context *c = v.c;
+        const int n = v.rec->counts[C_N_ROW_MATCHES], m = std::min(n, cap);
         std::vector<int> l(m), r(m);
-        d2h(c, l.data(), c->h_seqs[0].pair_l, m);
-        d2h(c, r.data(), c->h_seqs[0].pair_r, m);
+        d2h(c, l.data(), c->h_seqs[v.s].pair_l, m);
+        d2h(c, r.data(), c->h_seqs[v.s].pair_r, m);
         for (int i = 0; i < m; i++) pairs[2 * i] = l[i], pairs[2 * i + 1] = r[i];
         return n;
     } catch (...) {
@@ -1566,22 +1766,22 @@ static int get_points(Context *c, const MapSoA *bufs, const int *d_cur, const in
     return n;
 }
 LVT_API int lvt_amd_get_map(lvt_handle h, double *xyz, int *counter, int *age, uint8_t *desc, int cap) {
-    Context *c = static_cast<Context *>(h);
-    DeviceGuard guard(c);
     try {
-        drain(c);
-        const Seq &S = c->h_seqs[0];
+        View v;
+        if (!view_of(h, v)) return -1;
+        Context *c = v.c;
+        const Seq &S = c->h_seqs[v.s];
         return get_points(c, S.map, S.map_cur, S.map_n, xyz, counter, age, desc, cap);
     } catch (...) {
     }
     return -1;
 }
 LVT_API int lvt_amd_get_staged(lvt_handle h, double *xyz, int *counter, uint8_t *desc, int cap) {
-    Context *c = static_cast<Context *>(h);
-    DeviceGuard guard(c);
     try {
-        drain(c);
-        const Seq &S = c->h_seqs[0];
+        View v;
+        if (!view_of(h, v)) return -1;
+        Context *c = v.c;
+        const Seq &S = c->h_seqs[v.s];
         return get_points(c, S.staged, S.staged_cur, S.staged_n, xyz, counter, nullptr, desc, cap);
     } catch (...) {
     }
@@ -1590,6 +1790,17 @@ LVT_API int lvt_amd_get_staged(lvt_handle h, double *xyz, int *counter, uint8_t 
 // pose + state of the frame the last tracking call returned, WITHOUT waiting for that frame's tail: a synchronous call that returned on
 // the pose k_pnp handed over reads it from the same pinned record (quaternion as the tracker holds it, not re-derived from R)
 LVT_API int lvt_amd_get_last_pose(lvt_handle h, double q[4], double p[3]) {
+    if (is_slot(h)) {
+        try {
+            View v;
+            if (!view_of(h, v)) return -1;
+            for (int k = 0; k < 4; k++) q[k] = v.rec->last_pose.q[k];
+            for (int k = 0; k < 3; k++) p[k] = v.rec->last_pose.p[k];
+            return v.rec->state;
+        } catch (...) {
+        }
+        return -1;
+    }
     Context *c = static_cast<Context *>(h);
     if (!c) return -1;
     if (c->early_pending && c->enq > 0) {
@@ -1609,26 +1820,25 @@ LVT_API int lvt_amd_get_last_pose(lvt_handle h, double q[4], double p[3]) {
     return -1;
 }
 LVT_API void lvt_amd_get_pose(lvt_handle h, double q[4], double p[3]) {
-    Context *c = static_cast<Context *>(h);
-    DeviceGuard guard(c);
     try {
-        drain(c);
-        for (int k = 0; k < 4; k++) q[k] = last_ctl(c).last_pose.q[k];
-        for (int k = 0; k < 3; k++) p[k] = last_ctl(c).last_pose.p[k];
+        View v;
+        if (!view_of(h, v)) return;
+        for (int k = 0; k < 4; k++) q[k] = v.rec->last_pose.q[k];
+        for (int k = 0; k < 3; k++) p[k] = v.rec->last_pose.p[k];
     } catch (...) {
     }
 }
 LVT_API void lvt_amd_get_predicted_pose(lvt_handle h, double q[4], double p[3]) {
-    Context *c = static_cast<Context *>(h);
-    DeviceGuard guard(c);
     try {
-        drain(c);
-        for (int k = 0; k < 4; k++) q[k] = last_ctl(c).predicted.q[k];
-        for (int k = 0; k < 3; k++) p[k] = last_ctl(c).predicted.p[k];
+        View v;
+        if (!view_of(h, v)) return;
+        for (int k = 0; k < 4; k++) q[k] = v.rec->predicted.q[k];
+        for (int k = 0; k < 3; k++) p[k] = v.rec->predicted.p[k];
     } catch (...) {
     }
 }
 LVT_API void lvt_amd_get_debug(lvt_handle h, long long out[32]) {
+    if (!is_ctx(h)) return;
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
     try {
@@ -1637,10 +1847,12 @@ LVT_API void lvt_amd_get_debug(lvt_handle h, long long out[32]) {
     } catch (...) {
     }
 }
-LVT_API int lvt_amd_get_ordering(lvt_handle h) {  // 0: polling gates + early stream, 1: event barriers only
+LVT_API int lvt_amd_get_ordering(lvt_handle h) {  // 0: polling gates + early stream, 1: event barriers only, 2: a pooled handle (a seat of the device's shared lock-step chain)
+    if (is_slot(h)) return 2;
     return h && static_cast<Context *>(h)->events_only ? 1 : 0;
 }
 LVT_API void lvt_amd_get_timeline(lvt_handle h, long long out[16]) {  // of the frame collected last; a frame whose synchronous call
+    if (!is_ctx(h)) return;
     Context *c = static_cast<Context *>(h);                            // returned on its pose is collected first, nothing else is drained
     DeviceGuard guard(c);
     try {
@@ -1650,6 +1862,7 @@ LVT_API void lvt_amd_get_timeline(lvt_handle h, long long out[16]) {  // of the 
     for (int i = 0; i < 16; i++) out[i] = last_ctl(c).dbg[32 + i];
 }
 LVT_API int lvt_amd_get_plane(lvt_handle h, int eye, int what, void *dst, int cap_bytes, int *pitch_out) {
+    if (!is_ctx(h)) return -1;
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
     try {

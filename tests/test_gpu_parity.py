@@ -440,6 +440,96 @@ def test_lm_rejections_inside_a_tracked_sequence(hip_lib, oracle_lib):
     assert rej > 0 and term > 0, (rej, term)
 
 
+def test_pooled_handles_equal_the_oracle(hip_lib, oracle_lib):
+    """POOLED handles (lvt_amd_create_pooled: seats of ONE shared lock-step launch chain per device, fed by a submission thread) driven by three host
+    threads with three different sequences through the reference's own entry point (lvt_track, host buffers).  Every frame of every handle is held
+    to its own ORACLE instance with the full stage-by-stage diff -- key points, descriptors, match indices, row pairs, map, staged, counters,
+    predicted pose, pose -- while the other handles' frames share its steps or leave its seat empty (a step a handle sits out must change nothing
+    of its state, not even the frame counter)."""
+    import threading
+    from oracle import pyoracle as O
+    from parity_util import pose_errors
+    cases = [make_case("kitti", 50 + k, 0.5) for k in range(3)]
+    prm = cases[0][1]
+    hs = [hip_lib.LvtSystem.create(prm, 1, pooled=True) for _ in range(3)]
+    assert all(h.ordering() == "pooled" for h in hs)
+    orcs = [O.Oracle(prm, 1) for _ in range(3)]
+    frames = [[cases[k][0].render_stereo(i) for i in range(22)] for k in range(3)]
+    fails = [[] for _ in range(3)]
+
+    def work(k):
+        n = (22, 15, 18)[k]                       # the handles stop at different frames: the later steps run with empty seats
+        for i in range(n):
+            L, R = frames[k][i]
+            Ro, to = orcs[k].track(L, R)
+            Rh, th = hs[k].track(L, R)
+            msgs = diff_frame(hs[k], orcs[k])
+            e_t, e_R = pose_errors(Rh, th, Ro, to)
+            if e_t > POSE_TOL or e_R > POSE_TOL:
+                msgs.append(f"pose e_t={e_t:.3e} e_R={e_R:.3e}")
+            if msgs:
+                fails[k].append((i, msgs[:4]))
+                return
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(3)]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    assert fails == [[], [], []], fails
+    assert [h.counts()["frame"] for h in hs] == [21, 14, 17]            # every handle counted ITS frames, not the pool's steps
+    st = hs[0].host_stats()
+    assert st["collected"] >= 22 and st["event_ordering"] == 2, st       # (out[1]: steps the pool launched; out[7] == 2: pooled)
+    for h in hs: h.close()
+    # the pool is gone with its last handle; a new one starts from scratch (identity first frame)
+    h = hip_lib.LvtSystem.create(prm, 1, pooled=True)
+    R0, t0 = h.track(*frames[0][0])
+    assert np.array_equal(R0, np.eye(3)) and np.array_equal(t0, np.zeros(3)) and h.get_state() == 2
+    h.close()
+
+
+def test_pooled_async_handles_equal_a_solo_handle(hip_lib):
+    """four pooled handles fed the SAME device-resident sequence asynchronously (three frames in flight each) from four threads that start and stop
+    at different times: every handle's poses equal a solo handle's, bit for bit"""
+    import threading
+    import time
+    import torch
+    world, prm, sensor = make_case("kitti", 60, 0.5)
+    n = 48
+    pitch = ((world.W + 63) // 64) * 64
+    dev = torch.zeros((n, 2, world.H, pitch), dtype=torch.uint8, device="cuda")
+    for i in range(n):
+        L, R = world.render_stereo(i)
+        dev[i, 0, :, :world.W] = torch.from_numpy(L).cuda(); dev[i, 1, :, :world.W] = torch.from_numpy(R).cuda()
+    torch.cuda.synchronize()
+    solo = hip_lib.LvtSystem.create(prm, 1)
+    ref = [solo.track_device(dev[i].data_ptr(), dev[i].data_ptr() + world.H * pitch, world.H, world.W, pitch) for i in range(n)]
+    solo.close()
+    hs = [hip_lib.LvtSystem.create(prm, 1, pooled=True) for _ in range(4)]
+    got = [[] for _ in range(4)]
+
+    def work(k):
+        time.sleep(0.002 * k)                     # staggered starts: the first steps run with empty seats
+        m = n - 7 * k                             # ... and staggered ends
+        inflight = 0
+        for i in range(m):
+            p = dev[i].data_ptr()
+            hs[k].track_device_async(p, p + world.H * pitch, world.H, world.W, pitch)
+            inflight += 1
+            if inflight >= 3:
+                got[k].append(hs[k].wait_status()); inflight -= 1
+        while inflight:
+            got[k].append(hs[k].wait_status()); inflight -= 1
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(4)]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    for k in range(4):
+        assert len(got[k]) == n - 7 * k
+        for i, (R, t, st) in enumerate(got[k]):
+            assert st == 2 and np.array_equal(t, ref[i][1]) and np.array_equal(R, ref[i][0]), f"handle {k} frame {i}"
+        assert hs[k].last_error() == ""
+    st = hs[0].host_stats()
+    assert st["planes_in_place"] > 1.5 * st["collected"], st     # (out[2] / out[1]: on average more than one and a half seats of a step were taken)
+    for h in hs: h.close()
+
+
 @pytest.mark.parametrize("depth", [1, 3], ids=["one_in_flight", "three_in_flight"])
 def test_a_gate_time_out_moves_the_handle_to_event_ordering(hip_lib, monkeypatch, depth):
     """the polling gates are a bet on streams that run side by side; when one runs into its time limit (a tool serialising the dispatches,

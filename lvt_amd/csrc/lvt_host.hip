@@ -1030,9 +1030,17 @@ static bool view_of(lvt_handle h, View &v) {
     v.guard = new DeviceGuard(v.c);
     return true;
 }
-static bool pool_wanted() {
+// LVT_AMD_POOL=1: every handle the create calls make is pooled; =auto: the first live handle of a device keeps a launch chain of its own (the fastest
+// way to run ONE sequence), the handles created beside it are pooled; unset / 0: never
+static bool pool_wanted(int device) {
     const char *e = std::getenv("LVT_AMD_POOL");
-    return e && std::atoi(e) != 0;
+    if (!e) return false;
+    if (std::strcmp(e, "auto") == 0) {
+        int cur = 0;
+        if (device < 0 && hipGetDevice(&cur) == hipSuccess) device = cur;
+        return device >= 0 && g_live_contexts[device % MAX_DEVICES].load() > 0;
+    }
+    return std::atoi(e) != 0;
 }
 }  // namespace lvt
 
@@ -1056,7 +1064,7 @@ LVT_API lvt_handle lvt_amd_create_pooled(const lvt_amd_params *p, int sensor_typ
 
 LVT_API lvt_handle lvt_amd_create(const lvt_amd_params *p, int sensor_type) {
     try {
-        if (pool_wanted())
+        if (pool_wanted(-1))
             if (PoolSlot *S = pool_join(*p, sensor_type, -1)) return static_cast<lvt_handle>(S);
         return static_cast<lvt_handle>(create_context(*p, sensor_type, 1));
     } catch (...) {
@@ -1066,7 +1074,7 @@ LVT_API lvt_handle lvt_amd_create(const lvt_amd_params *p, int sensor_type) {
 
 LVT_API lvt_handle lvt_amd_create_on_device(const lvt_amd_params *p, int sensor_type, int device) {
     try {
-        if (pool_wanted())
+        if (pool_wanted(device))
             if (PoolSlot *S = pool_join(*p, sensor_type, device)) return static_cast<lvt_handle>(S);
         return static_cast<lvt_handle>(create_context(*p, sensor_type, 1, device));
     } catch (...) {
@@ -1083,7 +1091,7 @@ LVT_API lvt_handle lvt_create(const char *config_file_name, int sensor_type) {
         lvt_amd_params p;
         default_params(&p);
         if (params_from_file(config_file_name, &p) && (sensor_type == 1 || sensor_type == 2)) {
-            if (pool_wanted())
+            if (pool_wanted(-1))
                 if (PoolSlot *S = pool_join(p, sensor_type, -1)) return static_cast<lvt_handle>(S);
             return static_cast<lvt_handle>(create_context(p, sensor_type, 1));
         }

@@ -116,7 +116,12 @@ LVT_API void lvt_amd_batch_get_counts(lvt_handle h, int seq, int out[32]);
 
 /* run all work of this handle on an existing HIP stream (e.g. torch.cuda.current_stream().cuda_stream) */
 LVT_API void lvt_amd_set_stream(lvt_handle h, void *hip_stream);
-/* last HIP error string seen by this handle ("" if none); overflow / capacity diagnostics too */
+/* last HIP error string seen by this handle ("" if none); overflow / capacity diagnostics too.
+ * BLOCKING: when the last synchronous call returned on its early pose (the frame's tail -- staged update, triangulation -- was still running), this
+ * call first collects that frame: its own reports (capacity overflow, a gate that timed out, a skipped frame) arrive with its full record.  A caller
+ * that checks the string after EVERY lvt_track therefore gives up the overlap of that tail with its next upload (~30 us per frame); check it every N
+ * frames, or use lvt_amd_get_last_pose for pose + state, which never waits.  Not thread-safe against a concurrent call on the same handle (like every
+ * entry point); the returned pointer is valid until the next call on the handle (pooled handles: until the calling thread's next call). */
 LVT_API const char *lvt_amd_last_error(lvt_handle h);
 
 /* per-kernel timing with HIP events recorded on the handle's stream around every launch of the frame chain.

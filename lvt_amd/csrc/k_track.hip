@@ -457,6 +457,31 @@ __global__ void k_feat_done(Seq *seqs, int par, seq_t seq) {
     atomicExch(&fc.feat_seq, seq);
 }
 
+// Asynchronous host frames: the PCIe pull at the head of the feature stage makes that stream's chain the longest one (pull 34 + k_score 10 + k_cells 66 +
+// k_gather 8 + k_brief 12 us against the tracking chain's 113), so its tail -- k_gather and k_brief, 20 us -- moves to the early stream, which idles in
+// its gate at that time: k_cells_pub (feature stream, one thread) publishes the frame's number when its cells are complete, k_cells_wait (early stream,
+// one wave, polling like every gate) lets k_gather / k_brief of that frame through.  Both were enqueued after the kernels they wait for.
+__global__ void k_cells_pub(Seq *seqs, int par, seq_t seq) {
+    if (threadIdx.x != 0) return;
+    __threadfence();
+    atomicExch(&seqs[blockIdx.x].fb[par].fc->cells_seq, seq);
+}
+__global__ __launch_bounds__(64) void k_cells_wait(Seq *seqs, int par, seq_t seq) {
+    if (threadIdx.x != 0) return;
+    Seq &S = seqs[blockIdx.x];
+    FeatCtl &fc = *S.fb[par].fc;
+    const unsigned long long t0 = wall_clock64();
+    while (__hip_atomic_load(&fc.cells_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+        __builtin_amdgcn_s_sleep(8);
+        if (wall_clock64() - t0 > 200000000ull) {  // 2 s: as k_gate_buf -- the frame has no features, it is skipped and reported
+            fc.poison = 1;
+            atomicAdd(&S.ctl->gate_fatal, 1);
+            __threadfence();
+            break;
+        }
+    }
+}
+
 // behind k_candidates<ROW>: this frame's row-match candidate lists are complete (k_triangulate's head polls the word)
 __global__ void k_row_done(Seq *seqs, int par, seq_t seq) {
     if (threadIdx.x != 0) return;

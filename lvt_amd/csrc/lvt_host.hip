@@ -231,6 +231,8 @@ struct Context {
     size_t stage_ring_bytes = 0;
     seq_t *d_pull = nullptr;          // [0] last frame whose images are complete in HBM, [1] workgroup counter of the pull in flight
     hipEvent_t ev_pull[RING] = {};
+    bool split_tail = false;          // LVT_AMD_FEATURE_SPLIT=1: k_gather / k_brief of an asynchronous host frame run on the early stream (measured: no gain --
+                                      // 7 350 / 7 638 against 7 754 / 7 690 frames/s at 20 steps, 8 150 / 8 167 against 8 179 / 8 202 at 400; the hand-over costs what the shorter chain saves)
     seq_t pull_wait = 0;              // set for the frame being enqueued: its feature stage waits for this pull (0: images resident)
     long long async_frames = 0;
     float *d_ext[NPAR][2] = {};
@@ -508,6 +510,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_switch_e, hipEventDisableTiming));
         c->d_pull = c->dalloc<seq_t>(2);
         if (const char *e = std::getenv("LVT_AMD_PULL_STREAM")) c->pull_mode = std::atoi(e);
+        if (const char *e = std::getenv("LVT_AMD_FEATURE_SPLIT")) c->split_tail = std::atoi(e) != 0;
         if (const char *e = std::getenv("LVT_AMD_TEST_GATE_TIMEOUT")) c->test_gate_timeout = std::atol(e);
         {
             // "events": barrier-only ordering; "polling": the polling gates + early stream; unset: polling for the first live
@@ -736,6 +739,7 @@ static void enqueue_frame(Context *c) {
     // ---- feature stage (stream_f): may start as soon as the tracking chain of frame enq-NPAR released this buffer
     const bool evo = c->events_only;
     const bool pull_gate = c->pull_wait != 0 && c->pull_on_own;  // (pulls on the feature stream itself are ordered by that stream)
+    const bool split_tail = c->pull_wait != 0 && c->split_tail && B == 1 && !c->events_only && c->sensor == 1 && !c->prof && !c->h_fargs[slot].ext_corners;
     if (c->enq >= NPAR || pull_gate) {
         if (!evo)
             hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, Bz), dim3(64), 0, sf, S, (seq_t)(c->enq >= NPAR ? c->enq + 1 - NPAR : 0), par,
@@ -781,9 +785,16 @@ static void enqueue_frame(Context *c) {
         (void)hipStreamWaitEvent(sf, c->ev_depth, 0);
         c->depth_wait = false;
     }
-    LAUNCH_S(5, sf, k_gather, dim3(1, 2, Bz), dim3(1024), CELLS_LDS_BYTES, (const Seq *)S, par);
+    // the feature stage's tail: on the feature stream -- or, for an asynchronous host frame of a single sequence, on the early stream (k_cells_pub)
+    const bool tail_on_early = split_tail;
+    hipStream_t stail = tail_on_early ? c->stream_e : sf;
+    if (tail_on_early) {
+        hipLaunchKernelGGL(k_cells_pub, dim3(1), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));
+        hipLaunchKernelGGL(k_cells_wait, dim3(1), dim3(64), 0, stail, S, par, (seq_t)(c->enq + 1));
+    }
+    LAUNCH_S(5, stail, k_gather, dim3(1, 2, Bz), dim3(1024), CELLS_LDS_BYTES, (const Seq *)S, par);
     const bool brief_publishes = !evo && B == 1;  // (single sequence: k_brief's last workgroup publishes feat_seq; see k_feat_done)
-    LAUNCH_S(6, sf, k_brief, dim3(64, 2, Bz), dim3(256), 0, (const Seq *)S, par, brief_publishes ? (seq_t)(c->enq + 1) : (seq_t)0);
+    LAUNCH_S(6, stail, k_brief, dim3(64, 2, Bz), dim3(256), 0, (const Seq *)S, par, brief_publishes ? (seq_t)(c->enq + 1) : (seq_t)0);
     if (!evo && !brief_publishes) hipLaunchKernelGGL(k_feat_done, dim3(Bz), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));
     const int bl = c->binned_lists ? 1 : 0;
     if (evo && bl && c->sensor == 1) LAUNCH_SM(19, sf, k_hamming_batched_lists, MODE_ROW, dim3(c->lists_wgs_row, 1, Bz), dim3(LS_THREADS), LS_LDS_BYTES, par, (seq_t)0);
@@ -1030,17 +1041,12 @@ static bool view_of(lvt_handle h, View &v) {
     v.guard = new DeviceGuard(v.c);
     return true;
 }
-// LVT_AMD_POOL=1: every handle the create calls make is pooled; =auto: the first live handle of a device keeps a launch chain of its own (the fastest
-// way to run ONE sequence), the handles created beside it are pooled; unset / 0: never
-static bool pool_wanted(int device) {
+// LVT_AMD_POOL=1: every handle the create calls make is pooled.  (A mixed mode -- the first handle of a device on its own launch chain, the later ones
+// pooled -- was measured and removed: 2 / 4 / 8 handles 6.8k / 13.1k / 25.3k frames/s against 12.0k / 22.8k / 43.6k all pooled: the solo handle's
+// polling gates and the pool's chain hold each other up on the shared hardware queues.)
+static bool pool_wanted(int) {
     const char *e = std::getenv("LVT_AMD_POOL");
-    if (!e) return false;
-    if (std::strcmp(e, "auto") == 0) {
-        int cur = 0;
-        if (device < 0 && hipGetDevice(&cur) == hipSuccess) device = cur;
-        return device >= 0 && g_live_contexts[device % MAX_DEVICES].load() > 0;
-    }
-    return std::atoi(e) != 0;
+    return e && std::atoi(e) != 0;
 }
 }  // namespace lvt
 

@@ -407,6 +407,7 @@ class LvtBatch:
     profile_read = LvtSystem.profile_read
     timeline = LvtSystem.timeline   # (sequence 0's stamps)
     host_stats = LvtSystem.host_stats
+    debug_stamps = LvtSystem.debug_stamps
 
 
 def pnp(params: LvtParameters, q_in, p_in, pts, obs):

@@ -25,9 +25,11 @@ namespace lvt {
 constexpr int LS_THREADS = 1024;
 constexpr int LS_NMAX = 2048;   // train features of one LDS image
 constexpr int LS_BINS = 4100;   // hash cells / image rows + 1
-constexpr int LS_ARENA = 12800; // list entries in flight (one chunk of <= 1024 queries; larger chunks are cut)
+constexpr int LS_ARENA = 11776; // list entries in flight (one chunk of <= 1024 queries; larger chunks are cut)
+constexpr int LS_WORK = 1024;   // ... and behind them the work list of the lists a whole wavefront ranks (one word per thread at most)
+constexpr int LS_COOP_MIN = 20; // lists at least this long are ranked by a wavefront: a lane's rank-by-counting is (n / 4)^2 trips and the kernel ends with its longest list
 constexpr int LS_STARTS = (LS_BINS + 4) & ~3;  // (the arena behind the bin starts is 16-byte aligned)
-constexpr int LS_LDS_BYTES = LS_NMAX * 42 + LS_STARTS * 4 + LS_ARENA * 4 + 256;
+constexpr int LS_LDS_BYTES = LS_NMAX * 42 + LS_STARTS * 4 + (LS_ARENA + LS_WORK) * 4 + 256;
 typedef unsigned int ls_u32x4 __attribute__((ext_vector_type(4)));
 
 template <int MODE, bool BV>
@@ -64,10 +66,14 @@ __global__ __launch_bounds__(LS_THREADS) void k_hamming_batched_lists(SeqArg<BV>
     uint16_t *s_idx = reinterpret_cast<uint16_t *>(s_xy + LS_NMAX);
     int *s_start = reinterpret_cast<int *>(s_idx + LS_NMAX);
     uint32_t *s_arena = reinterpret_cast<uint32_t *>(s_start + LS_STARTS);
+    uint32_t *s_work = s_arena + LS_ARENA;
+    __shared__ int s_work_n;
     __shared__ int s_scan[32];
     __shared__ int s_next;
     __shared__ double w2c[12];
 
+    long long *stamp = (MODE == MODE_ROW && blockIdx.x == 0 && tid == 0) ? ctl.dbg + 26 : nullptr;  // (tools/lists_phases.py)
+    if (stamp) stamp[0] = clock64();
     if (MODE == MODE_MAP && tid == 0) {  // the prediction, recomputed from the persistent state (k_early_map does the same)
         Pose predicted;
         double mmn[14];
@@ -75,6 +81,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_hamming_batched_lists(SeqArg<BV>
         world_to_camera(predicted, w2c);
     }
     // ---- the train set, counting-sorted into the reference's hash cells / image rows (two features per thread at most)
+    if (tid == 0) s_work_n = 0;
     for (int i = tid; i <= nbins; i += LS_THREADS) s_start[i] = 0;
     __syncthreads();
     int tbin[2], trank[2];
@@ -117,6 +124,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_hamming_batched_lists(SeqArg<BV>
     }
     __syncthreads();
 
+    if (stamp) stamp[1] = clock64();
     const uint64_t *qdesc = (MODE == MODE_MAP) ? S.map[*S.map_cur].desc : S.fb[par].feat[0].desc;
     uint32_t *cand = (MODE == MODE_MAP) ? S.cand : S.rcand + (size_t)par * NF_MAX * KC;
     int *ncand = (MODE == MODE_MAP) ? S.ncand : S.rncand + par * NF_MAX;
@@ -186,6 +194,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_hamming_batched_lists(SeqArg<BV>
                 }
                 cnt += ok ? 1 : 0;
             }
+        if (stamp) stamp[2] = clock64();
         int total;
         const int cnt4 = (cnt + 3) & ~3;  // segments start on 16-byte boundaries: the ranking below reads four keys per LDS access
         const int off = block_excl_scan(cnt4, s_scan, &total);
@@ -226,7 +235,11 @@ __global__ __launch_bounds__(LS_THREADS) void k_hamming_batched_lists(SeqArg<BV>
                 // rank = number of smaller keys (keys are unique: they carry the index): n^2 INDEPENDENT LDS reads and compares per lane,
                 // where an insertion sort is a chain of dependent read-modify-writes as long as its longest list in the wavefront
                 // (measured: 400 us for the row lists of a 16-sequence batch with the insertion sort)
-                if (n <= KC) {
+                if (n <= KC && n >= LS_COOP_MIN) {
+                    // a long list: a whole wavefront ranks it below (one key per lane, every comparison partner a broadcast read)
+                    for (int e = n; e < cnt4; e++) seg[e] = 0xFFFFFFFFu;
+                    s_work[atomicAdd(&s_work_n, 1)] = (uint32_t)tid | ((uint32_t)(off - base) << 10) | ((uint32_t)(n - 1) << 24);
+                } else if (n <= KC) {
                     for (int e = n; e < cnt4; e++) seg[e] = 0xFFFFFFFFu;  // padding: never smaller than a key
                     const uint4 *seg4 = reinterpret_cast<const uint4 *>(seg);
                     for (int e = 0; e < n; e += 4) {  // four keys against every vector of four: n^2 / 16 LDS reads
@@ -249,6 +262,33 @@ __global__ __launch_bounds__(LS_THREADS) void k_hamming_batched_lists(SeqArg<BV>
                 ncand[q] = n;  // (> KC: the resolvers take the exact slow path, as with k_candidates)
                 done = true;
             }
+            if (stamp) stamp[3] = clock64();
+            // ---- the long lists of this pass, one per wavefront at a time: lane l owns keys l and l + 64 (n <= KC = 128), counts the smaller ones
+            //      among all n (four per broadcast read) and stores its keys at their ranks -- ~n / 4 trips where a single lane needs (n / 4)^2
+            __syncthreads();
+            if (stamp) stamp[4] = clock64();
+            {
+                const int nwork = s_work_n, lane = tid & 63;
+                for (int w = tid >> 6; w < nwork; w += LS_THREADS / 64) {
+                    const uint32_t e = s_work[w];
+                    const int qw = q0 + (int)(e & 1023u), n = (int)(e >> 24) + 1;
+                    const uint32_t *seg = s_arena + ((e >> 10) & 16383u);
+                    const uint4 *seg4 = reinterpret_cast<const uint4 *>(seg);
+                    const uint32_t ka = lane < n ? seg[lane] : 0xFFFFFFFFu, kb = lane + 64 < n ? seg[lane + 64] : 0xFFFFFFFFu;
+                    int ra = 0, rb = 0;
+                    for (int o = 0; o < n; o += 4) {  // (the segment is padded with 0xFFFFFFFF up to a multiple of four)
+                        const uint4 v = seg4[o >> 2];
+                        ra += (v.x < ka) + (v.y < ka) + (v.z < ka) + (v.w < ka);
+                        rb += (v.x < kb) + (v.y < kb) + (v.z < kb) + (v.w < kb);
+                    }
+                    uint32_t *dst = cand + (size_t)qw * KC;
+                    if (lane < n) dst[ra] = ka;
+                    if (lane + 64 < n) dst[rb] = kb;
+                }
+            }
+            __syncthreads();
+            if (stamp) stamp[5] = clock64();
+            if (tid == 0) s_work_n = 0;
             if (total <= LS_ARENA) break;  // (block-uniform: everything fitted in one go)
             __syncthreads();
             if (tid == 0) s_next = 0x7FFFFFFF;

@@ -106,7 +106,7 @@ def run_rank(args, env, dist, backend):
         "metric": METRIC, "value": round(fps, 2), "unit": "frames/s", "n_gpus": env.world_size, "steps": K, "warmup": Wm,
         "ms_per_step": round(1e3 * dt / K, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "u8/f64", "data": "synthetic",
-        "config": {"workload": backend.workload, "sequences_per_gpu": S, "frames_in_flight": args.depth,
+        "config": {"workload": backend.workload + (" [--share-gpu: the ranks share fewer GPUs -- a rehearsal, not a scaling measurement]" if getattr(args, "share_gpu", False) else ""), "sequences_per_gpu": S, "frames_in_flight": args.depth,
                    "total_sequences": S * env.world_size, "total_sequences_requested": (getattr(args, "total_seqs", 0) or None),
                    "parallelism": f"{env.world_size * S} independent sequences, one process per GPU, no collective"},
         "tracking": {"frames_not_tracking": lost, "checked": "lvt_amd_wait_status == 2 on every timed frame of every rank"},
@@ -130,9 +130,10 @@ class HipBackend:
         if not torch.cuda.is_available():
             raise SystemExit("bench.py needs a GPU: the tracking path has no CPU fallback")
         self.torch, self.lvt, self.make_world = torch, lvt_amd, make_world
-        torch.cuda.set_device(env.local_rank)
-        self.device = torch.device("cuda", env.local_rank)
-        self.affinity = gpu_cpu_affinity(env.local_rank) if env.world_size > 1 else None   # (a single rank keeps the scheduler's choice)
+        dev_index = env.local_rank % torch.cuda.device_count() if args.share_gpu else env.local_rank   # (--share-gpu: a rehearsal of the N-rank path on fewer GPUs)
+        torch.cuda.set_device(dev_index)
+        self.device = torch.device("cuda", dev_index)
+        self.affinity = gpu_cpu_affinity(dev_index) if env.world_size > 1 else None   # (a single rank keeps the scheduler's choice)
         self.env = env
         self.sequences_per_gpu = args.seqs_per_gpu
         self.depth = args.depth
@@ -707,6 +708,8 @@ def parse_args(argv=None):
     ap.add_argument("--config-frames", type=int, default=60)
     ap.add_argument("--total-seqs", type=int, default=0, help="track this many sequences in all: ceil(T / gpus) per GPU in lock-step (cfg 5 with T = 8 on fewer than 8 GPUs)")
     ap.add_argument("--device-frames", action="store_true", help="headline on frames already resident in HBM (lvt_amd_track_device_async) instead of pinned host frames")
+    ap.add_argument("--share-gpu", action="store_true", help="ranks beyond the box's GPU count share its GPUs (local_rank mod device count): rehearses the multi-rank "
+                    "launch, timing and reduction path on a one-GPU box; the number it prints is not a scaling result")
     ap.add_argument("--backend", default="hip", choices=["hip", "standin"], help="standin: sleeps instead of GPU work (CPU test of the multi-rank launch path)")
     ap.add_argument("--standin-ms", type=float, default=0.0, help="stand-in backend: every rank's step takes this long (default: rank r takes 1 + r ms)")
     ap.add_argument("--standin-tail-ms", type=float, default=0.0, help="stand-in backend: rank 1 sleeps this long between its timed window and the reductions")

@@ -22,6 +22,38 @@ def make_case(kind="kitti", seed=0, scale=1.0, overrides=None):
     return world, prm, (2 if kind == "tum" else 1)
 
 
+class HardWorld:
+    """the synthetic sequences are kind to a tracker: integer-pixel warps of one texture, identical photometry in both eyes and all frames.  This
+    wrapper makes the SAME geometry harder the way real footage is: per-frame and per-eye gain / bias (auto-exposure), sensor noise that differs
+    between the eyes, a 3 x 3 blur on every third frame (motion blur / defocus), and a right image that sits one row off on every fourth frame
+    (imperfect rectification: candidates at the edge of the +-2 row band).  More ambiguous ratio tests, more outliers in front of the chi2 gates,
+    fewer features per cell -- and the HIP path must still equal the oracle bit for bit."""
+
+    def __init__(self, world, seed=0):
+        self.w, self.seed = world, seed
+        self.W, self.H = world.W, world.H
+
+    def _degrade(self, img, rng, blur):
+        a = img.astype(np.float32)
+        if blur:
+            p = np.pad(a, 1, mode="edge")
+            a = (p[:-2, :-2] + 2 * p[:-2, 1:-1] + p[:-2, 2:] + 2 * p[1:-1, :-2] + 4 * p[1:-1, 1:-1] + 2 * p[1:-1, 2:] + p[2:, :-2] + 2 * p[2:, 1:-1] + p[2:, 2:]) / 16.0
+        a = a * rng.uniform(0.8, 1.2) + rng.uniform(-12, 12) + rng.normal(0.0, 4.0, a.shape)
+        return np.clip(np.rint(a), 0, 255).astype(np.uint8)
+
+    def render_stereo(self, i):
+        L, R = self.w.render_stereo(i)
+        rng = np.random.default_rng(1000003 * self.seed + i)
+        blur = (i % 3) == 2
+        L2, R2 = self._degrade(L, rng, blur), self._degrade(R, rng, blur)
+        if i % 4 == 3:
+            R2 = np.vstack([R2[1:], R2[-1:]])     # one row up
+        return np.ascontiguousarray(L2), np.ascontiguousarray(R2)
+
+    def pose(self, i):
+        return self.w.pose(i)
+
+
 def pose_errors(Rh, th, Ro, to):
     e_t = np.linalg.norm(th - to) / max(np.linalg.norm(to), 1.0)
     e_R = float(np.arccos(np.clip((np.trace(Rh.T @ Ro) - 1) / 2, -1, 1)))

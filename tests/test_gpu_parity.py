@@ -5,7 +5,7 @@ match indices, row matches, map bookkeeping bit-exact; map positions and per-fra
 import numpy as np
 import pytest
 
-from parity_util import make_case, run_sequence, diff_frame, sparse_pair, POSE_TOL
+from parity_util import make_case, run_sequence, diff_frame, sparse_pair, HardWorld, POSE_TOL
 
 pytestmark = pytest.mark.gpu
 
@@ -25,6 +25,10 @@ CASES = [
     ("kitti_full_1000", "kitti", 13, 1.0, {}, list(range(1000))),
     ("euroc_300", "euroc", 2, 1.0, {}, list(range(300))),
     ("tum_rgbd_300", "tum", 2, 1.0, {}, list(range(300))),
+    # degraded footage on the same geometry (parity_util.HardWorld: exposure changes per frame and eye, sensor noise, blur, a right image one row off):
+    # ~20 % of the matches end as outliers in front of the chi2 gates, ratio tests are borderline far more often
+    ("kitti_hard", "kitti", 70, 1.0, {}, list(range(80))),
+    ("kitti_hard_half", "kitti", 71, 0.5, {}, list(range(60))),
     ("kitti_always_triangulate", "kitti", 5, 0.5, {"triangulation_policy": 2, "staged_threshold": 0}, list(range(10))),
     ("kitti_map_size_policy", "kitti", 6, 0.5, {"triangulation_policy": 3}, list(range(10))),
     ("euroc", "euroc", 0, 1.0, {}, list(range(10))),                           # configs[2] shape
@@ -37,11 +41,15 @@ CASES = [
 @pytest.mark.parametrize("name,kind,seed,scale,overrides,frames", CASES, ids=[c[0] for c in CASES])
 def test_sequence_parity(hip_lib, oracle_lib, name, kind, seed, scale, overrides, frames):
     world, prm, sensor = make_case(kind, seed, scale, overrides)
+    if name.startswith("kitti_hard"):
+        world = HardWorld(world, seed)
     res, hip, orc = run_sequence(world, prm, sensor, frames)
     bad = [(i, m) for i, m, _, _ in res if m]
     assert not bad, f"{name}: first divergence at frame {bad[0][0]}: {bad[0][1][:6]}"
     assert max(r[2] for r in res) <= POSE_TOL and max(r[3] for r in res) <= POSE_TOL
     c = hip.counts()
+    if name.startswith("kitti_hard"):
+        assert hip.get_state() == 2 and c["pnp_inliers"] < 0.9 * c["n_matches"], (c["pnp_inliers"], c["n_matches"])   # the gates really demote edges here
     if name == "kitti_low_corner_retry":
         assert c["retry_left"] == 1, "the <200-corner retry path was not exercised"
     if name == "kitti_sparse_second_pass":

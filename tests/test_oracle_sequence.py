@@ -50,3 +50,19 @@ def test_oracle_lost_latch(oracle_lib):
     orc.track(*sparse_pair(world))
     assert orc.status == 3 and orc.counts()["second_pass"] == 1
     assert np.array_equal(orc.track(*world.render_stereo(4))[1], last)
+
+
+def test_oracle_follows_the_ground_truth_on_degraded_footage(oracle_lib):
+    """parity_util.HardWorld (exposure changes, per-eye noise, blur, a right image one row off): the oracle keeps TRACKING, stays within centimetres
+    of the ground-truth motion, and the chi2 gates really demote edges (the GPU tier runs the same frames through the HIP path)"""
+    from parity_util import HardWorld
+    world, prm, _ = make_case("kitti", 71, 0.5)
+    hw = HardWorld(world, 71)
+    orc = oracle_lib.Oracle(prm, 1)
+    demoted = 0
+    for i in range(30):
+        R, t = orc.track(*hw.render_stereo(i))
+        assert orc.status == 2 and np.linalg.norm(t - world.pose(i)[1]) < 0.1, i   # (half-size images: half the disparity)
+        c = orc.counts()
+        demoted += c["n_matches"] - c["pnp_inliers"]
+    assert demoted > 300, demoted

@@ -69,30 +69,46 @@ int main(int argc, char **argv) {
     if (max_frames >= 0 && max_frames < frame_count) frame_count = max_frames;
     const float depth_scale = 1.0f / 5000.0f;  // depth values in TUM are scaled
     std::vector<double> poses;                 // q (w x y z), p per processed frame
-    std::vector<float> depth_m;
     double total_time = 0;
     long n = 0;
+    // frame i is enqueued (lvt_amd_track_rgbd_async: pageable buffers are the library's copy when the call returns), frame i + 1 is read, decoded and
+    // converted to metres while it tracks, then frame i's pose is collected -- the reference's loop (tum_rgbd_example.cpp:83-103) does the two in turn
+    struct Frame {
+        Gray rgb;
+        std::vector<float> depth_m;
+        bool ok = false;
+    };
+    auto load = [&](long i, Frame &f) {
+        Gray depth;
+        std::string err;
+        f.ok = i < frame_count && load_image(root_dir + "/" + dataset_name + "/" + rgb_titles[i], f.rgb, err) &&
+               load_image(root_dir + "/" + dataset_name + "/" + depth_titles[i], depth, err) && !depth.px16.empty() && depth.w == f.rgb.w && depth.h == f.rgb.h;
+        if (!f.ok) return;
+        f.depth_m.resize(depth.px16.size());
+        for (size_t k = 0; k < f.depth_m.size(); k++) f.depth_m[k] = (float)depth.px16[k] * depth_scale;
+    };
+    Frame cur, nxt;
+    load(0, cur);
     for (long i = 0; i < frame_count; i++) {
         std::cout << "Frame number: " << i << "/" << frame_count << "\r" << std::flush;
-        Gray rgb, depth;
-        std::string err;
-        if (!load_image(root_dir + "/" + dataset_name + "/" + rgb_titles[i], rgb, err) ||
-            !load_image(root_dir + "/" + dataset_name + "/" + depth_titles[i], depth, err) || depth.px16.empty() || depth.w != rgb.w || depth.h != rgb.h) {
+        if (!cur.ok) {
             std::cout << "Failed to load image " << std::endl;
             break;
         }
-        depth_m.resize(depth.px16.size());
-        for (size_t k = 0; k < depth_m.size(); k++) depth_m[k] = (float)depth.px16[k] * depth_scale;
-        double R[3][3], t[3];
         const auto t0 = std::chrono::steady_clock::now();
-        lvt_amd_track_rgbd(vo, rgb.px.data(), depth_m.data(), rgb.h, rgb.w, R, t);
-        total_time += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const int queued = lvt_amd_track_rgbd_async(vo, cur.rgb.px.data(), cur.depth_m.data(), cur.rgb.h, cur.rgb.w);
+        double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        if (queued != 0) break;  // (a frame of another size: the reference would throw inside OpenCV)
+        load(i + 1, nxt);
+        const auto t1 = std::chrono::steady_clock::now();
         double q[4], p[3];
-        lvt_amd_get_pose(vo, q, p);
+        const int state = lvt_amd_wait_pose(vo, q, p);
+        total_time += dt + std::chrono::duration<double>(std::chrono::steady_clock::now() - t1).count();
         for (int k = 0; k < 4; k++) poses.push_back(q[k]);
         for (int k = 0; k < 3; k++) poses.push_back(p[k]);
         n++;
-        if (lvt_get_status(vo) == 3) break;  // LOST
+        if (state == 3) break;  // LOST
+        std::swap(cur, nxt);
     }
     std::ofstream file(out_name.c_str());
     file << std::fixed;

@@ -62,6 +62,7 @@ struct Pool {
     std::deque<uint32_t> inflight;   // present-mask of every enqueued, un-collected step (FIFO)
     bool busy = false;               // the submission thread is inside HIP calls on ctx (lock released)
     bool stop = false;
+    int quiet = 0;                   // callers waiting for exclusive use of ctx (pool_quiesce): no new step is launched while there are any
     std::thread worker;
     long steps = 0, slot_frames = 0;  // statistics: steps launched, slot frames folded into them
     std::string err_seen;
@@ -125,6 +126,7 @@ static void pool_enqueue_step(Pool *P, std::unique_lock<std::mutex> &lk) {
     }
     lk.lock();
     P->busy = false;
+    P->cv_done.notify_all();
 }
 
 static void pool_collect_step(Pool *P, std::unique_lock<std::mutex> &lk) {
@@ -174,11 +176,13 @@ static void pool_worker(Pool *P) {
                 if (!P->slots[s]->pending.empty()) with_frames++;
                 else if (P->slots[s]->in_flight == 0 && P->slots[s]->results.empty()) idle_live++;
             }
-        if (with_frames == 0 && P->inflight.empty()) {
-            P->cv_work.wait(lk);
+        const bool may_enqueue = with_frames > 0 && (int)P->inflight.size() < POOL_DEPTH && P->quiet == 0;
+        if (!may_enqueue && P->inflight.empty()) {
+            if (with_frames > 0) P->cv_work.wait_for(lk, std::chrono::microseconds(200));  // (held back by a caller's exclusive section: look again soon)
+            else P->cv_work.wait(lk);
             continue;
         }
-        if (with_frames > 0 && (int)P->inflight.size() < POOL_DEPTH) {
+        if (may_enqueue) {
             // a lone step of synchronous callers: the others arrive within microseconds of each other (they all returned from the same step) --
             // give them 40 us before a step goes out with seats empty.  Never while steps are in flight (asynchronous callers keep their queues filled).
             if (P->inflight.empty() && idle_live > 0 && with_frames < P->live) {
@@ -193,13 +197,12 @@ static void pool_worker(Pool *P) {
 }
 
 // exclusive use of the pool's context from a caller thread (introspection, reset, destroy): no step in flight, the submission thread parked
+// (frames the other handles have deposited meanwhile stay in their queues: the thread launches nothing while `quiet` is raised, and cannot take the
+//  lock before the caller's exclusive section ends)
 static void pool_quiesce(Pool *P, std::unique_lock<std::mutex> &lk) {
-    P->cv_done.wait(lk, [&] {
-        if (P->busy || !P->inflight.empty()) return false;
-        for (int s = 0; s < POOL_SLOTS; s++)
-            if (P->slots[s] && !P->slots[s]->pending.empty()) return false;
-        return true;
-    });
+    P->quiet++;
+    P->cv_done.wait(lk, [&] { return !P->busy && P->inflight.empty(); });
+    P->quiet--;
 }
 
 static bool same_params(const lvt_amd_params &a, const lvt_amd_params &b) { return std::memcmp(&a, &b, sizeof(a)) == 0; }
@@ -254,8 +257,8 @@ static void pool_leave(PoolSlot *S) {
     Pool *P = S->pool;
     std::unique_lock<std::mutex> g(g_pool_mu);
     std::unique_lock<std::mutex> lk(P->mu);
-    P->cv_done.wait(lk, [&] { return S->pending.empty() && S->in_flight == 0; });
-    pool_quiesce(P, lk);
+    // the seat's own frames are through and the thread is not inside a launch that might look at the seat: enough to leave (the other seats go on)
+    P->cv_done.wait(lk, [&] { return S->pending.empty() && S->in_flight == 0 && !P->busy; });
     P->slots[S->slot] = nullptr;
     P->live--;
     {

@@ -140,6 +140,22 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     }
 #pragma unroll
     for (int k = 0; k < QPT; k++) qp[k] = qxy[min(tid + k * HB_THREADS, M - 1)];
+#if defined(LAB_STOP) && LAB_STOP == 3
+    {   // the launch's memory traffic alone: every load of the problem, folded into the stores the real kernel makes (nothing else)
+        uint32_t f = 0;
+#pragma unroll
+        for (int k = 0; k < TPT; k++)
+            f ^= tdlo[k].x ^ tdlo[k].y ^ tdlo[k].z ^ tdlo[k].w ^ tdhi[k].x ^ tdhi[k].y ^ tdhi[k].z ^ tdhi[k].w ^ __float_as_uint(tp[k].x) ^ __float_as_uint(tp[k].y) ^ tfl[k];
+#pragma unroll
+        for (int k = 0; k < QPT; k++) {
+            const int q = tid + k * HB_THREADS;
+            const v4u w0 = reinterpret_cast<const v4u *>(qd)[2 * min(q, M - 1)], w1 = reinterpret_cast<const v4u *>(qd)[2 * min(q, M - 1) + 1];
+            f ^= w0.x ^ w0.y ^ w0.z ^ w0.w ^ w1.x ^ w1.y ^ w1.z ^ w1.w ^ __float_as_uint(qp[k].x) ^ __float_as_uint(qp[k].y);
+            if (q < M) out[q] = make_int4((int)f, 0, 0, 0);
+        }
+        return;
+    }
+#endif
     for (int i = tid; i <= nb + 1; i += HB_THREADS) cnt[i] = 0;
     if (tid < HB_HIST) s_hist[tid] = 0;
     __syncthreads();

@@ -433,7 +433,8 @@ class HipBackend:
                     "instance; the rocprofv3 --stats average of this kernel over the same command is the same statistic (profiles/); "
                     "traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950 counts this kernel's 16-B-per-lane loads at one half) of the same launch: "
                     "collected by this run through rocprofv3 when the tool is there and this process is not itself being profiled, else the "
-                    "committed passes of tools/profile.sh (traffic_source says which)"}}
+                    "committed passes of tools/profile.sh (traffic_source says which).  Ceiling of this access pattern on an MI355X, measured in round 4 "
+                    "(profiles/r04_hamming_analysis.md 3b): the launch's loads and stores ALONE take 174 us = 0.69 of the 8 TB/s spec"}}
 
     def _leg_sync(self, args):
         """one frame at a time, nothing overlapped: what a caller of the reference's lvt_track gets (lvt_c.cpp:63-88); mean of the

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Soak run: N frames of a KITTI-shaped synthetic sequence through the ASYNCHRONOUS pipeline (4 frames in flight), every pose
-compared with the CPU oracle's.  python tests/tools/soak.py [frames] [seed]   (run on the GPU box)"""
+compared with the CPU oracle's.  python tests/tools/soak.py [frames] [seed] [host]   (run on the GPU box; a third argument "host" feeds the frames from
+page-locked HOST memory through lvt_amd_track_async instead of lvt_amd_track_device_async)"""
 import os
 import sys
 import time
@@ -15,6 +16,7 @@ from oracle import pyoracle as O
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 3000
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+host_mode = len(sys.argv) > 3 and sys.argv[3] == "host"
 w = make_world("kitti", seed=seed)
 prm = lvt_amd.kitti_params()
 H, W = w.H, w.W
@@ -32,12 +34,18 @@ for c0 in range(0, n, CH):
     for i in range(m):
         frames[i, :, :, :W] = w.render_stereo_torch(c0 + i, device="cuda")
     torch.cuda.synchronize()
-    host = frames[:, :, :, :W].contiguous().cpu().numpy()
+    host_t = frames[:, :, :, :W].contiguous().cpu().pin_memory()
+    host = host_t.numpy()
+    hbase, himg = host_t.data_ptr(), H * W
     base, fs = frames.data_ptr(), 2 * H * pitch
     poses, inflight = [], 0
     t0 = time.perf_counter()
     for i in range(m):
-        vo.track_device_async(base + i * fs, base + i * fs + H * pitch, H, W, pitch); inflight += 1
+        if host_mode:
+            assert vo.track_async_ptr(hbase + 2 * i * himg, hbase + (2 * i + 1) * himg, H, W) == 0
+        else:
+            vo.track_device_async(base + i * fs, base + i * fs + H * pitch, H, W, pitch)
+        inflight += 1
         if inflight >= 4:
             poses.append(vo.wait()); inflight -= 1
     while inflight:

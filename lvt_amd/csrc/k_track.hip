@@ -420,14 +420,11 @@ __global__ __launch_bounds__(256) void k_match_map(SeqArg<BV> sa, int par, seq_t
 // is finished.  Polled: a feature stream parked on an event barrier stalls the queues that share its hardware pipe -- with
 // the barrier, SHORTENING the feature chain made the whole pipeline slower -- and the event record costs the tracking stream
 // 3-4 us per frame.  (LVT_AMD_ORDERING=events uses the barrier instead of this kernel.)
-// Asynchronous host-buffer calls (lvt_amd_track_async): the frame's images are pulled over PCIe on a stream of their own; the gate also waits until
-// the pull kernels have published this frame's number in *pull_seq (nullptr: the images are resident already).
-__global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, seq_t want, int par, const seq_t *pull_seq, seq_t pull_want) {
+__global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, seq_t want, int par) {
     Ctl &ctl = *seqs[blockIdx.z].ctl;
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(&ctl.track_done_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want ||
-           (pull_seq && __hip_atomic_load(pull_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < pull_want)) {
+    while (__hip_atomic_load(&ctl.track_done_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
         __builtin_amdgcn_s_sleep(8);
         if (wall_clock64() - t0 > 200000000ull) {  // 2 s: the tracking stream is wedged, or a tool serialises the dispatches and this
             // kernel holds the slot.  The buffer still belongs to an older frame: this frame's feature kernels leave it alone
@@ -455,31 +452,6 @@ __global__ void k_feat_done(Seq *seqs, int par, seq_t seq) {
     }
     __threadfence();
     atomicExch(&fc.feat_seq, seq);
-}
-
-// Asynchronous host frames: the PCIe pull at the head of the feature stage makes that stream's chain the longest one (pull 34 + k_score 10 + k_cells 66 +
-// k_gather 8 + k_brief 12 us against the tracking chain's 113), so its tail -- k_gather and k_brief, 20 us -- moves to the early stream, which idles in
-// its gate at that time: k_cells_pub (feature stream, one thread) publishes the frame's number when its cells are complete, k_cells_wait (early stream,
-// one wave, polling like every gate) lets k_gather / k_brief of that frame through.  Both were enqueued after the kernels they wait for.
-__global__ void k_cells_pub(Seq *seqs, int par, seq_t seq) {
-    if (threadIdx.x != 0) return;
-    __threadfence();
-    atomicExch(&seqs[blockIdx.x].fb[par].fc->cells_seq, seq);
-}
-__global__ __launch_bounds__(64) void k_cells_wait(Seq *seqs, int par, seq_t seq) {
-    if (threadIdx.x != 0) return;
-    Seq &S = seqs[blockIdx.x];
-    FeatCtl &fc = *S.fb[par].fc;
-    const unsigned long long t0 = wall_clock64();
-    while (__hip_atomic_load(&fc.cells_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) {
-        __builtin_amdgcn_s_sleep(8);
-        if (wall_clock64() - t0 > 200000000ull) {  // 2 s: as k_gate_buf -- the frame has no features, it is skipped and reported
-            fc.poison = 1;
-            atomicAdd(&S.ctl->gate_fatal, 1);
-            __threadfence();
-            break;
-        }
-    }
 }
 
 // behind k_candidates<ROW>: this frame's row-match candidate lists are complete (k_triangulate's head polls the word)

@@ -132,7 +132,6 @@ struct FeatCtl {        // per-frame state of the FEATURE stage (own stream, one
     int absent;         // this step has no frame for the sequence (a pooled handle that did not submit one): poison without a report, the frame is not counted
     int poison;         // k_gate_buf gave up waiting for this buffer's previous user: the feature kernels of this frame must not touch it
     seq_t skip_seq;     // ... and this frame (sequence number) has no features: the tracking chain skips it
-    seq_t cells_seq;  // (asynchronous host frames) ... whose detection cells are complete: k_gather / k_brief of that frame run on the early stream behind this word
     seq_t feat_seq;  // sequence number of the frame whose features this buffer holds, published by k_feat_done (polled by k_gate)
 };
 

@@ -75,25 +75,7 @@ __device__ __forceinline__ void stage_put(uint8_t *dst, size_t i, int W, int pit
     const size_t y = i / (size_t)W;
     dst[y * pitch + (i - y * W)] = v;
 }
-// Asynchronous host-buffer calls run the pulls on a stream of their own: the workgroup that finishes last (counted over `total` workgroups, which
-// may belong to several launches of one frame) publishes the frame's sequence number in *pub, and the feature stream's gate (k_gate_buf) polls it.
-struct PullDone {
-    unsigned *ctr = nullptr;
-    seq_t *pub = nullptr;
-    seq_t seq = 0;
-    unsigned total = 0;
-};
-__device__ __forceinline__ void pull_done(const PullDone &d) {
-    if (!d.pub) return;
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0 && atomicAdd(d.ctr, 1u) == d.total - 1) {
-        atomicExch(d.ctr, 0u);
-        __threadfence();
-        atomicExch(d.pub, d.seq);
-    }
-}
-__global__ __launch_bounds__(256) void k_stage_in(const uint8_t *src0, const uint8_t *src1, uint8_t *dst0, uint8_t *dst1, int W, int H, int pitch, PullDone done) {
+__global__ __launch_bounds__(256) void k_stage_in(const uint8_t *src0, const uint8_t *src1, uint8_t *dst0, uint8_t *dst1, int W, int H, int pitch) {
     const uint8_t *src = blockIdx.y ? src1 : src0;
     uint8_t *dst = blockIdx.y ? dst1 : dst0;
     const size_t n = (size_t)W * H;
@@ -113,11 +95,10 @@ __global__ __launch_bounds__(256) void k_stage_in(const uint8_t *src0, const uin
     }
     if (t0 < head) stage_put(dst, t0, W, pitch, src[t0]);
     if (t0 < n - tail0) stage_put(dst, tail0 + t0, W, pitch, src[tail0 + t0]);
-    pull_done(done);
 }
 // the (unpitched) fp32 depth image: 16-byte loads between the first 16-byte boundary of the source and its last whole vector, single
 // floats on either side; the destination is written float by float (it is 16-byte aligned, the source need not be)
-__global__ __launch_bounds__(256) void k_stage_copy(const float *src, float *dst, size_t n, PullDone done) {
+__global__ __launch_bounds__(256) void k_stage_copy(const float *src, float *dst, size_t n) {
     const size_t head = min((size_t)(((16 - ((uintptr_t)src & 15)) & 15) / 4), n);
     const size_t nv = (n - head) / 4, tail0 = head + nv * 4;
     const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
@@ -128,7 +109,6 @@ __global__ __launch_bounds__(256) void k_stage_copy(const float *src, float *dst
     }
     if (t0 < head) dst[t0] = src[t0];
     if (t0 < n - tail0) dst[tail0 + t0] = src[tail0 + t0];
-    pull_done(done);
 }
 
 // handles alive in this process: a handle whose k_match_map polls for its early stream parks 32 workgroups (50 KB of LDS each)
@@ -217,23 +197,13 @@ struct Context {
     float *d_depth[NPAR] = {};
     // asynchronous host-buffer calls (lvt_amd_track_async / lvt_amd_track_rgbd_async): one image set and one staging buffer per RING slot -- frame t's
     // slot was last used by frame t - RING, which make_room() has collected, so neither the pull (a write) nor the CPU copy into the staging
-    // buffer needs a device-side hand-over; the pulls run on stream_p beside the previous frames' kernels and publish d_pull[0] (k_gate_buf polls it;
-    // event ordering: ev_pull).  LVT_AMD_PULL_STREAM=0 keeps the pulls on the feature stream (one stream less, the pull then lengthens that chain).
-    hipStream_t stream_p = nullptr;
-    int pull_mode = 0;   // LVT_AMD_PULL_STREAM: 0 = the feature stream (default: measured 8 110 frames/s against 4 400 with a fourth stream of the library's own --
-                         // the process's hardware queues are taken, two streams then share one and a polling gate holds up the other), 1 = a stream of its own,
-                         // 2 = the legacy null stream (it has a hardware queue already; the library's streams are non-blocking, so nothing else is ordered by it)
-    bool pull_on_own = false;
+    // buffer needs a device-side hand-over.  The pull kernel runs at the head of the frame's feature stage, on the feature stream: a stream of its own
+    // (4 400 against 8 100 frames/s), the null stream or other priorities (6 100) and the copy engine (5 600) were measured and removed
+    // (profiles/r04_async_host.md; the variants are in the history at 7f39175).
     uint8_t *d_img_ring[RING][2] = {};
-    uint8_t *d_pack_ring[RING][2] = {};   // LVT_AMD_PULL_STREAM=5: tightly packed copies made by the copy engine, re-pitched on the device
     float *d_depth_ring[RING] = {};
     uint8_t *h_stage_ring[RING] = {}, *h_stage_ring_dev[RING] = {};
     size_t stage_ring_bytes = 0;
-    seq_t *d_pull = nullptr;          // [0] last frame whose images are complete in HBM, [1] workgroup counter of the pull in flight
-    hipEvent_t ev_pull[RING] = {};
-    bool split_tail = false;          // LVT_AMD_FEATURE_SPLIT=1: k_gather / k_brief of an asynchronous host frame run on the early stream (measured: no gain --
-                                      // 7 350 / 7 638 against 7 754 / 7 690 frames/s at 20 steps, 8 150 / 8 167 against 8 179 / 8 202 at 400; the hand-over costs what the shorter chain saves)
-    seq_t pull_wait = 0;              // set for the frame being enqueued: its feature stage waits for this pull (0: images resident)
     long long async_frames = 0;
     float *d_ext[NPAR][2] = {};
     int pitch = 0;
@@ -276,12 +246,8 @@ struct Context {
         if (stream) (void)hipStreamSynchronize(stream);
         if (stream_f) (void)hipStreamSynchronize(stream_f);
         if (stream_e) (void)hipStreamSynchronize(stream_e);
-        if (stream_p) (void)hipStreamSynchronize(stream_p);
-        else if (pull_on_own) (void)hipStreamSynchronize(nullptr);
         for (void *p : allocs) (void)hipFree(p);
-        for (auto &x : ev_pull) if (x) (void)hipEventDestroy(x);
         for (auto &x : h_stage_ring) if (x) (void)hipHostFree(x);
-        if (stream_p) (void)hipStreamDestroy(stream_p);
         for (auto &e : ev)
             for (auto &x : e)
                 if (x) (void)hipEventDestroy(x);
@@ -508,9 +474,6 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_depth, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_switch, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&c->ev_switch_e, hipEventDisableTiming));
-        c->d_pull = c->dalloc<seq_t>(2);
-        if (const char *e = std::getenv("LVT_AMD_PULL_STREAM")) c->pull_mode = std::atoi(e);
-        if (const char *e = std::getenv("LVT_AMD_FEATURE_SPLIT")) c->split_tail = std::atoi(e) != 0;
         if (const char *e = std::getenv("LVT_AMD_TEST_GATE_TIMEOUT")) c->test_gate_timeout = std::atol(e);
         {
             // "events": barrier-only ordering; "polling": the polling gates + early stream; unset: polling for the first live
@@ -738,19 +701,12 @@ static void enqueue_frame(Context *c) {
     for (int i = 0; i < Context::PROF_SLOTS; i++) c->ev_used[i] = false;
     // ---- feature stage (stream_f): may start as soon as the tracking chain of frame enq-NPAR released this buffer
     const bool evo = c->events_only;
-    const bool pull_gate = c->pull_wait != 0 && c->pull_on_own;  // (pulls on the feature stream itself are ordered by that stream)
-    const bool split_tail = c->pull_wait != 0 && c->split_tail && B == 1 && !c->events_only && c->sensor == 1 && !c->prof && !c->h_fargs[slot].ext_corners;
-    if (c->enq >= NPAR || pull_gate) {
+    if (c->enq >= NPAR) {
         if (!evo)
-            hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, Bz), dim3(64), 0, sf, S, (seq_t)(c->enq >= NPAR ? c->enq + 1 - NPAR : 0), par,
-                               pull_gate ? (const seq_t *)c->d_pull : (const seq_t *)nullptr, c->pull_wait);  // polls; see k_gate_buf
-        else {
-            if (c->enq >= NPAR && (c->switched_at < 0 || (long)c->enq - NPAR >= c->switched_at))  // (frames from before a switch of the ordering: covered by ev_switch)
-                (void)hipStreamWaitEvent(sf, c->ev_done[(int)((c->enq - NPAR) % RING)], 0);
-            if (pull_gate) (void)hipStreamWaitEvent(sf, c->ev_pull[slot], 0);
-        }
+            hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, Bz), dim3(64), 0, sf, S, (seq_t)(c->enq + 1 - NPAR), par);  // polls; see k_gate_buf
+        else if (c->switched_at < 0 || (long)c->enq - NPAR >= c->switched_at)  // (frames from before a switch of the ordering: covered by ev_switch)
+            (void)hipStreamWaitEvent(sf, c->ev_done[(int)((c->enq - NPAR) % RING)], 0);
     }
-    c->pull_wait = 0;
     if (B == 1) {  // the frame's inputs travel as a kernel argument: no separate "begin" launch, no device read of pinned host memory
         LAUNCH(2, sf, k_score<true>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2), dim3(256), 0, S, c->h_fargs[slot], par, 0);
     } else {
@@ -785,16 +741,9 @@ static void enqueue_frame(Context *c) {
         (void)hipStreamWaitEvent(sf, c->ev_depth, 0);
         c->depth_wait = false;
     }
-    // the feature stage's tail: on the feature stream -- or, for an asynchronous host frame of a single sequence, on the early stream (k_cells_pub)
-    const bool tail_on_early = split_tail;
-    hipStream_t stail = tail_on_early ? c->stream_e : sf;
-    if (tail_on_early) {
-        hipLaunchKernelGGL(k_cells_pub, dim3(1), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));
-        hipLaunchKernelGGL(k_cells_wait, dim3(1), dim3(64), 0, stail, S, par, (seq_t)(c->enq + 1));
-    }
-    LAUNCH_S(5, stail, k_gather, dim3(1, 2, Bz), dim3(1024), CELLS_LDS_BYTES, (const Seq *)S, par);
+    LAUNCH_S(5, sf, k_gather, dim3(1, 2, Bz), dim3(1024), CELLS_LDS_BYTES, (const Seq *)S, par);
     const bool brief_publishes = !evo && B == 1;  // (single sequence: k_brief's last workgroup publishes feat_seq; see k_feat_done)
-    LAUNCH_S(6, stail, k_brief, dim3(64, 2, Bz), dim3(256), 0, (const Seq *)S, par, brief_publishes ? (seq_t)(c->enq + 1) : (seq_t)0);
+    LAUNCH_S(6, sf, k_brief, dim3(64, 2, Bz), dim3(256), 0, (const Seq *)S, par, brief_publishes ? (seq_t)(c->enq + 1) : (seq_t)0);
     if (!evo && !brief_publishes) hipLaunchKernelGGL(k_feat_done, dim3(Bz), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));
     const int bl = c->binned_lists ? 1 : 0;
     if (evo && bl && c->sensor == 1) LAUNCH_SM(19, sf, k_hamming_batched_lists, MODE_ROW, dim3(c->lists_wgs_row, 1, Bz), dim3(LS_THREADS), LS_LDS_BYTES, par, (seq_t)0);
@@ -1193,7 +1142,7 @@ LVT_API void lvt_amd_get_host_stats(lvt_handle h, long long out[8]) {
         return;
     }
     out[0] = (long long)c->enq, out[1] = (long long)c->done, out[2] = c->planes_in_place, out[3] = c->planes_staged;
-    out[4] = c->async_frames, out[5] = c->pull_mode, out[6] = c->score_pieces, out[7] = c->events_only ? 1 : 0;
+    out[4] = c->async_frames, out[5] = 0, out[6] = c->score_pieces, out[7] = c->events_only ? 1 : 0;
 }
 
 LVT_API void lvt_amd_profile_enable(lvt_handle h, int enable) {
@@ -1442,13 +1391,13 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
         std::memcpy(c->h_stage[par], left, nbytes);
         s0 = c->h_stage_dev[par];
     }
-    if (split) hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sf, s0, s0, c->d_img[par][0], c->d_img[par][0], n_cols, n_rows, c->pitch, PullDone{});
+    if (split) hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sf, s0, s0, c->d_img[par][0], c->d_img[par][0], n_cols, n_rows, c->pitch);
     if (!s1 && !rgbd) {
         std::memcpy(c->h_stage[par] + c->stage_img, second, nbytes);
         s1 = c->h_stage_dev[par] + c->stage_img;
     }
-    if (split) hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sf, s1, s1, c->d_img[par][1], c->d_img[par][1], n_cols, n_rows, c->pitch, PullDone{});
-    else hipLaunchKernelGGL(k_stage_in, dim3(128, rgbd ? 1 : 2), dim3(256), 0, sf, s0, s1, c->d_img[par][0], c->d_img[par][1], n_cols, n_rows, c->pitch, PullDone{});
+    if (split) hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sf, s1, s1, c->d_img[par][1], c->d_img[par][1], n_cols, n_rows, c->pitch);
+    else hipLaunchKernelGGL(k_stage_in, dim3(128, rgbd ? 1 : 2), dim3(256), 0, sf, s0, s1, c->d_img[par][0], c->d_img[par][1], n_cols, n_rows, c->pitch);
     drain(c);
     FrameArgs &f = c->h_fargs[(size_t)(c->enq % RING) * c->B];
     f.img[0] = c->d_img[par][0];
@@ -1470,7 +1419,7 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
                 src = c->h_stage_dev[par] + c->stage_img;
             }
             hipStream_t sd = c->events_only ? sf : c->stream_e;
-            hipLaunchKernelGGL(k_stage_copy, dim3(256), dim3(256), 0, sd, reinterpret_cast<const float *>(src), reinterpret_cast<float *>(c->d_depth[par]), nbytes, PullDone{});
+            hipLaunchKernelGGL(k_stage_copy, dim3(256), dim3(256), 0, sd, reinterpret_cast<const float *>(src), reinterpret_cast<float *>(c->d_depth[par]), nbytes);
             if (sd != sf) {
                 (void)hipEventRecord(c->ev_depth, sd);
                 c->depth_wait = true;
@@ -1494,7 +1443,8 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
 // Asynchronous counterpart of upload_and_track (lvt_amd_track_async / lvt_amd_track_rgbd_async): borrowed HOST images, the frame is enqueued and the
 // call returns; the pose comes out of the same FIFO as lvt_amd_track_device_async's (lvt_amd_wait / lvt_amd_wait_status).  Pageable buffers are copied
 // into this slot's pinned staging buffer during the call; page-locked ones are pulled where they lie (and must stay valid until the frame is collected).
-// The pull runs on its own stream: the images of frame t + 1 cross PCIe while the kernels of frame t run (SURVEY 8e "pinned H2D staging double-buffered").
+// The pull kernel heads the frame's feature stage: with several frames in flight the images of frame t + 1 cross PCIe while the tracking chain of frame t
+// runs (SURVEY 8e "pinned H2D staging double-buffered").
 // Returns 0 when the frame was enqueued, -1 when it was rejected (nothing enqueued; lvt_amd_last_error says why).
 static int upload_async(Context *c, const unsigned char *left, const void *second, bool rgbd, int n_rows, int n_cols) {
     if (c->B != 1 || (rgbd ? c->sensor != 2 : c->sensor != 1)) {
@@ -1513,18 +1463,7 @@ static int upload_async(Context *c, const unsigned char *left, const void *secon
         for (int r = 0; r < RING; r++) {
             for (int e = 0; e < (rgbd ? 1 : 2); e++) c->d_img_ring[r][e] = c->dalloc<uint8_t>(plane + 64);
             if (rgbd) c->d_depth_ring[r] = c->dalloc<float>(nbytes + 4);
-            HIPCHK(c, hipEventCreateWithFlags(&c->ev_pull[r], hipEventDisableTiming));
         }
-        if (c->pull_mode == 1) HIPCHK(c, hipStreamCreateWithFlags(&c->stream_p, hipStreamNonBlocking));
-        if (c->pull_mode == 5 && !rgbd)
-            for (int r = 0; r < RING; r++)
-                for (int e = 0; e < 2; e++) c->d_pack_ring[r][e] = c->dalloc<uint8_t>(nbytes + 64);
-        if (c->pull_mode == 3 || c->pull_mode == 4) {  // a stream of another PRIORITY: the runtime keeps one pool of hardware queues per priority level
-            int lo = 0, hi = 0;
-            HIPCHK(c, hipDeviceGetStreamPriorityRange(&lo, &hi));  // (lo = numerically greatest = least urgent)
-            HIPCHK(c, hipStreamCreateWithPriority(&c->stream_p, hipStreamNonBlocking, c->pull_mode == 3 ? lo : hi));
-        }
-        c->pull_on_own = c->pull_mode >= 1 && c->pull_mode <= 4;
     }
     auto device_view = [](const void *p, size_t align) -> const uint8_t * {
         hipPointerAttribute_t a;
@@ -1542,48 +1481,33 @@ static int upload_async(Context *c, const unsigned char *left, const void *secon
         HIPCHK(c, hipHostMalloc((void **)&c->h_stage_ring[slot], c->stage_ring_bytes, hipHostMallocDefault));
         HIPCHK(c, hipHostGetDevicePointer((void **)&c->h_stage_ring_dev[slot], c->h_stage_ring[slot], 0));
     }
-    hipStream_t sp = c->pull_on_own ? c->stream_p /* (nullptr = the null stream in mode 2) */ : c->stream_f;
-    const seq_t seq = (seq_t)(c->enq + 1);
-    PullDone done;
-    if (c->pull_on_own && !c->events_only) done.ctr = reinterpret_cast<unsigned *>(c->d_pull + 1), done.pub = c->d_pull, done.seq = seq;
+    hipStream_t sp = c->stream_f;
     uint8_t *d0 = c->d_img_ring[slot][0], *d1 = c->d_img_ring[slot][1];
-    if (!rgbd && c->pull_mode == 5) {
-        // copy engine: host -> packed device buffer (pageable sources go through the staging ring first), then one kernel re-pitches both planes
-        const void *h0 = left, *h1 = second;
-        if (!s0) std::memcpy(c->h_stage_ring[slot], left, nbytes), h0 = c->h_stage_ring[slot];
-        if (!s1) std::memcpy(c->h_stage_ring[slot] + img_b, second, nbytes), h1 = c->h_stage_ring[slot] + img_b;
-        HIPCHK(c, hipMemcpyAsync(c->d_pack_ring[slot][0], h0, nbytes, hipMemcpyHostToDevice, sp));
-        HIPCHK(c, hipMemcpyAsync(c->d_pack_ring[slot][1], h1, nbytes, hipMemcpyHostToDevice, sp));
-        hipLaunchKernelGGL(k_stage_in, dim3(128, 2), dim3(256), 0, sp, c->d_pack_ring[slot][0], c->d_pack_ring[slot][1], d0, d1, n_cols, n_rows, c->pitch, PullDone{});
-    } else if (!rgbd) {
-        done.total = 256;  // two launches of (128, 1) or one of (128, 2)
+    if (!rgbd) {
         const bool split = !s0 && !s1;  // two pageable images: the left one crosses PCIe while the CPU copies the right one
         if (!s0) {
             std::memcpy(c->h_stage_ring[slot], left, nbytes);
             s0 = c->h_stage_ring_dev[slot];
         }
-        if (split) hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sp, s0, s0, d0, d0, n_cols, n_rows, c->pitch, done);
+        if (split) hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sp, s0, s0, d0, d0, n_cols, n_rows, c->pitch);
         if (!s1) {
             std::memcpy(c->h_stage_ring[slot] + img_b, second, nbytes);
             s1 = c->h_stage_ring_dev[slot] + img_b;
         }
-        if (split) hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sp, s1, s1, d1, d1, n_cols, n_rows, c->pitch, done);
-        else hipLaunchKernelGGL(k_stage_in, dim3(128, 2), dim3(256), 0, sp, s0, s1, d0, d1, n_cols, n_rows, c->pitch, done);
+        if (split) hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sp, s1, s1, d1, d1, n_cols, n_rows, c->pitch);
+        else hipLaunchKernelGGL(k_stage_in, dim3(128, 2), dim3(256), 0, sp, s0, s1, d0, d1, n_cols, n_rows, c->pitch);
     } else {
-        done.total = 128 + 256;
         if (!s0) {
             std::memcpy(c->h_stage_ring[slot], left, nbytes);
             s0 = c->h_stage_ring_dev[slot];
         }
-        hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sp, s0, s0, d0, d0, n_cols, n_rows, c->pitch, done);
+        hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sp, s0, s0, d0, d0, n_cols, n_rows, c->pitch);
         if (!s1) {
             std::memcpy(c->h_stage_ring[slot] + img_b, second, sizeof(float) * nbytes);
             s1 = c->h_stage_ring_dev[slot] + img_b;
         }
-        hipLaunchKernelGGL(k_stage_copy, dim3(256), dim3(256), 0, sp, reinterpret_cast<const float *>(s1), c->d_depth_ring[slot], nbytes, done);
+        hipLaunchKernelGGL(k_stage_copy, dim3(256), dim3(256), 0, sp, reinterpret_cast<const float *>(s1), c->d_depth_ring[slot], nbytes);
     }
-    if (c->pull_on_own && c->events_only) (void)hipEventRecord(c->ev_pull[slot], sp);
-    c->pull_wait = seq;
     FrameArgs &f = c->h_fargs[(size_t)slot * c->B];
     f.img[0] = d0;
     f.img[1] = rgbd ? d0 : d1;
@@ -1591,7 +1515,7 @@ static int upload_async(Context *c, const unsigned char *left, const void *secon
     f.depth = rgbd ? c->d_depth_ring[slot] : nullptr;
     f.depth_pitch = rgbd ? n_cols : 0;
     f.ext_corners = 0;
-        f.absent = 0;
+    f.absent = 0;
     f.n_ext[0] = f.n_ext[1] = 0;
     c->async_frames++;
     enqueue_frame(c);

@@ -113,7 +113,7 @@ static void pool_enqueue_step(Pool *P, std::unique_lock<std::mutex> &lk) {
                 PoolSlot *S = P->slots[s];
                 const int rows = c->prm.H, cols = c->prm.W;
                 hipLaunchKernelGGL(k_stage_in, dim3(128, 2), dim3(256), 0, c->stream_f, S->h_stage_dev[p.stage], S->h_stage_dev[p.stage] + S->stage_img,
-                                   S->d_img[p.stage][0], S->d_img[p.stage][1], cols, rows, c->pitch, PullDone{});
+                                   S->d_img[p.stage][0], S->d_img[p.stage][1], cols, rows, c->pitch);
                 f.img[0] = S->d_img[p.stage][0], f.img[1] = S->d_img[p.stage][1];
                 f.img_pitch = c->pitch;
             } else {

@@ -89,7 +89,10 @@ LVT_API void lvt_amd_track_device_async(lvt_handle h, const void *d_left, const 
  *  - pageable buffers are copied into a pinned staging ring during the call: they are the caller's again when it returns;
  *  - page-locked buffers (hipHostMalloc / hipHostRegister) are pulled over PCIe WHERE THEY LIE: they must stay valid and unchanged until that frame
  *    has been collected (lvt_amd_get_host_stats out[2] / out[3] count the planes that went either way).
- * The pull kernel of a frame runs at the head of its feature stage, i.e. beside the tracking chain of the frames before it.
+ * A stereo frame is HELD until the next one arrives or somebody waits for it (lvt_amd_wait* release it when the device would otherwise run dry, every
+ * other entry point releases it first): the held frame's corner-cell launch then carries the workgroups that pull the NEXT frame's images over PCIe
+ * beside its cells, and the pull is on no stream's chain (out[5] of lvt_amd_get_host_stats counts the frames whose images came that way;
+ * LVT_AMD_FUSED_PULL=0: every frame pulls its own images at the head of its feature stage, as RGB-D frames and held frames nobody followed do).
  * Returns 0 when the frame was enqueued; -1 when it was rejected -- wrong image size, NULL buffer, wrong sensor type, a batch handle -- and then
  * NOTHING was enqueued (frames in flight are unaffected, lvt_amd_last_error says why). */
 LVT_API int lvt_amd_track_async(lvt_handle h, const unsigned char *left, const unsigned char *right, int n_rows, int n_cols);
@@ -127,7 +130,7 @@ LVT_API const char *lvt_amd_last_error(lvt_handle h);
  * enable=1 resets the accumulators.  lvt_amd_profile_read returns 0 past the last slot. */
 /* host-side counters of a handle: out[0] frames enqueued, out[1] frames collected, out[2] image / depth planes of host-buffer calls
    (lvt_track, lvt_amd_track_rgbd, ...) that were read IN PLACE because the caller's buffer is page-locked, out[3] planes copied through the
-   library's staging buffer; out[4] frames that came through lvt_amd_track_async / _rgbd_async, out[5] reserved (0),
+   library's staging buffer; out[4] frames that came through lvt_amd_track_async / _rgbd_async, out[5] of them: frames whose images were pulled by the launch of the frame before them,
    out[6] launches a lock-step batch's k_score is currently sent in (1 / 2: chosen from the batch's own gate stamps unless LVT_AMD_SCORE_PIECES fixes it),
    out[7] 1 when the handle orders its streams with events */
 LVT_API void lvt_amd_get_host_stats(lvt_handle h, long long out[8]);

@@ -218,7 +218,7 @@ class LvtSystem:
         a = (C.c_longlong * 8)()
         load_library().lvt_amd_get_host_stats(self._h, a)
         return {"enqueued": int(a[0]), "collected": int(a[1]), "planes_in_place": int(a[2]), "planes_staged": int(a[3]),
-                "async_host_frames": int(a[4]), "score_pieces": int(a[6]), "event_ordering": int(a[7])}
+                "async_host_frames": int(a[4]), "pulls_carried_by_the_previous_frame": int(a[5]), "score_pieces": int(a[6]), "event_ordering": int(a[7])}
 
     # lvt_system::track(img1, img2)  -- lvt_system.cpp:157-207
     def track(self, img1, img2):

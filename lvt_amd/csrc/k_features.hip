@@ -1334,6 +1334,40 @@ __device__ __forceinline__ void cells_work(const Seq &S, const FrameBuf &FB, int
     cell_finish(FB, eye, cell, pass, n_out);
 }
 
+// ---- host images into the pitched planes (the body of k_stage_in, lvt_host.hip; also the pull workgroups of k_cells below) -------------------
+// tightly packed source (stride == cols, ANY byte address and byte count) -> pitched plane: bytes up to the first 16-byte boundary and behind the
+// last whole vector travel one by one, everything between as aligned 16-byte loads; no load reaches outside [src, src + W H).
+__device__ __forceinline__ void stage_put(uint8_t *dst, size_t i, int W, int pitch, uint8_t v) {
+    const size_t y = i / (size_t)W;
+    dst[y * pitch + (i - y * W)] = v;
+}
+__device__ __forceinline__ void stage_in_body(const uint8_t *src, uint8_t *dst, int W, int H, int pitch, size_t t0, size_t stride) {
+    const size_t n = (size_t)W * H;
+    const size_t head = min((size_t)((16 - ((uintptr_t)src & 15)) & 15), n);
+    const size_t nv = (n - head) / 16, tail0 = head + nv * 16;
+    for (size_t v = t0; v < nv; v += stride) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(src + head + v * 16);
+        const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
+        size_t i = head + v * 16;
+        int y = (int)(i / (size_t)W), x = (int)(i - (size_t)y * W);
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            dst[(size_t)y * pitch + x] = (uint8_t)(wds[k >> 2] >> (8 * (k & 3)));
+            if (++x == W) x = 0, y++;
+        }
+    }
+    if (t0 < head) stage_put(dst, t0, W, pitch, src[t0]);
+    if (t0 < n - tail0) stage_put(dst, tail0 + t0, W, pitch, src[tail0 + t0]);
+}
+// Asynchronous host frames of a single sequence: k_cells is the longest kernel of the feature stage (66 us) and occupies 40 of the 256 CUs -- its
+// launch carries extra workgroups (blockIdx.x >= n_cells) that pull the NEXT frame's images over PCIe into their planes (24 us, beside the cells):
+// the pull leaves the feature stream's chain, which was the longest of the three with it (lvt_host.hip, upload_async).
+struct NextPull {
+    const uint8_t *src[2];  // nullptr: nothing to pull
+    uint8_t *dst[2];
+    int W, H, pitch;
+};
+
 // pass 0 of the detection (the <200-corner retry, handler.cpp:161-169, runs inside k_gather)
 // A lock-step batch launches its cells as ONE row of workgroups, the cells with the largest area first (CellOrder, filled by the host): with more
 // workgroups than CUs (16 sequences x 20 cells on 256) the workgroups that start late -- on the CUs the first small cells leave -- are then small
@@ -1342,8 +1376,15 @@ struct CellOrder {
     uint8_t v[CELLS_MAX];
 };
 template <bool BV>  // (a single sequence's descriptor travels in the kernel arguments: one dependent memory hop less at the head of the longest kernel)
-__device__ __forceinline__ void cells_entry(const SeqArg<BV> &sa, int pass, int par, const CellOrder &ord, int lanes, int raw_cap) {
+__device__ __forceinline__ void cells_entry(const SeqArg<BV> &sa, int pass, int par, const CellOrder &ord, int lanes, int raw_cap, const NextPull &np) {
     int eye = blockIdx.y, cell = blockIdx.x;
+    if constexpr (BV) {
+        if ((int)blockIdx.x >= sa.v.prm.n_cells) {  // a pull workgroup (only launched when there is something to pull)
+            const int k = (int)blockIdx.x - sa.v.prm.n_cells, nk = (int)gridDim.x - sa.v.prm.n_cells;
+            stage_in_body(np.src[eye], np.dst[eye], np.W, np.H, np.pitch, (size_t)k * blockDim.x + threadIdx.x, (size_t)nk * blockDim.x);
+            return;
+        }
+    }
     const Seq *Sp;
     if constexpr (BV) {
         Sp = &sa.v;
@@ -1363,12 +1404,12 @@ __device__ __forceinline__ void cells_entry(const SeqArg<BV> &sa, int pass, int 
 // instance is held to 64 so that TWO of its 80-KB workgroups share a CU (at 66 registers it ran one per CU whatever its LDS) -- an occupancy
 // attribute on the template would cap the single-sequence instance too, where a second workgroup can never fit and the cap can only spill.
 template <bool BV>
-__global__ __launch_bounds__(1024) void k_cells(SeqArg<BV> sa, int pass, int par, CellOrder ord, int lanes, int raw_cap) {
-    cells_entry<BV>(sa, pass, par, ord, lanes, raw_cap);
+__global__ __launch_bounds__(1024) void k_cells(SeqArg<BV> sa, int pass, int par, CellOrder ord, int lanes, int raw_cap, NextPull np) {
+    cells_entry<BV>(sa, pass, par, ord, lanes, raw_cap, np);
 }
 template <>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_cells<false>(SeqArg<false> sa, int pass, int par, CellOrder ord, int lanes, int raw_cap) {
-    cells_entry<false>(sa, pass, par, ord, lanes, raw_cap);
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_cells<false>(SeqArg<false> sa, int pass, int par, CellOrder ord, int lanes, int raw_cap, NextPull np) {
+    cells_entry<false>(sa, pass, par, ord, lanes, raw_cap, np);
 }
 
 // ---- an oversized cell as row strips --------------------------------------------------------------------------------------------

@@ -19,6 +19,7 @@
 // The Hamming distance evaluation is parallel (k_candidates); only the accept/mark scan is sequential,
 // and it walks pre-sorted candidate lists so it touches a few words per query.
 #include "lvt_dev.h"
+#include "wave_reduce.h"
 #include "lvt_math.h"
 
 namespace lvt {
@@ -1394,57 +1395,27 @@ constexpr int PNP_THREADS = 256;
 constexpr int PNP_ILP = 3;  // edges per thread in flight in one sweep iteration (KITTI: ~650 edges = one iteration)
 
 // block-wide sum of NV doubles per thread.  NV < 8: result in v[] of every thread.  NV >= 8: result in dst[0..NV-1] (LDS).
-// Large NV: partials go through LDS ([NV][PNP_THREADS] doubles), wave w sums values w, w+NW, ... (PNP_THREADS/64
-// partials per lane, then one 64-lane butterfly), interleaved so the butterfly chains overlap.
+// Large NV: every wavefront reduce-scatters its NV values in registers (wave_reduce.h: 29 additions and their lane exchanges for 28 values, the lane
+// pair (l, l ^ 1) ends with the total of value wave_rs_index(l)), 32 lanes per wavefront put them into LDS, thread k adds the four wavefronts' totals of value k.
+// Two barriers and 1 KB through LDS (round 3's form -- every thread's 28 partials through LDS, transposed, 57 KB each way, three barriers -- took ~2 000
+// cycles of the ~4 000 a sweep takes).  red[128, 256) only: block_sum<1> (red[0, 4)) may still be read by a slow wavefront when this one is entered.
 constexpr int PNP_NW = PNP_THREADS / 64;
 template <int NV>
-__device__ __forceinline__ void block_sum(double (&v)[NV], double *red, double *dst = nullptr, long long *bs = nullptr) {
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *red, double *dst = nullptr) {
     const int w = wave_id(), l = lane_id(), tid = threadIdx.x;
     if (NV >= 8) {
-        // transposed partials part[k][tid], then thread (k, j) adds the 32 entries j, j + 8, j + 16, ... of row k (one
-        // address register, immediate offsets, no predicates), then thread k adds the 8 segment sums.  No cross-lane
-        // traffic, three barriers.  Row stride 264 doubles: rows k and k + 4 share banks, nothing else does.
-        constexpr int SEG = 8, SLEN = PNP_THREADS / SEG;  // SEG = 8: one DPP row holds two rows' segment sums
-        constexpr int STRIDE = PNP_THREADS + 8;
-        static_assert(NV * SEG <= PNP_THREADS && PNP_THREADS % SEG == 0, "block_sum layout");
-        double *part = red + 384;  // [NV][STRIDE]
-        long long b0 = clock64();
+        static_assert(NV <= 32, "block_sum: one reduce-scatter");
+        double *part = red + 128;  // [PNP_NW][32]
+        const double s = wave_reduce_scatter<NV>(v);
+        if (!(l & 1)) part[w * 32 + wave_rs_index(l)] = s;
         __syncthreads();
-        long long b1 = clock64();
+        if (tid < NV) {
+            double t = part[tid];
 #pragma unroll
-        for (int k = 0; k < NV; k++) part[k * STRIDE + tid] = v[k];
-        __syncthreads();
-        long long b2 = clock64();
-        if (tid < NV * SEG) {
-            const double *p = part + (tid / SEG) * STRIDE + (tid % SEG);
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-#pragma unroll
-            for (int u = 0; u < SLEN; u += 4) {
-                s0 += p[SEG * u];
-                s1 += p[SEG * (u + 1)];
-                s2 += p[SEG * (u + 2)];
-                s3 += p[SEG * (u + 3)];
-            }
-            // the 8 segment sums of row k sit in 8 consecutive lanes: three DPP row shifts add them up in lane 8k + 7
-            double s = (s0 + s1) + (s2 + s3);
-#define LVT_DPP_ADD_F64(CTRL)                                                                          \
-    {                                                                                                  \
-        const int lo_ = __builtin_amdgcn_update_dpp(0, __double2loint(s), CTRL, 0xf, 0xf, false);      \
-        const int hi_ = __builtin_amdgcn_update_dpp(0, __double2hiint(s), CTRL, 0xf, 0xf, false);      \
-        s += __hiloint2double(hi_, lo_);                                                               \
-    }
-            LVT_DPP_ADD_F64(0x111)  // row_shr:1 (lanes without a source read 0)
-            LVT_DPP_ADD_F64(0x112)  // row_shr:2
-            LVT_DPP_ADD_F64(0x114)  // row_shr:4
-#undef LVT_DPP_ADD_F64
-            if ((tid & (SEG - 1)) == SEG - 1) dst[tid / SEG] = s;
+            for (int m = 1; m < PNP_NW; m++) t += part[m * 32 + tid];
+            dst[tid] = t;  // v[] is NOT updated (only thread 0 wants the sums)
         }
         __syncthreads();
-        long long b3 = clock64(), b4 = b3;  // the NV sums are in dst[0..NV-1]; v[] is NOT updated (only thread 0 wants them)
-        if (bs) {
-            long long b5 = clock64();
-            bs[0] += b1 - b0, bs[1] += b2 - b1, bs[2] += b3 - b2, bs[3] += b4 - b3, bs[4] += b5 - b4;
-        }
     } else {
 #pragma unroll
         for (int k = 0; k < NV; k++) v[k] = wave_sum(v[k]);
@@ -1580,7 +1551,6 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
                         int8_t *level, int n, PnpShared &sh, double *red, Pose &result, int &inliers, int &solve_calls, int &borderline, long long *dbg = nullptr) {
     const int tid = threadIdx.x;
     long long t_sweep = 0, t_solve = 0, t_dec = 0, t_red = 0, t_all = clock64();
-    long long bs[5] = {0, 0, 0, 0, 0};
     const double fx = prm.fx, fy = prm.fy, cx = prm.cx, cy = prm.cy;
     const double mono_chi = sqrt(REPROJ_TH2);
     const double dsqr = mono_chi * mono_chi;
@@ -1691,7 +1661,7 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
                     if (speculate) {
                         pnp_sweep<true>(cam, ct, fx, fy, cx, cy, dsqr, dsqrReci, X, obs, err, sink, level, n, acc);
                         const long long c2 = clock64();
-                        block_sum<28>(acc, red, sh.sys[sh.cur ^ 1], bs);  // the trial's system goes to the spare slot
+                        block_sum<28>(acc, red, sh.sys[sh.cur ^ 1]);  // the trial's system goes to the spare slot
                         t_red += clock64() - c2;
                         tempChi = sh.sys[sh.cur ^ 1][27];
                     } else {
@@ -1808,7 +1778,7 @@ __device__ __forceinline__ void pnp_solve(const Params &prm, const Pose &prior, 
         for (int i = threadIdx.x; i < 2 * n; i += PNP_THREADS) sObs[i] = obs[i];
         for (int i = threadIdx.x; i < n; i += PNP_THREADS) sLvl[i] = level[i];
         __syncthreads();
-        pnp_run(prm, prior, sX, sObs, sErr, red + 382, sLvl, n, sh, red, res, inliers, calls, borderline, dbg);  // red[382..383]: free (block_sum uses [0, 32) and [384, ...))
+        pnp_run(prm, prior, sX, sObs, sErr, red + 382, sLvl, n, sh, red, res, inliers, calls, borderline, dbg);  // red[382..383]: free (block_sum uses [0, 4) and [128, 256))
         for (int i = threadIdx.x; i < 2 * n; i += PNP_THREADS) err[i] = sErr[i];
         for (int i = threadIdx.x; i < n; i += PNP_THREADS) level[i] = sLvl[i];
     } else
@@ -1835,7 +1805,7 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(SeqArg<BV> sa, int par, seq
         return;
     }
     __shared__ PnpShared sh;
-    __shared__ double red[384 + 28 * (PNP_THREADS + 8)];
+    __shared__ double red[384];
     extern __shared__ __attribute__((aligned(16))) uint8_t pnp_dyn[];
     Pose res;
     int inliers, calls, borderline;
@@ -1875,7 +1845,7 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(SeqArg<BV> sa, int par, seq
 __global__ __launch_bounds__(PNP_THREADS) void k_pnp_standalone(Params prm, Pose prior, const double *X, const float *obs, double *err,
                                                                 int8_t *level, int n, Pose *out, int *info, double *trace, int trace_cap) {
     __shared__ PnpShared sh;
-    __shared__ double red[384 + 28 * (PNP_THREADS + 8)];
+    __shared__ double red[384];
     extern __shared__ __attribute__((aligned(16))) uint8_t pnp_dyn[];
     for (int i = threadIdx.x; i < n; i += PNP_THREADS) level[i] = 0;
     if (threadIdx.x == 0) sh.trace = trace, sh.trace_cap = trace_cap;

@@ -71,30 +71,8 @@ __global__ void k_feat_begin(Seq *seqs, const FrameArgs *fa, int par) {
 // copies + two re-pitch kernels (0.32 ms per stereo pair -> see DESIGN.md section 6).  The source may start at ANY byte address and
 // hold any byte count (1241 x 376 = 466 616 is 8 mod 16): bytes up to the first 16-byte boundary and behind the last whole vector
 // travel one by one, everything between as aligned 16-byte loads -- no load reaches outside [src, src + n).
-__device__ __forceinline__ void stage_put(uint8_t *dst, size_t i, int W, int pitch, uint8_t v) {
-    const size_t y = i / (size_t)W;
-    dst[y * pitch + (i - y * W)] = v;
-}
 __global__ __launch_bounds__(256) void k_stage_in(const uint8_t *src0, const uint8_t *src1, uint8_t *dst0, uint8_t *dst1, int W, int H, int pitch) {
-    const uint8_t *src = blockIdx.y ? src1 : src0;
-    uint8_t *dst = blockIdx.y ? dst1 : dst0;
-    const size_t n = (size_t)W * H;
-    const size_t head = min((size_t)((16 - ((uintptr_t)src & 15)) & 15), n);
-    const size_t nv = (n - head) / 16, tail0 = head + nv * 16;
-    const size_t t0 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, stride = (size_t)gridDim.x * blockDim.x;
-    for (size_t v = t0; v < nv; v += stride) {
-        const uint4 q = *reinterpret_cast<const uint4 *>(src + head + v * 16);
-        const uint32_t wds[4] = {q.x, q.y, q.z, q.w};
-        size_t i = head + v * 16;
-        int y = (int)(i / (size_t)W), x = (int)(i - (size_t)y * W);
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            dst[(size_t)y * pitch + x] = (uint8_t)(wds[k >> 2] >> (8 * (k & 3)));
-            if (++x == W) x = 0, y++;
-        }
-    }
-    if (t0 < head) stage_put(dst, t0, W, pitch, src[t0]);
-    if (t0 < n - tail0) stage_put(dst, tail0 + t0, W, pitch, src[tail0 + t0]);
+    stage_in_body(blockIdx.y ? src1 : src0, blockIdx.y ? dst1 : dst0, W, H, pitch, (size_t)blockIdx.x * blockDim.x + threadIdx.x, (size_t)gridDim.x * blockDim.x);
 }
 // the (unpitched) fp32 depth image: 16-byte loads between the first 16-byte boundary of the source and its last whole vector, single
 // floats on either side; the destination is written float by float (it is 16-byte aligned, the source need not be)
@@ -205,6 +183,17 @@ struct Context {
     uint8_t *h_stage_ring[RING] = {}, *h_stage_ring_dev[RING] = {};
     size_t stage_ring_bytes = 0;
     long long async_frames = 0;
+    // A stereo frame handed to lvt_amd_track_async is HELD until the next one arrives (or somebody waits for it): the held frame's k_cells launch then carries
+    // the workgroups that pull the NEXT frame's images (k_features.hip, NextPull), and a frame whose images came that way starts without a pull of its own.
+    struct PendingFrame {
+        bool valid = false, pulled = false;
+        FrameArgs f{};
+        const uint8_t *src[2] = {nullptr, nullptr};
+        uint8_t *dst[2] = {nullptr, nullptr};
+    } pend;
+    NextPull next_pull{};   // what this enqueue_frame's k_cells pulls (src[0] == nullptr: nothing)
+    bool fuse_pull = true;  // LVT_AMD_FUSED_PULL=0: every frame pulls its own images at the head of its feature stage
+    long long fused_pulls = 0;
     float *d_ext[NPAR][2] = {};
     int pitch = 0;
     long enq = 0, done = 0;    // frames enqueued / collected
@@ -517,6 +506,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
             if (!prm.big_cell_strips && prm.n_cells * 2 * B > n_cu) c->cells_raw_cap = RAW_CAP_SMALL;
         }
         if (const char *e = std::getenv("LVT_AMD_CELLS_RAW_CAP")) c->cells_raw_cap = std::max(RAW_CAP_SMALL, std::min(RAW_CAP, std::atoi(e) & ~1));
+        if (const char *e = std::getenv("LVT_AMD_FUSED_PULL")) c->fuse_pull = std::atoi(e) != 0;
         if (const char *e = std::getenv("LVT_AMD_LISTS_WGS")) {
             int r = 0, m = 0;
             const int got = std::sscanf(e, "%d,%d", &r, &m);
@@ -723,7 +713,9 @@ static void enqueue_frame(Context *c) {
     if (!ext) {
         {
             const int pass = 0;  // (the <200-corner retry pass runs inside k_gather: it is almost never taken)
-            LAUNCH_S(3, sf, k_cells, (B == 1 ? dim3(p.n_cells, 2, 1) : dim3(p.n_cells * 2 * Bz, 1, 1)), dim3(1024), cells_lds_bytes(c->cells_raw_cap), pass, par, c->cell_order, 2 * Bz, c->cells_raw_cap);
+            // (a single sequence: + the workgroups that pull the next asynchronous host frame, one 16-byte vector per thread)
+            const int pull_wgs = (B == 1 && c->next_pull.src[0]) ? std::min(64, (int)(((size_t)p.W * p.H / 16 + 1023) / 1024)) : 0;
+            LAUNCH_S(3, sf, k_cells, (B == 1 ? dim3(p.n_cells + pull_wgs, 2, 1) : dim3(p.n_cells * 2 * Bz, 1, 1)), dim3(1024), cells_lds_bytes(c->cells_raw_cap), pass, par, c->cell_order, 2 * Bz, c->cells_raw_cap, c->next_pull);
             if (p.big_cell_strips) {  // oversized cells: NMS as row strips on several CUs, then ANMS of the merged survivors in three launches
                 hipLaunchKernelGGL(k_cells_strip, dim3(p.n_cells * STRIPS, 2, Bz), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
                 hipLaunchKernelGGL(k_cells_big, dim3(p.n_cells, 2, Bz), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
@@ -893,7 +885,19 @@ static void collect_oldest(Context *c) {
         }
     }
 }
+// the held asynchronous host frame (Context::pend) enters the launch chain; np: the images its k_cells launch pulls for the frame behind it
+static void flush_pending(Context *c, const NextPull *np = nullptr) {
+    if (!c->pend.valid) return;
+    Context::PendingFrame &q = c->pend;
+    q.valid = false;
+    if (!q.pulled) hipLaunchKernelGGL(k_stage_in, dim3(128, 2), dim3(256), 0, c->stream_f, q.src[0], q.src[1], q.dst[0], q.dst[1], c->prm.W, c->prm.H, c->pitch);
+    c->h_fargs[(size_t)(c->enq % RING) * c->B] = q.f;
+    if (np) c->next_pull = *np, c->fused_pulls++;
+    enqueue_frame(c);
+    c->next_pull = NextPull{};
+}
 static void drain(Context *c) {
+    flush_pending(c);
     while (c->done < c->enq) collect_oldest(c);
     c->early_pending = false;
 }
@@ -932,6 +936,7 @@ static bool wait_pose_or_frame(Context *c, double R[3][3], double t[3]) {
     return false;
 }
 static void make_room(Context *c) {  // at most RING-1 frames un-collected before a new one is enqueued
+    flush_pending(c);
     while (c->enq - c->done >= RING - 1) collect_oldest(c);
 }
 static const Ctl &last_ctl(Context *c, int s = 0) { return c->h_ctl[(size_t)c->last_slot * c->B + s]; }
@@ -1141,8 +1146,8 @@ LVT_API void lvt_amd_get_host_stats(lvt_handle h, long long out[8]) {
         out[0] = S->submitted, out[1] = S->pool->steps, out[2] = S->pool->slot_frames, out[3] = S->pool->live, out[7] = 2;
         return;
     }
-    out[0] = (long long)c->enq, out[1] = (long long)c->done, out[2] = c->planes_in_place, out[3] = c->planes_staged;
-    out[4] = c->async_frames, out[5] = 0, out[6] = c->score_pieces, out[7] = c->events_only ? 1 : 0;
+    out[0] = (long long)c->enq + (c->pend.valid ? 1 : 0), out[1] = (long long)c->done, out[2] = c->planes_in_place, out[3] = c->planes_staged;
+    out[4] = c->async_frames, out[5] = c->fused_pulls, out[6] = c->score_pieces, out[7] = c->events_only ? 1 : 0;
 }
 
 LVT_API void lvt_amd_profile_enable(lvt_handle h, int enable) {
@@ -1279,6 +1284,7 @@ LVT_API void lvt_amd_wait(lvt_handle h, double R[3][3], double t[3]) {
     DeviceGuard guard(c);
     try {
         if (c->early_pending) drain(c);
+        if (c->enq - c->done <= 1) flush_pending(c);  // (a held host frame: kept back only while the device has other frames to work on)
         if (c->done < c->enq) collect_oldest(c);  // FIFO: the oldest frame not yet collected
         result_out(c, 0, R, t);
     } catch (...) {
@@ -1300,6 +1306,7 @@ LVT_API int lvt_amd_wait_status(lvt_handle h, double R[3][3], double t[3]) {  //
     DeviceGuard guard(c);
     try {
         if (c->early_pending) drain(c);
+        if (c->enq - c->done <= 1) flush_pending(c);
         if (c->done < c->enq) collect_oldest(c);
         result_out(c, 0, R, t);
         return last_ctl(c).state;
@@ -1443,8 +1450,10 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
 // Asynchronous counterpart of upload_and_track (lvt_amd_track_async / lvt_amd_track_rgbd_async): borrowed HOST images, the frame is enqueued and the
 // call returns; the pose comes out of the same FIFO as lvt_amd_track_device_async's (lvt_amd_wait / lvt_amd_wait_status).  Pageable buffers are copied
 // into this slot's pinned staging buffer during the call; page-locked ones are pulled where they lie (and must stay valid until the frame is collected).
-// The pull kernel heads the frame's feature stage: with several frames in flight the images of frame t + 1 cross PCIe while the tracking chain of frame t
-// runs (SURVEY 8e "pinned H2D staging double-buffered").
+// Stereo: the frame is HELD (Context::pend) until the next one arrives -- its k_cells launch then carries the workgroups that pull that next frame's
+// images (24 us of PCIe reads beside 66 us of corner cells: on no stream's chain; SURVEY 8e "pinned H2D staging double-buffered") -- or until
+// lvt_amd_wait* finds the device about to run dry / any other entry point needs the launch chain.  A frame nobody pulled for pulls its own images at the
+// head of its feature stage (k_stage_in), as every RGB-D frame does.
 // Returns 0 when the frame was enqueued, -1 when it was rejected (nothing enqueued; lvt_amd_last_error says why).
 static int upload_async(Context *c, const unsigned char *left, const void *second, bool rgbd, int n_rows, int n_cols) {
     if (c->B != 1 || (rgbd ? c->sensor != 2 : c->sensor != 1)) {
@@ -1456,8 +1465,10 @@ static int upload_async(Context *c, const unsigned char *left, const void *secon
         return -1;
     }
     if (c->early_pending) drain(c);
-    make_room(c);
-    const int slot = (int)(c->enq % RING);
+    if (rgbd) flush_pending(c);
+    const int held = c->pend.valid ? 1 : 0;  // (the held frame owns slot enq % RING)
+    while (c->enq + held - c->done >= RING - 1) collect_oldest(c);
+    const int slot = (int)((c->enq + held) % RING);
     const size_t nbytes = (size_t)n_rows * n_cols, plane = (size_t)c->pitch * c->prm.H;
     if (!c->d_img_ring[0][0]) {  // first asynchronous host-buffer call
         for (int r = 0; r < RING; r++) {
@@ -1484,18 +1495,29 @@ static int upload_async(Context *c, const unsigned char *left, const void *secon
     hipStream_t sp = c->stream_f;
     uint8_t *d0 = c->d_img_ring[slot][0], *d1 = c->d_img_ring[slot][1];
     if (!rgbd) {
-        const bool split = !s0 && !s1;  // two pageable images: the left one crosses PCIe while the CPU copies the right one
         if (!s0) {
             std::memcpy(c->h_stage_ring[slot], left, nbytes);
             s0 = c->h_stage_ring_dev[slot];
         }
-        if (split) hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sp, s0, s0, d0, d0, n_cols, n_rows, c->pitch);
         if (!s1) {
             std::memcpy(c->h_stage_ring[slot] + img_b, second, nbytes);
             s1 = c->h_stage_ring_dev[slot] + img_b;
         }
-        if (split) hipLaunchKernelGGL(k_stage_in, dim3(128, 1), dim3(256), 0, sp, s1, s1, d1, d1, n_cols, n_rows, c->pitch);
-        else hipLaunchKernelGGL(k_stage_in, dim3(128, 2), dim3(256), 0, sp, s0, s1, d0, d1, n_cols, n_rows, c->pitch);
+        // the frame held so far goes out now, and its k_cells launch pulls THIS frame's images beside its cells
+        const bool carried = c->pend.valid && c->fuse_pull;
+        if (c->pend.valid) {
+            const NextPull np{{s0, s1}, {d0, d1}, n_cols, n_rows, c->pitch};
+            flush_pending(c, carried ? &np : nullptr);
+        }
+        Context::PendingFrame &q = c->pend;
+        q.valid = true, q.pulled = carried;
+        q.src[0] = s0, q.src[1] = s1, q.dst[0] = d0, q.dst[1] = d1;
+        q.f = FrameArgs{};
+        q.f.img[0] = d0, q.f.img[1] = d1;
+        q.f.img_pitch = c->pitch;
+        c->async_frames++;
+        if (!c->fuse_pull) flush_pending(c);
+        return 0;
     } else {
         if (!s0) {
             std::memcpy(c->h_stage_ring[slot], left, nbytes);

@@ -287,7 +287,7 @@ def _pinned(a):
 
 
 def test_async_host_path_equals_the_oracle(hip_lib, oracle_lib):
-    """lvt_amd_track_async: borrowed HOST images (lvt_c.cpp:64-89), frames enqueued four deep, the pull of frame t + 1 on its own stream beside
+    """lvt_amd_track_async: borrowed HOST images (lvt_c.cpp:64-89), frames enqueued four deep, the pull of frame t + 1 carried by the corner-cell launch of frame t, beside
     the kernels of frame t.  Held to the ORACLE (not to the synchronous HIP path) over 210 full-size frames (1241 x 376 = 8 mod 16 bytes per
     image): every pose within 1e-4, the state after every frame, and the complete frame diff at the end.  Page-locked buffers (read in place)
     and pageable ones (copied into the staging ring) alternate in blocks; a wrong-size frame arrives mid-flight and must be rejected without
@@ -328,6 +328,8 @@ def test_async_host_path_equals_the_oracle(hip_lib, oracle_lib):
     assert not msgs, msgs[:6]
     hs = hip.host_stats()
     assert hs["async_host_frames"] == n and hs["planes_in_place"] > 0 and hs["planes_staged"] > 0, hs
+    # frames that arrived while their predecessor was still held had their images pulled by that frame's corner-cell launch; the others pulled their own
+    assert 0 < hs["pulls_carried_by_the_previous_frame"] < n, hs
     assert hip.get_state() == 2
 
 

@@ -662,7 +662,10 @@ constexpr uint32_t PERM = 0xFFFFFFFFu;
 
 template <class NFn>
 __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint32_t *cand, ResolveLds &L, uint32_t &iter, float ratio,
-                                             float desc_th, int acc[2], int nq[2] = nullptr, const uint32_t *qidx = nullptr, int qid[2] = nullptr) {
+                                             float desc_th, int acc[2], int nq[2] = nullptr, const uint32_t *qidx = nullptr, int qid[2] = nullptr,
+                                             bool no_marks = false) {
+    // no_marks (block-uniform): no feature carries a permanent mark yet -- the first super-chunk of a call that starts from cleared marks -- so the
+    // packing below has nothing to drop and skips its 32 table look-ups per query (they were half of the packing's time)
     // qidx != nullptr: b0 / M / the return value count entries of the COMPACTED query list qidx[] (query | candidate count << 24, in
     // query order -- the greedy scan only ever decides queries that have candidates, and their relative order is all it depends on)
     const int tid = threadIdx.x;
@@ -726,6 +729,13 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
             uint4 v[8];
 #pragma unroll
             for (int k = 0; k < 8; k++) v[k] = (e0 + 4 * k < n[u]) ? src[(e0 >> 2) + k] : make_uint4(0, 0, 0, 0);
+            if (no_marks) {
+#pragma unroll
+                for (int k = 0; k < 8; k++)
+                    if (e0 + 4 * k < n[u]) *reinterpret_cast<uint4 *>(dst + e0 + 4 * k) = v[k];  // (list starts are 16-byte aligned; the padding is never evaluated)
+                w = n[u];
+                continue;
+            }
             uint32_t mk[32];
 #pragma unroll
             for (int k = 0; k < 8; k++) {
@@ -767,6 +777,7 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
             const int lq = tid + u * RES_THREADS;
             if (n[u] == 0 || lq < fin) continue;
             const uint32_t *list = L.lists + off[u];
+            const uint32_t mine = ((iter - 1u) << 11) | (uint32_t)(2047 - lq);
             uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
             int cnt = 0;
             // 4 candidates per step: the 4 list reads and then the 4 claim reads are independent, so their LDS latencies
@@ -781,8 +792,10 @@ __device__ __forceinline__ int resolve_super(int b0, int M, NFn nfn, const uint3
                 for (int k = 0; k < 4; k++) v[k] = rd[c[k] & (uint32_t)(NF_MAX - 1)];  // valid indices are < NF_MAX; padding stays in range
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    // unavailable: marked (PERM), or accepted in iteration iter-1 by an earlier query
-                    const bool un = (v[k] == PERM) || ((v[k] >> 11) == iter - 1u && (int)(2047u - (v[k] & 2047u)) < lq);
+                    // unavailable: marked (PERM), or accepted in iteration iter-1 by an earlier query.  ONE comparison: a claim of iteration
+                    // iter-1 by query q' reads (iter-1) << 11 | 2047 - q', which exceeds `mine` exactly for q' < lq; claims left over from older
+                    // iterations are below (iter-1) << 11, PERM is the largest word there is
+                    const bool un = v[k] > mine;
                     if (e + k < n[u] && !un && cnt < 2) {
                         if (cnt == 0) k1 = c[k];
                         else k2 = c[k];
@@ -914,7 +927,8 @@ __device__ __forceinline__ void resolve_body(const Seq &S, Ctl &ctl, int pass2, 
     for (; b0 < M;) {
         int acc[2], nq[2] = {0, 0}, qid[2];
         const uint8_t *lflag = S.fb[par].feat[0].flag;
-        const int used = resolve_super(b0, M, [&](int q) { return (MODE == MODE_ROW && lflag[q]) ? 0 : ncand[q]; }, cand, L, iter, ratio, desc_th, acc, nq, qidx, qid);
+        const int used = resolve_super(b0, M, [&](int q) { return (MODE == MODE_ROW && lflag[q]) ? 0 : ncand[q]; }, cand, L, iter, ratio, desc_th, acc, nq, qidx, qid,
+                                       /* no_marks = */ phase != 2 && iter == 0);
         if (used < 0) st_slow++;
         else if (tid == 0) st_chunks++, st_iter += L.misc[4], st_itmax = max(st_itmax, L.misc[4]), st_fix += L.misc[5], st_cs += L.misc[6], st_pack += L.misc[7];
         if (used < 0) {  // query b0 overflowed KC: exact scan of all train features by wavefront 0

@@ -194,6 +194,7 @@ struct Context {
     NextPull next_pull{};   // what this enqueue_frame's k_cells pulls (src[0] == nullptr: nothing)
     bool fuse_pull = true;  // LVT_AMD_FUSED_PULL=0: every frame pulls its own images at the head of its feature stage
     long long fused_pulls = 0;
+    int feature_cus = 0;    // CUs the feature stream is confined to (0: all; lock-step batches, see create_context)
     float *d_ext[NPAR][2] = {};
     int pitch = 0;
     long enq = 0, done = 0;    // frames enqueued / collected
@@ -455,7 +456,27 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         c->sensor = sensor;
         c->prm = prm;
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
-        HIPCHK(c, hipStreamCreateWithFlags(&c->stream_f, hipStreamNonBlocking));
+        {   // A lock-step batch's feature stream is confined to 7/8 of the device's CUs.  k_cells' workgroups (80 KB of LDS each, two per CU, 50 - 90 us)
+            // otherwise hold EVERY CU's LDS while they run, and the single-workgroup kernels of the tracking / early chains (50 - 135 KB) -- whose loop
+            // pnp -> early map -> match -> resolve -> pnp is a batch's period up to ~28 sequences -- queue behind them (k_track_mid: 36 us in the
+            // pipeline, 12 alone).  Measured, frames/s with all CUs -> with 224 of 256: 8 sequences 43.5k -> 45.7k, 16: 70.1k -> 74.9k, 24: 82.4k -> 86.6k;
+            // 32 sequences are bound by the feature stream itself (k_score is VALU-bound) and lose: 92.6k -> 88.6k, so larger batches keep every CU.
+            // LVT_AMD_FEATURE_CUS=n overrides (0: all CUs).  (A CU-masked stream cannot be created non-blocking: it synchronises with the NULL
+            // stream like any default-flag stream -- this library never uses the NULL stream.)
+            int ncu = 0;
+            if (B >= 2 && B <= 28) {
+                int total = 0;
+                if (hipDeviceGetAttribute(&total, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && total >= 64) ncu = total / 8 * 7;
+            }
+            if (const char *e = std::getenv("LVT_AMD_FEATURE_CUS")) ncu = (B >= 2) ? std::atoi(e) : 0;
+            if (ncu > 0 && ncu < 1024) {
+                uint32_t mask[32] = {};
+                for (int i = 0; i < ncu; i++) mask[i >> 5] |= 1u << (i & 31);
+                HIPCHK(c, hipExtStreamCreateWithCUMask(&c->stream_f, 32, mask));
+                c->feature_cus = ncu;
+            } else
+                HIPCHK(c, hipStreamCreateWithFlags(&c->stream_f, hipStreamNonBlocking));
+        }
         HIPCHK(c, hipStreamCreateWithFlags(&c->stream_e, hipStreamNonBlocking));
         c->own_stream = true;
         for (auto &e : c->ev_done) HIPCHK(c, hipEventCreateWithFlags(&e, hipEventDisableTiming));

@@ -1301,28 +1301,6 @@ __global__ __launch_bounds__(64) void k_gate_late(SeqArg<BV> sa, int par, seq_t 
 // =================================================================================================
 // k_pnp : motion-only bundle adjustment, one 256-thread workgroup per sequence
 // =================================================================================================
-// SBACam derived matrices from the rotation quaternion r and position t; every thread keeps its
-// own copy in registers, thread 0 only publishes (r, t) through LDS after each update.
-struct CamRegs {
-    double w2n[12], w2i[12];
-};
-__device__ __forceinline__ void cam_refresh(CamRegs &c, const double r[4], const double t[3], double fx, double fy, double cx, double cy) {
-    double R[9];
-    q_to_R(r, R);
-#pragma unroll
-    for (int i = 0; i < 3; i++) {
-#pragma unroll
-        for (int j = 0; j < 3; j++) c.w2n[4 * i + j] = R[3 * j + i];
-    }
-#pragma unroll
-    for (int i = 0; i < 3; i++) c.w2n[4 * i + 3] = -(c.w2n[4 * i] * t[0] + c.w2n[4 * i + 1] * t[1] + c.w2n[4 * i + 2] * t[2]);
-#pragma unroll
-    for (int j = 0; j < 4; j++) {
-        c.w2i[j] = fx * c.w2n[j] + cx * c.w2n[8 + j];
-        c.w2i[4 + j] = fy * c.w2n[4 + j] + cy * c.w2n[8 + j];
-        c.w2i[8 + j] = c.w2n[8 + j];
-    }
-}
 // 1 / sqrt(s) for s > 0 in the normal range: hardware seed (v_rsq_f64, ~26 bits) + two Newton steps in fma form.
 // One dependency chain of ~10 instructions where sqrt followed by a division costs ~45 -- thread 0 runs the pose solve
 // alone, so these chains ARE its time.  The result is within 1 ulp of the correctly rounded value.
@@ -1369,35 +1347,54 @@ __device__ __forceinline__ double rsqrt_nr(double s) {
     return y;
 }
 
-__device__ bool solve6_spd(const double *H /*6x6*/, const double *b, double *x) {
-    // Cholesky (Eigen LLT as used by g2o's dense linear solver) in the form that never needs L_jj itself: every use of the
-    // pivot is a division by it, so the column keeps inv_j = 1 / sqrt(s_j) (column scaling and both substitutions multiply
-    // by it).  Each quotient differs from the divide-by-sqrt form by at most a rounding or two; see DESIGN.md section 5.
-    double L[36], inv[6];
-    for (int i = 0; i < 36; i++) L[i] = 0;
-    for (int j = 0; j < 6; j++) {
-        double s = H[6 * j + j];
-        for (int k = 0; k < j; k++) s -= L[6 * j + k] * L[6 * j + k];
-        if (!(s > 0) || !isfinite(s)) return false;
-        inv[j] = rsqrt_nr(s);
-        for (int i = j + 1; i < 6; i++) {
-            double v = H[6 * i + j];
-            for (int k = 0; k < j; k++) v -= L[6 * i + k] * L[6 * j + k];
-            L[6 * i + j] = v * inv[j];
+// (H + lambda I) x = b for the 6x6 system packed in `sys` (upper triangle row-major in [0, 21), b in [21, 27)) -- the role of g2o's dense solve
+// behind LinearSolverPCG with the exact block-Jacobi preconditioner (A.6).  Thread 0 runs this alone, one wavefront on its SIMD: a dependent fp64
+// operation costs its full latency here (32 cycles, profiles/r04_fp64_issue_rate.txt), so the routine is written for the LENGTH OF THE DEPENDENCY
+// CHAIN: a right-looking LDL^T (no square root: the pivot's reciprocal is a seed + two Newton steps, 5 dependent operations where 1 / sqrt needs 7),
+// fused multiply-adds, the forward substitution folded into the elimination, the back substitution adding its newest term last: ~50 dependent
+// operations where the Cholesky form of rounds 1-3 had ~85 (2.5k -> 1.6k cycles per solve).  Same pivots as Cholesky (d_j = the square of L_jj):
+// "not positive definite" is detected on the same quantity; the solution differs from the LL^T form by roundings.
+__device__ __forceinline__ bool solve6_ldl(const double *sys, double lambda, double *x) {
+    double A[6][6], z[6], inv[6];
+    {
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+#pragma unroll
+            for (int cc = a; cc < 6; cc++) A[cc][a] = sys[k++];
         }
     }
-    double y[6];
-    for (int i = 0; i < 6; i++) {
-        double v = b[i];
-        for (int k = 0; k < i; k++) v -= L[6 * i + k] * y[k];
-        y[i] = v * inv[i];
+#pragma unroll
+    for (int a = 0; a < 6; a++) A[a][a] += lambda, z[a] = sys[21 + a];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const double d = A[j][j];
+        ok = ok && (d > 0) && isfinite(d);
+        inv[j] = rcp_nr(d);
+        double cj[6], lj[6];
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) cj[i] = A[i][j], lj[i] = cj[i] * inv[j];
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+#pragma unroll
+            for (int k2 = j + 1; k2 <= i; k2++) A[i][k2] = __builtin_fma(-lj[i], cj[k2], A[i][k2]);
+            z[i] = __builtin_fma(-lj[i], z[j], z[i]);
+            A[i][j] = lj[i];
+        }
     }
+#pragma unroll
     for (int i = 5; i >= 0; i--) {
-        double v = y[i];
-        for (int k = i + 1; k < 6; k++) v -= L[6 * k + i] * x[k];
-        x[i] = v * inv[i];
+        double v = z[i] * inv[i];
+#pragma unroll
+        for (int k2 = 5; k2 > i; k2--) v = __builtin_fma(-A[k2][i], x[k2], v);
+        x[i] = v;
     }
-    return true;
+    if (!ok) {
+#pragma unroll
+        for (int i = 0; i < 6; i++) x[i] = 0.0;  // the failed solve of the reference leaves the step at zero
+    }
+    return ok;
 }
 
 __device__ __forceinline__ double wave_sum(double v) {
@@ -1405,58 +1402,57 @@ __device__ __forceinline__ double wave_sum(double v) {
     return v;
 }
 
-constexpr int PNP_THREADS = 256;
-constexpr int PNP_ILP = 3;  // edges per thread in flight in one sweep iteration (KITTI: ~650 edges = one iteration)
+constexpr int PNP_THREADS = 256;  // one wavefront per SIMD.  More wavefronts were measured (768 threads, one edge each instead of three interleaved:
+                                   // sweep + reduction 4.7k -> 6.6k cycles): a single wavefront with three independent chains already issues an fp64
+                                   // instruction every ~4.5 cycles (profiles/r04_fp64_issue_rate.txt), more of them only add barrier and reduction time
+constexpr int PNP_ILP = 3;         // edges per thread in flight in one sweep iteration (KITTI: ~650 edges = one iteration)
+constexpr int PNP_NW = PNP_THREADS / 64;
+static_assert(PNP_NW == 4, "block_sum's tree is written for four wavefronts");
+constexpr int PNP_RED = 16 + PNP_NW * 32 + 2;  // small sums [0, 4) | reduce-scatter partials [16, 16 + 4 * 32) | the inactive edges' sink (2)
+
+__device__ __forceinline__ double tree4(const double *p, int stride) { return (p[0] + p[stride]) + (p[2 * stride] + p[3 * stride]); }  // fixed order: deterministic
 
 // block-wide sum of NV doubles per thread.  NV < 8: result in v[] of every thread.  NV >= 8: result in dst[0..NV-1] (LDS).
 // Large NV: every wavefront reduce-scatters its NV values in registers (wave_reduce.h: 29 additions and their lane exchanges for 28 values, the lane
-// pair (l, l ^ 1) ends with the total of value wave_rs_index(l)), 32 lanes per wavefront put them into LDS, thread k adds the four wavefronts' totals of value k.
-// Two barriers and 1 KB through LDS (round 3's form -- every thread's 28 partials through LDS, transposed, 57 KB each way, three barriers -- took ~2 000
-// cycles of the ~4 000 a sweep takes).  red[128, 256) only: block_sum<1> (red[0, 4)) may still be read by a slow wavefront when this one is entered.
-constexpr int PNP_NW = PNP_THREADS / 64;
+// pair (l, l ^ 1) ends with the total of value wave_rs_index(l)), 32 lanes per wavefront put them into LDS, thread k adds the wavefronts' totals of
+// value k.  A wavefront without an edge (`wave_active` false: its values are zero) stores zeros and skips the exchange.
+// Two barriers.  red[16, ...) only: block_sum<1> (red[0, 4)) may still be read by a slow wavefront when this one is entered.
 template <int NV>
-__device__ __forceinline__ void block_sum(double (&v)[NV], double *red, double *dst = nullptr) {
+__device__ __forceinline__ void block_sum(double (&v)[NV], double *red, double *dst = nullptr, bool wave_active = true) {
     const int w = wave_id(), l = lane_id(), tid = threadIdx.x;
-    if (NV >= 8) {
+    if constexpr (NV >= 8) {
         static_assert(NV <= 32, "block_sum: one reduce-scatter");
-        double *part = red + 128;  // [PNP_NW][32]
-        const double s = wave_reduce_scatter<NV>(v);
-        if (!(l & 1)) part[w * 32 + wave_rs_index(l)] = s;
+        double *part = red + 16;  // [PNP_NW][32]
+        if (wave_active) {
+            const double s = wave_reduce_scatter<NV>(v);
+            if (!(l & 1)) part[w * 32 + wave_rs_index(l)] = s;
+        } else if (l < 32)
+            part[w * 32 + l] = 0.0;
         __syncthreads();
-        if (tid < NV) {
-            double t = part[tid];
-#pragma unroll
-            for (int m = 1; m < PNP_NW; m++) t += part[m * 32 + tid];
-            dst[tid] = t;  // v[] is NOT updated (only thread 0 wants the sums)
-        }
+        if (tid < NV) dst[tid] = tree4(part + tid, 32);  // v[] is NOT updated (only thread 0 wants the sums)
         __syncthreads();
     } else {
 #pragma unroll
         for (int k = 0; k < NV; k++) v[k] = wave_sum(v[k]);
         __syncthreads();
-        if (l == 0) {
-#pragma unroll
-            for (int k = 0; k < NV; k++) red[w * NV + k] = v[k];
-        }
+        static_assert(NV == 1, "block_sum: the small form carries one value");
+        if (l == 0) red[w] = v[0];
         __syncthreads();
-#pragma unroll
-        for (int k = 0; k < NV; k++) {
-            double s = 0.0;
-#pragma unroll
-            for (int m = 0; m < PNP_NW; m++) s += red[m * NV + k];
-            v[k] = s;
-        }
+        v[0] = tree4(red, 1);
     }
 }
 
 // State of the solve.  Everything only thread 0 computes with lives HERE, not in registers: a 6x6 system, its
 // right-hand side and the step would otherwise sit in ~110 VGPRs of every lane across the sweeps.
 struct PnpShared {
-    double r[4], t[3];    // current estimate, published by thread 0
+    double r[4], t[3];    // current estimate (during a trial: the trial's), published by thread 0
     double br[4], bt[3];  // push(): the estimate before the trial
+    double cam[2][16];    // world -> normalised camera (3x4, SBACam's w2n) + position [12, 15) of two estimates: [camcur] the current one, [camcur ^ 1] a trial's
+    int camcur;
     double sys[2][28];    // H (upper triangle), b, chi2: [cur] at the current estimate, [cur ^ 1] receives a trial's
     int cur;
     double dx[6];
+    double inv_scale;     // 1 / (dx . (lambda dx + b) + 1e-3): known with the step, so it is formed beside the pose update instead of behind the sweep
     double lambda, ni;
     int cont, ok, accepted, ok2;
     // LM bookkeeping for the tests (the oracle counts the same): trials, rejected trials, passes ended by Terminate; and, stand-alone entry only,
@@ -1465,21 +1461,36 @@ struct PnpShared {
     double *trace;
 };
 
-// One sweep over the active edges at the camera `cam`: errors (stored), robust chi2 partial in acc[27], and -- when
+// thread 0: the matrices every lane's sweep needs from (r, t) -- SBACam's w2n = [R^T | -R^T t] in cam_refresh's operation order -- go to LDS once
+// instead of being recomputed by every wavefront
+__device__ __forceinline__ void publish_cam(double *dst, const double r[4], const double t[3]) {
+    double R[9];
+    q_to_R(r, R);
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const double a = R[i], b = R[3 + i], c = R[6 + i];
+        dst[4 * i] = a, dst[4 * i + 1] = b, dst[4 * i + 2] = c;
+        dst[4 * i + 3] = -(a * t[0] + b * t[1] + c * t[2]);
+    }
+    dst[12] = t[0], dst[13] = t[1], dst[14] = t[2];
+}
+
+// One sweep over the active edges at the camera w2n / position ct: errors (stored), robust chi2 partial in acc[27], and -- when
 // WANT_H -- the edge's contribution to H (upper triangle, acc[0..20]) and b (acc[21..26]) linearised at the same
 // estimate (EdgeProjectP2MC::computeError / linearizeOplus / constructQuadraticForm with the Cauchy weight, A.6).
+// Returns whether this wavefront had an edge at all.
 template <bool WANT_H>
-__device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3], double fx, double fy, double cx, double cy, double dsqr, double dsqrReci,
+__device__ __forceinline__ bool pnp_sweep(const double (&w)[12], const double ct[3], double fx, double fy, double cx, double cy, double dsqr, double dsqrReci,
                                           const double *__restrict__ X, const float *__restrict__ obs, double *__restrict__ err,
                                           double *__restrict__ sink, const int8_t *__restrict__ level, int n, double (&acc)[28]) {
 #pragma unroll
     for (int k = 0; k < 28; k++) acc[k] = 0.0;
+    const int wbase = __builtin_amdgcn_readfirstlane((int)(threadIdx.x & ~63u));
+    if (wbase >= n) return false;
     // One edge, straight-line: an inactive slot (past the end, or an edge of level 1) runs the same instructions on a
     // clamped index with its weights selected to zero, so the PNP_ILP edges of one iteration sit in one basic block
     // and their fp64 dependency chains interleave (there is one wavefront per SIMD: nothing else hides the latency).
-    // The sweep runs at the fp64 issue rate of a CU -- measured: v_mul_f64 / v_add_f64 issue in 4 cycles per wave64, v_fma_f64
-    // in 8, and the loop's cycle count is the sum of those whatever the order (a stage-interleaved version of the three edges
-    // ran at exactly the same speed) -- so it is written for operation count: the four IEEE divisions of an edge are
+    // The sweep runs at the fp64 issue rate of a CU, so it is written for operation count: the four IEEE divisions of an edge are
     // reciprocal seeds with two Newton steps, the pixel error is formed from the camera-frame point the Jacobian needs anyway,
     // the logarithm is specialised to arguments >= 1 (400 -> 223 instructions per edge).  Multiply-adds are fused where that
     // saves an instruction slot.  Every value is within a rounding or two of the form the oracle evaluates (deviations).
@@ -1491,14 +1502,12 @@ __device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3]
         const double x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2];
         // pixel = K * (normalised camera point): u = fx pcx / pcz + cx (w2i = K w2n, whose third row is w2n's), so the
         // error needs the camera-frame point only -- the same one the Jacobian is built from
-        const double *w = cam.w2n;
         const double pcx = ((w[0] * x + w[1] * y) + w[2] * z) + w[3];
         const double pcy = ((w[4] * x + w[5] * y) + w[6] * z) + w[7];
         const double pcz = ((w[8] * x + w[9] * y) + w[10] * z) + w[11];
         const double ipcz = rcp_nr(pcz);
         const double e0 = fx * (pcx * ipcz) + (cx - (double)obs[2 * i]), e1 = fy * (pcy * ipcz) + (cy - (double)obs[2 * i + 1]);
-        {  // an inactive slot stores into the sink: a conditional store would split the block and the three edges of an
-           // iteration would no longer interleave
+        {  // an inactive slot stores into the sink: no conditional store inside the block
             double *ep = active ? err + 2 * i : sink;
             ep[0] = e0;
             ep[1] = e1;
@@ -1549,11 +1558,11 @@ __device__ __forceinline__ void pnp_sweep(const CamRegs &cam, const double ct[3]
             for (int a = 0; a < 6; a++) acc[21 + a] = __builtin_fma(J0[a], wr0, __builtin_fma(J1[a], wr1, acc[21 + a]));
         }
     };
-    if (n <= 0) return;
     for (int i = threadIdx.x; i < n; i += PNP_ILP * PNP_THREADS) {
 #pragma unroll
         for (int u = 0; u < PNP_ILP; u++) edge(i + u * PNP_THREADS);
     }
+    return true;
 }
 
 // g2o's OptimizationAlgorithmLevenberg as configured by lvt_pnp_solver.cpp:44-53,60-128, one workgroup.
@@ -1570,33 +1579,31 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
     const double dsqr = mono_chi * mono_chi;
     const double dsqrReci = 1.0 / dsqr;
     if (tid == 0) {  // SE3Quat ctor: normalizeRotation()
-        double r[4];
+        double r[4], t[3];
         for (int k = 0; k < 4; k++) r[k] = prior.q[k];
         if (r[0] < 0)
             for (int k = 0; k < 4; k++) r[k] = -r[k];
         q_normalize(r);
         for (int k = 0; k < 4; k++) sh.r[k] = r[k];
-        for (int k = 0; k < 3; k++) sh.t[k] = prior.p[k];
+        for (int k = 0; k < 3; k++) sh.t[k] = t[k] = prior.p[k];
+        publish_cam(sh.cam[0], r, t);
+        sh.camcur = 0;
         sh.cur = 0;
         sh.trials = sh.rejections = sh.terminates = 0;
     }
     __syncthreads();
-    CamRegs cam;
-    double cr[4], ct[3];
-    auto load_cam = [&]() {
-        for (int k = 0; k < 4; k++) cr[k] = sh.r[k];
-        for (int k = 0; k < 3; k++) ct[k] = sh.t[k];
-        cam_refresh(cam, cr, ct, fx, fy, cx, cy);
+    double w2n[12], ct[3];
+    int sw_slot = 0;  // the slot of sh.cam the most recent sweep ran at = the estimate the stored edge errors belong to (after a rejected last trial
+                      // that is NOT the estimate the pass ends with: pop() restores the camera, the errors stay those of the trial)
+    auto load_cam = [&](int slot) {
+        const double *c = sh.cam[slot];
+#pragma unroll
+        for (int k = 0; k < 12; k++) w2n[k] = c[k];
+#pragma unroll
+        for (int k = 0; k < 3; k++) ct[k] = c[12 + k];
     };
-    load_cam();
+    load_cam(0);
     int calls = 0;
-    // the estimate of the most recent sweep = the one the stored edge errors belong to (after a rejected last trial that is NOT the
-    // estimate the pass ends with: pop() restores the camera, the errors stay those of the trial)
-    double swr[4], swt[3];
-    auto note_sweep_cam = [&]() {
-        for (int k = 0; k < 4; k++) swr[k] = cr[k];
-        for (int k = 0; k < 3; k++) swt[k] = ct[k];
-    };
     double n_border[1] = {0.0};
 
     for (int pass = 0; pass < 2; pass++) {
@@ -1611,9 +1618,9 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
             long long c0 = clock64();
             if (!have_sys) {
                 double acc[28];
-                pnp_sweep<true>(cam, ct, fx, fy, cx, cy, dsqr, dsqrReci, X, obs, err, sink, level, n, acc);
-                note_sweep_cam();
-                block_sum<28>(acc, red, sh.sys[sh.cur]);
+                const bool wa = pnp_sweep<true>(w2n, ct, fx, fy, cx, cy, dsqr, dsqrReci, X, obs, err, sink, level, n, acc);
+                sw_slot = sh.camcur;
+                block_sum<28>(acc, red, sh.sys[sh.cur], wa);
             }
             t_sweep += clock64() - c0;
             if (tid == 0 && iter == 0) {
@@ -1631,56 +1638,61 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
             bool cont;
             do {
                 long long c1 = clock64();
+                const int trial_slot = sh.camcur ^ 1;
                 if (tid == 0) {
-                    for (int k = 0; k < 4; k++) sh.br[k] = cr[k];  // push()
-                    for (int k = 0; k < 3; k++) sh.bt[k] = ct[k];
-                    double Hl[36], bb[6], dx[6];
+                    double cr[4], c0t[3];
+                    for (int k = 0; k < 4; k++) cr[k] = sh.r[k], sh.br[k] = cr[k];  // push()
+                    for (int k = 0; k < 3; k++) c0t[k] = sh.t[k], sh.bt[k] = c0t[k];
+                    double dx[6];
                     const double *sys = sh.sys[sh.cur];
-                    int k = 0;
-                    for (int a = 0; a < 6; a++)
-                        for (int cc = a; cc < 6; cc++) {
-                            Hl[6 * a + cc] = sys[k];
-                            Hl[6 * cc + a] = sys[k];
-                            k++;
-                        }
                     const double lambda = sh.lambda;
-                    for (int a = 0; a < 6; a++) Hl[7 * a] += lambda;
-                    for (int a = 0; a < 6; a++) bb[a] = sys[21 + a], dx[a] = 0;
-                    sh.ok2 = solve6_spd(Hl, bb, dx) ? 1 : 0;
+                    sh.ok2 = solve6_ldl(sys, lambda, dx) ? 1 : 0;
                     for (int a = 0; a < 6; a++) sh.dx[a] = dx[a];
+                    {   // the gain ratio's denominator (g2o: computeScale() + 1e-3) needs the step only: formed here, beside the pose update's chain,
+                        // as a reciprocal -- the decision behind the sweep is then one subtraction and one product
+                        const double s0 = dx[0] * (lambda * dx[0] + sys[21]), s1 = dx[1] * (lambda * dx[1] + sys[22]), s2 = dx[2] * (lambda * dx[2] + sys[23]);
+                        const double s3 = dx[3] * (lambda * dx[3] + sys[24]), s4 = dx[4] * (lambda * dx[4] + sys[25]), s5 = dx[5] * (lambda * dx[5] + sys[26]);
+                        double scale = 0;
+                        scale += s0, scale += s1, scale += s2, scale += s3, scale += s4, scale += s5;  // (the reference's order)
+                        scale += 1e-3;
+                        sh.inv_scale = rcp_nr(scale);
+                    }
                     // SBACam::update
                     double nt[3], qr[4], nr[4];
-                    for (int k2 = 0; k2 < 3; k2++) nt[k2] = ct[k2] + dx[k2];
+                    for (int k2 = 0; k2 < 3; k2++) nt[k2] = c0t[k2] + dx[k2];
                     qr[1] = dx[3], qr[2] = dx[4], qr[3] = dx[5];
                     qr[0] = sqrt(1.0 - (dx[3] * dx[3] + dx[4] * dx[4] + dx[5] * dx[5]));
                     q_mul(cr, qr, nr);
-                    {  // normalize(): one reciprocal square root instead of sqrt + four divisions
+                    {  // normalize(): the product of two unit quaternions has z = 1 + e with |e| ~ 1e-16, and 1 / sqrt(1 + e) = 1 - e / 2 + 3 e^2 / 8 to
+                       // the last bit for |e| < 1e-5 (three dependent operations); anything else takes the seed + Newton form
                         const double z = nr[0] * nr[0] + nr[1] * nr[1] + nr[2] * nr[2] + nr[3] * nr[3];
                         if (z > 0) {
-                            const double rn = rsqrt_nr(z);
+                            const double e = z - 1.0;
+                            const double rn = (fabs(e) < 1e-5) ? __builtin_fma(e, __builtin_fma(0.375, e, -0.5), 1.0) : rsqrt_nr(z);
                             nr[0] *= rn, nr[1] *= rn, nr[2] *= rn, nr[3] *= rn;
                         }
                     }
                     for (int k2 = 0; k2 < 4; k2++) sh.r[k2] = nr[k2];
                     for (int k2 = 0; k2 < 3; k2++) sh.t[k2] = nt[k2];
+                    publish_cam(sh.cam[trial_slot], nr, nt);
                 }
                 t_solve += clock64() - c1;
                 __syncthreads();
-                load_cam();
+                load_cam(trial_slot);
                 c1 = clock64();
                 double tempChi;
-                note_sweep_cam();
+                sw_slot = trial_slot;
                 {
                     double acc[28];
                     if (speculate) {
-                        pnp_sweep<true>(cam, ct, fx, fy, cx, cy, dsqr, dsqrReci, X, obs, err, sink, level, n, acc);
+                        const bool wa = pnp_sweep<true>(w2n, ct, fx, fy, cx, cy, dsqr, dsqrReci, X, obs, err, sink, level, n, acc);
                         const long long c2 = clock64();
-                        block_sum<28>(acc, red, sh.sys[sh.cur ^ 1]);  // the trial's system goes to the spare slot
+                        block_sum<28>(acc, red, sh.sys[sh.cur ^ 1], wa);  // the trial's system goes to the spare slot
                         t_red += clock64() - c2;
                         tempChi = sh.sys[sh.cur ^ 1][27];
                     } else {
-                        pnp_sweep<false>(cam, ct, fx, fy, cx, cy, dsqr, dsqrReci, X, obs, err, sink, level, n, acc);
-                        double ch[1] = {acc[27]};
+                        const bool wa = pnp_sweep<false>(w2n, ct, fx, fy, cx, cy, dsqr, dsqrReci, X, obs, err, sink, level, n, acc);
+                        double ch[1] = {wa ? acc[27] : 0.0};
                         block_sum<1>(ch, red);
                         tempChi = ch[0];
                     }
@@ -1692,11 +1704,7 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
                     const double *sys = sh.sys[sh.cur];
                     const double currentChi = sys[27];
                     double lambda = sh.lambda, ni = sh.ni;
-                    double rho = currentChi - tempChi;
-                    double scale = 0;
-                    for (int j = 0; j < 6; j++) scale += sh.dx[j] * (lambda * sh.dx[j] + sys[21 + j]);
-                    scale += 1e-3;
-                    rho /= scale;
+                    const double rho = (currentChi - tempChi) * sh.inv_scale;  // (g2o divides by the scale: within a rounding or two)
                     const bool accept = (rho > 0 && isfinite(tempChi));
                     if (sh.trace && sh.trials < sh.trace_cap) {
                         double *row = sh.trace + 4 * sh.trials;
@@ -1712,6 +1720,7 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
                         lambda *= scaleFactor;
                         ni = 2;
                         if (speculate) sh.cur ^= 1;  // the trial's system IS the system of the next solve()
+                        sh.camcur = trial_slot;      // ... and its camera the current one
                     } else {
                         lambda *= ni;
                         ni *= 2;
@@ -1728,11 +1737,11 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
                 }
                 t_dec += clock64() - c1;
                 __syncthreads();
-                if (!sh.accepted) load_cam();  // pop() restored the old estimate; an accepted trial's camera is already loaded
+                if (!sh.accepted) load_cam(trial_slot ^ 1);  // pop() restored the old estimate; an accepted trial's camera is already loaded
                 cont = sh.cont != 0;
                 ok = sh.ok != 0;
                 have_sys = speculate && (sh.accepted != 0);  // sh.sys = system at the (accepted) current estimate
-                __syncthreads();  // sh.cont / sh.r consumed before thread 0 publishes again
+                __syncthreads();  // sh.cont / sh.camcur consumed before thread 0 publishes again
             } while (cont);
         }
         // chi2 gate on the last computed errors (lvt_pnp_solver.cpp:109-116).  The sweep evaluates an edge's error with refined
@@ -1746,12 +1755,18 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
                 const double e2 = e0 * e0 + e1 * e1;
                 bool out = e2 > REPROJ_TH2;
                 if (fabs(e2 - REPROJ_TH2) < PNP_GATE_MARGIN) {
-                    CamRegs gc;  // (rare) the camera of the last sweep; cam_refresh forms w2i in the reference's order
-                    cam_refresh(gc, swr, swt, fx, fy, cx, cy);
+                    // (rare) the camera of the last sweep; w2i = K w2n formed in the reference's order (cam_refresh)
+                    const double *gw = sh.cam[sw_slot];
+                    double wi[12];
+                    for (int j = 0; j < 4; j++) {
+                        wi[j] = fx * gw[j] + cx * gw[8 + j];
+                        wi[4 + j] = fy * gw[4 + j] + cy * gw[8 + j];
+                        wi[8 + j] = gw[8 + j];
+                    }
                     const double x = X[3 * i], y = X[3 * i + 1], z = X[3 * i + 2];
-                    const double px = ((gc.w2i[0] * x + gc.w2i[1] * y) + gc.w2i[2] * z) + gc.w2i[3];
-                    const double py = ((gc.w2i[4] * x + gc.w2i[5] * y) + gc.w2i[6] * z) + gc.w2i[7];
-                    const double pz = ((gc.w2i[8] * x + gc.w2i[9] * y) + gc.w2i[10] * z) + gc.w2i[11];
+                    const double px = ((wi[0] * x + wi[1] * y) + wi[2] * z) + wi[3];
+                    const double py = ((wi[4] * x + wi[5] * y) + wi[6] * z) + wi[7];
+                    const double pz = ((wi[8] * x + wi[9] * y) + wi[10] * z) + wi[11];
                     const double r0 = px / pz - (double)obs[2 * i], r1 = py / pz - (double)obs[2 * i + 1];
                     out = (r0 * r0 + r1 * r1) > REPROJ_TH2;
                     n_border[0] += 1.0;
@@ -1768,8 +1783,8 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
     block_sum<1>(n_border, red);
     borderline = (int)n_border[0];
     solve_calls = calls;
-    for (int k = 0; k < 4; k++) result.q[k] = cr[k];
-    for (int k = 0; k < 3; k++) result.p[k] = ct[k];
+    for (int k = 0; k < 4; k++) result.q[k] = sh.r[k];
+    for (int k = 0; k < 3; k++) result.p[k] = sh.t[k];
     if (dbg && tid == 0) {
         dbg[12] = t_sweep, dbg[13] = t_red, dbg[14] = t_solve, dbg[15] = t_dec, dbg[16] = clock64() - t_all, dbg[17] = calls;
     }
@@ -1792,7 +1807,7 @@ __device__ __forceinline__ void pnp_solve(const Params &prm, const Pose &prior, 
         for (int i = threadIdx.x; i < 2 * n; i += PNP_THREADS) sObs[i] = obs[i];
         for (int i = threadIdx.x; i < n; i += PNP_THREADS) sLvl[i] = level[i];
         __syncthreads();
-        pnp_run(prm, prior, sX, sObs, sErr, red + 382, sLvl, n, sh, red, res, inliers, calls, borderline, dbg);  // red[382..383]: free (block_sum uses [0, 4) and [128, 256))
+        pnp_run(prm, prior, sX, sObs, sErr, red + PNP_RED - 2, sLvl, n, sh, red, res, inliers, calls, borderline, dbg);  // (the last two doubles of red: block_sum never touches them)
         for (int i = threadIdx.x; i < 2 * n; i += PNP_THREADS) err[i] = sErr[i];
         for (int i = threadIdx.x; i < n; i += PNP_THREADS) level[i] = sLvl[i];
     } else
@@ -1819,7 +1834,7 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(SeqArg<BV> sa, int par, seq
         return;
     }
     __shared__ PnpShared sh;
-    __shared__ double red[384];
+    __shared__ double red[PNP_RED];
     extern __shared__ __attribute__((aligned(16))) uint8_t pnp_dyn[];
     Pose res;
     int inliers, calls, borderline;
@@ -1859,7 +1874,7 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(SeqArg<BV> sa, int par, seq
 __global__ __launch_bounds__(PNP_THREADS) void k_pnp_standalone(Params prm, Pose prior, const double *X, const float *obs, double *err,
                                                                 int8_t *level, int n, Pose *out, int *info, double *trace, int trace_cap) {
     __shared__ PnpShared sh;
-    __shared__ double red[384];
+    __shared__ double red[PNP_RED];
     extern __shared__ __attribute__((aligned(16))) uint8_t pnp_dyn[];
     for (int i = threadIdx.x; i < n; i += PNP_THREADS) level[i] = 0;
     if (threadIdx.x == 0) sh.trace = trace, sh.trace_cap = trace_cap;

@@ -22,10 +22,19 @@ for i in range(n):
 torch.cuda.synchronize()
 vo = lvt_amd.LvtSystem.create(prm, 1)
 base, fs = frames.data_ptr(), 2 * H * pitch
+host = len(sys.argv) > 1 and sys.argv[1] == "host"   # frames in page-locked host memory through lvt_amd_track_async (the bench headline's entry)
+if host:
+    hf = torch.empty((n, 2, H, W), dtype=torch.uint8).pin_memory()
+    hf.copy_(frames[:, :, :, :W])
+    hbase, hfs = hf.data_ptr(), 2 * H * W
+    print("host frames (page-locked), lvt_amd_track_async")
 tl = []
 inflight = 0
 for i in range(n):
-    vo.track_device_async(base + i * fs, base + i * fs + H * pitch, H, W, pitch)
+    if host:
+        vo.track_async_ptr(hbase + i * hfs, hbase + i * hfs + H * W, H, W)
+    else:
+        vo.track_device_async(base + i * fs, base + i * fs + H * pitch, H, W, pitch)
     inflight += 1
     if inflight >= 4:
         vo.wait(); inflight -= 1

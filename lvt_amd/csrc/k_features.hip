@@ -1334,6 +1334,133 @@ __device__ __forceinline__ void cells_work(const Seq &S, const FrameBuf &FB, int
     cell_finish(FB, eye, cell, pass, n_out);
 }
 
+// ---- a single sequence's tall cells as TWO (or three) co-operating workgroups of the same launch --------------------------------------
+// k_cells is the longest kernel of the feature stage (66 us of one CU per cell) and half of it is AGAST's NMS, which can be cut by rows exactly as
+// for the oversized cells below (one survivor per 4-connected blob, decided by the blob's pixels alone): workgroup "strip s" gathers the raw corners of
+// its core rows + SPLIT_HALO rows on either side, runs the same cell_nms, vouches that no blob reaches from a core row to the outermost halo row, and
+// keeps the survivors of its core rows.  Strips 1.. ("helpers") put theirs into global memory and publish a count + this launch's token; strip 0
+// ("main") appends them behind its own -- strip order IS raster order -- and runs LVT's ANMS on the merged list as before.  A strip that cannot vouch
+// (or overflows) reports -1 and the main workgroup runs the whole cell alone, as before.
+// No deadlock: the helpers have the LOWER workgroup ids and the same id modulo 8 as their main workgroup (cells_entry), i.e. they sit in the same XCD's
+// dispatch order in front of it: when a main workgroup runs, its helpers are resident or done.  The wait is bounded all the same (2 ms -> whole cell alone).
+constexpr int STRIPS = 8;  // (row strips of an oversized cell, k_cells_strip below; the per-cell stride of Seq::strip_n)
+constexpr int SPLIT_HALO = 16, SPLIT_MIN_ROWS = 160, SPLIT_MAX = 3, SPLIT_KP_CAP = 2048;
+__device__ __forceinline__ void cells_work_split(const Seq &S, const FrameBuf &FB, int eye, int cell, int strip, int nsplit, unsigned token, const CellLds &L, int raw_cap) {
+    const int tid = threadIdx.x;
+    CellGeom g;
+    int cxi;
+    if (!cell_begin(S, FB, eye, cell, 0, g, cxi)) return;
+    const int cs = S.prm.cell_size;
+    const bool splittable = g.cw >= 7 && g.ch >= SPLIT_MIN_ROWS && g.cw <= 1024 && g.ch <= 1024 && cs >= TS_W && !S.prm.big_cell_strips;
+    if (!splittable) {
+        if (strip == 0) cells_work(S, FB, eye, cell, 0, L, raw_cap);
+        return;
+    }
+    long long *dbg = (cell == 0 && eye == 0 && strip == 0) ? S.ctl->dbg : nullptr;
+    if (dbg && tid == 0) dbg[0] = clock64();
+    int *cnt_all = S.strip_n[eye] + cell * STRIPS;          // [1, nsplit): the helpers' counts; [4 + s]: their tokens
+    const int per = (g.ch - 6 + nsplit - 1) / nsplit;
+    const int c0 = 3 + strip * per, c1 = min(c0 + per, g.ch - 3);
+    const int e0 = max(3, c0 - SPLIT_HALO), e1 = min(g.ch - 3, c1 + SPLIT_HALO);
+    CellGeom g2 = g;  // the extended strip as a "cell" whose interior rows are [e0, e1)
+    g2.Y0 = g.Y0 + e0 - 3;
+    g2.ch = (e1 - e0) + 6;
+    int n_core = -1;
+    const int n_raw = (c0 < c1) ? cell_gather_segments(FB, eye, g2, cs, cxi, (S.prm.W + TS_W - 1) / TS_W, L.keys, raw_cap, L.scan) : 0;
+    if (dbg && tid == 0) dbg[1] = clock64();
+    uint32_t *dst = S.strip_kp[eye] + ((size_t)cell * SPLIT_MAX + strip) * SPLIT_KP_CAP;  // (helpers)
+    if (n_raw <= raw_cap) {
+        const int n_kp = cell_nms<uint16_t>(L.keys, L.uf, L.root16, L.abv16, L.nms16, L.tie8, n_raw, L.row_first, L.row_end, L.scan, dbg);
+        // a blob with a pixel in an outermost extended row (that is not the cell's own first / last interior row) AND one in a core row?
+        for (int i = tid; i < n_raw; i += 1024) L.tie8[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n_raw; i += 1024) {
+            const int y = key_y(L.keys[i]);
+            if ((e0 > 3 && y == e0) || (e1 < g.ch - 3 && y == e1 - 1)) L.tie8[L.root16[i]] = 1;
+        }
+        __syncthreads();
+        int unsafe = 0;
+        for (int i = tid; i < n_raw; i += 1024) {
+            const int y = key_y(L.keys[i]);
+            if (y >= c0 && y < c1 && L.tie8[L.root16[i]]) unsafe = 1;
+        }
+        if (!__syncthreads_or(unsafe)) {
+            // survivors of the core rows, raster order: the main workgroup keeps them where they are (uf[0 ..): off <= i), a helper sends them out
+            int n_out = 0;
+            for (int base = 0; base < n_kp; base += 1024) {
+                const int i = base + tid;
+                const uint32_t k = (i < n_kp) ? L.uf[i] : 0u;
+                const bool keep = (i < n_kp) && key_y(k) >= c0 && key_y(k) < c1;
+                int total;
+                const int off = n_out + block_excl_scan(keep ? 1 : 0, L.scan, &total);
+                if (keep) {
+                    if (strip == 0) L.uf[off] = k;
+                    else if (off < SPLIT_KP_CAP) dst[off] = k;
+                }
+                n_out += total;
+            }
+            n_core = (strip != 0 && n_out > SPLIT_KP_CAP) ? -1 : n_out;
+        }
+    }
+    if (strip != 0) {  // helper: the survivors, then the count, then the token.  strip_kp / strip_n are UNCACHED device memory (lvt_host.hip): a store is
+        // performed when its wave's vmcnt says so -- no release fence, whose L2 write-back costs ~13 us behind k_score's planes (measured)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            __hip_atomic_store(cnt_all + strip, n_core, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __hip_atomic_store(reinterpret_cast<unsigned *>(cnt_all + 4 + strip), token, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        return;
+    }
+    // main: wait for the helpers
+    __shared__ int s_helper[SPLIT_MAX];
+    if (tid == 0) {
+        for (int h = 1; h < nsplit; h++) {
+            const unsigned *fl = reinterpret_cast<const unsigned *>(cnt_all + 4 + h);
+            const long long t0 = wall_clock64();
+            int n = -1;
+            while (true) {
+                if (__hip_atomic_load(fl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == token) {
+                    n = __hip_atomic_load(cnt_all + h, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    break;
+                }
+                if (wall_clock64() - t0 > 200000) break;  // 2 ms of the 100-MHz clock: the whole cell on this workgroup
+                __builtin_amdgcn_s_sleep(2);
+            }
+            s_helper[h] = n;
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    bool bad = n_core < 0;
+    int total = max(n_core, 0);
+    for (int h = 1; h < nsplit; h++) {
+        bad = bad || s_helper[h] < 0;
+        total += max(s_helper[h], 0);
+    }
+    if (bad || total > raw_cap) {
+        __syncthreads();
+        cells_work(S, FB, eye, cell, 0, L, raw_cap);
+        if (dbg && tid == 0) dbg[10] = 2003;  // (tests: a strip could not vouch or overflowed -- the whole cell on this workgroup, as without the split)
+        return;
+    }
+    {
+        int off = n_core;
+        for (int h = 1; h < nsplit; h++) {
+            const uint32_t *src = S.strip_kp[eye] + ((size_t)cell * SPLIT_MAX + h) * SPLIT_KP_CAP;
+            for (int i = tid; i < s_helper[h]; i += 1024) L.uf[off + i] = __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            off += s_helper[h];
+        }
+    }
+    __syncthreads();
+    if (dbg && tid == 0) dbg[5] = clock64();
+    float *out = FB.cell_kp[eye] + (size_t)cell * CELL_OUT_CAP * 3;
+    const int n_out = cell_anms<uint16_t>(S, g, L.keys, L.uf, L.root16, L.abv16, L.nms16, total, raw_cap, L.row_first, L.row_end, L.scan, L.misc, out, dbg, total);
+    if (dbg && tid == 0) dbg[11] = clock64();
+    cell_finish(FB, eye, cell, 0, n_out);
+}
+
 // ---- host images into the pitched planes (the body of k_stage_in, lvt_host.hip; also the pull workgroups of k_cells below) -------------------
 // tightly packed source (stride == cols, ANY byte address and byte count) -> pitched plane: bytes up to the first 16-byte boundary and behind the
 // last whole vector travel one by one, everything between as aligned 16-byte loads; no load reaches outside [src, src + W H).
@@ -1376,13 +1503,25 @@ struct CellOrder {
     uint8_t v[CELLS_MAX];
 };
 template <bool BV>  // (a single sequence's descriptor travels in the kernel arguments: one dependent memory hop less at the head of the longest kernel)
-__device__ __forceinline__ void cells_entry(const SeqArg<BV> &sa, int pass, int par, const CellOrder &ord, int lanes, int raw_cap, const NextPull &np) {
+__device__ __forceinline__ void cells_entry(const SeqArg<BV> &sa, int pass, int par, const CellOrder &ord, int lanes, int raw_cap, const NextPull &np, int nsplit, unsigned token) {
     int eye = blockIdx.y, cell = blockIdx.x;
+    int strip = -1;  // >= 0: this workgroup is one row strip of a split cell (cells_work_split)
     if constexpr (BV) {
-        if ((int)blockIdx.x >= sa.v.prm.n_cells) {  // a pull workgroup (only launched when there is something to pull)
-            const int k = (int)blockIdx.x - sa.v.prm.n_cells, nk = (int)gridDim.x - sa.v.prm.n_cells;
+        // nsplit >= 2: x in [0, NH (nsplit - 1)) helpers (strip 1 + x / NH of cell x % NH), [NH (nsplit - 1), NH nsplit) the cells' main workgroups,
+        // behind them the pull workgroups; NH = n_cells rounded up to 8 and gridDim.x % 8 == 0, so a cell's workgroups share their id modulo 8
+        const int nc = sa.v.prm.n_cells;
+        const int first_pull = (nsplit >= 2) ? ((nc + 7) & ~7) * nsplit : nc;
+        if ((int)blockIdx.x >= first_pull) {  // a pull workgroup (or grid padding when there is nothing to pull)
+            if (!np.src[eye]) return;
+            const int k = (int)blockIdx.x - first_pull, nk = (int)gridDim.x - first_pull;
             stage_in_body(np.src[eye], np.dst[eye], np.W, np.H, np.pitch, (size_t)k * blockDim.x + threadIdx.x, (size_t)nk * blockDim.x);
             return;
+        }
+        if (nsplit >= 2) {
+            const int NH = (nc + 7) & ~7, role = (int)blockIdx.x / NH;
+            cell = (int)blockIdx.x - role * NH;
+            if (cell >= nc) return;
+            strip = (role == nsplit - 1) ? 0 : role + 1;
         }
     }
     const Seq *Sp;
@@ -1395,21 +1534,22 @@ __device__ __forceinline__ void cells_entry(const SeqArg<BV> &sa, int pass, int 
     }
     const Seq &S = *Sp;
     const FrameBuf &FB = S.fb[par];
-    if (threadIdx.x == 0 && cell < CELLS_MAX) S.cell_big[eye][cell] = 0;  // (nobody reads it before this launch is over)
+    if (threadIdx.x == 0 && cell < CELLS_MAX && strip <= 0) S.cell_big[eye][cell] = 0;  // (nobody reads it before this launch is over)
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const CellLds L = carve_cell_lds(smem, raw_cap);
-    cells_work(S, FB, eye, cell, pass, L, raw_cap);
+    if (strip >= 0) cells_work_split(S, FB, eye, cell, strip, nsplit, token, L, raw_cap);
+    else cells_work(S, FB, eye, cell, pass, L, raw_cap);
 }
 // A single sequence runs one workgroup per CU with the 159-KB carve: it may use the 128 registers a 1024-thread workgroup can have.  The batch
 // instance is held to 64 so that TWO of its 80-KB workgroups share a CU (at 66 registers it ran one per CU whatever its LDS) -- an occupancy
 // attribute on the template would cap the single-sequence instance too, where a second workgroup can never fit and the cap can only spill.
 template <bool BV>
-__global__ __launch_bounds__(1024) void k_cells(SeqArg<BV> sa, int pass, int par, CellOrder ord, int lanes, int raw_cap, NextPull np) {
-    cells_entry<BV>(sa, pass, par, ord, lanes, raw_cap, np);
+__global__ __launch_bounds__(1024) void k_cells(SeqArg<BV> sa, int pass, int par, CellOrder ord, int lanes, int raw_cap, NextPull np, int nsplit, unsigned token) {
+    cells_entry<BV>(sa, pass, par, ord, lanes, raw_cap, np, nsplit, token);
 }
 template <>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_cells<false>(SeqArg<false> sa, int pass, int par, CellOrder ord, int lanes, int raw_cap, NextPull np) {
-    cells_entry<false>(sa, pass, par, ord, lanes, raw_cap, np);
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void k_cells<false>(SeqArg<false> sa, int pass, int par, CellOrder ord, int lanes, int raw_cap, NextPull np, int nsplit, unsigned token) {
+    cells_entry<false>(sa, pass, par, ord, lanes, raw_cap, np, 0, token);
 }
 
 // ---- an oversized cell as row strips --------------------------------------------------------------------------------------------
@@ -1419,7 +1559,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 // outermost halo row of the extended strip -- such a blob might continue outside.  That is checked per blob; a strip that cannot
 // vouch (or whose extended rows overflow the LDS) reports -1 and k_cells_big runs the whole cell on the single-workgroup global path
 // instead, as before.  Survivors of the strips, concatenated in strip order, ARE the cell's survivors in raster order.
-constexpr int STRIPS = 8, STRIP_HALO = 16;
+constexpr int STRIP_HALO = 16;
 __global__ __launch_bounds__(1024) void k_cells_strip(Seq *seqs, int pass, int par) {
     Seq &S = seqs[blockIdx.z];
     const int eye = blockIdx.y, cell = blockIdx.x / STRIPS, strip = blockIdx.x % STRIPS;

@@ -158,6 +158,8 @@ struct Context {
     // RAW_CAP_SMALL corners -- 80 KB of LDS instead of 159, TWO workgroups per CU (k_cells is held to 64 VGPRs for that: at 66 it ran one per CU whatever its LDS) --
     // and a cell with more raw corners than that takes the exact global-memory path, as one beyond RAW_CAP does (LVT_AMD_CELLS_RAW_CAP overrides)
     int cells_raw_cap = RAW_CAP;
+    unsigned cell_token = 0;  // one per k_cells launch, never reset: what a split cell's helper workgroups publish their survivors under
+    int cell_split = 2;     // workgroups a single sequence's tall detection cell is cut into (cells_work_split; LVT_AMD_CELL_SPLIT=0 | 2 | 3)
     int lists_wgs_row = LISTS_WGS_ROW, lists_wgs_map = LISTS_WGS_MAP;
     int match_blocks_batch = 32;   // workgroups per sequence of a batch's k_match_map (it lists the points appended since the early part: none on most frames,
                                    // and every workgroup's thread 0 recomputes the prediction before it can leave): 256 -> 32 = +6 % frames/s at 16 sequences
@@ -212,6 +214,16 @@ struct Context {
 
     void set_error(const std::string &s) { err = s; }
 
+    template <typename T>
+    T *dalloc_uncached(size_t n) {  // device memory no cache holds (MTYPE UC): what one workgroup stores, another of the same launch may read without fences
+        void *p = nullptr;
+        size_t bytes = ((n * sizeof(T) + 255) / 256) * 256;
+        if (bytes == 0) bytes = 256;
+        HIPCHK(this, hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached));
+        HIPCHK(this, hipMemset(p, 0, bytes));
+        allocs.push_back(p);
+        return static_cast<T *>(p);
+    }
     template <typename T>
     T *dalloc(size_t n) {
         void *p = nullptr;
@@ -526,6 +538,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
             (void)hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, c->device);
             if (!prm.big_cell_strips && prm.n_cells * 2 * B > n_cu) c->cells_raw_cap = RAW_CAP_SMALL;
         }
+        if (const char *e = std::getenv("LVT_AMD_CELL_SPLIT")) c->cell_split = std::max(0, std::min(SPLIT_MAX, std::atoi(e)));
         if (const char *e = std::getenv("LVT_AMD_CELLS_RAW_CAP")) c->cells_raw_cap = std::max(RAW_CAP_SMALL, std::min(RAW_CAP, std::atoi(e) & ~1));
         if (const char *e = std::getenv("LVT_AMD_FUSED_PULL")) c->fuse_pull = std::atoi(e) != 0;
         if (const char *e = std::getenv("LVT_AMD_LISTS_WGS")) {
@@ -556,8 +569,8 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
             }
             for (int e = 0; e < 2; e++) S.cell_scratch[e] = c->dalloc<uint32_t>((size_t)prm.W * prm.H * 6 + 64);
             for (int e = 0; e < 2; e++) {
-                S.strip_kp[e] = c->dalloc<uint32_t>(prm.big_cell_strips ? (size_t)prm.n_cells * STRIPS * RAW_CAP : 64);
-                S.strip_n[e] = c->dalloc<int>((size_t)CELLS_MAX * STRIPS);
+                S.strip_kp[e] = prm.big_cell_strips ? c->dalloc<uint32_t>((size_t)prm.n_cells * STRIPS * RAW_CAP) : c->dalloc_uncached<uint32_t>((size_t)prm.n_cells * SPLIT_MAX * SPLIT_KP_CAP);
+                S.strip_n[e] = c->dalloc_uncached<int>((size_t)CELLS_MAX * STRIPS);
                 S.cell_big[e] = c->dalloc<int>(CELLS_MAX);
             }
             S.lists_fb = c->dalloc<int>(2);
@@ -736,7 +749,10 @@ static void enqueue_frame(Context *c) {
             const int pass = 0;  // (the <200-corner retry pass runs inside k_gather: it is almost never taken)
             // (a single sequence: + the workgroups that pull the next asynchronous host frame, one 16-byte vector per thread)
             const int pull_wgs = (B == 1 && c->next_pull.src[0]) ? std::min(64, (int)(((size_t)p.W * p.H / 16 + 1023) / 1024)) : 0;
-            LAUNCH_S(3, sf, k_cells, (B == 1 ? dim3(p.n_cells + pull_wgs, 2, 1) : dim3(p.n_cells * 2 * Bz, 1, 1)), dim3(1024), cells_lds_bytes(c->cells_raw_cap), pass, par, c->cell_order, 2 * Bz, c->cells_raw_cap, c->next_pull);
+            // a single sequence's tall cells run as cell_split co-operating workgroups (cells_work_split); grid: helpers, main workgroups, pull, padded to 8
+            const int ns = (B == 1 && !p.big_cell_strips) ? c->cell_split : 0;
+            const int gx = (ns >= 2) ? ((((p.n_cells + 7) & ~7) * ns + pull_wgs + 7) & ~7) : p.n_cells + pull_wgs;
+            LAUNCH_S(3, sf, k_cells, (B == 1 ? dim3(gx, 2, 1) : dim3(p.n_cells * 2 * Bz, 1, 1)), dim3(1024), cells_lds_bytes(c->cells_raw_cap), pass, par, c->cell_order, 2 * Bz, c->cells_raw_cap, c->next_pull, ns, ++c->cell_token);
             if (p.big_cell_strips) {  // oversized cells: NMS as row strips on several CUs, then ANMS of the merged survivors in three launches
                 hipLaunchKernelGGL(k_cells_strip, dim3(p.n_cells * STRIPS, 2, Bz), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
                 hipLaunchKernelGGL(k_cells_big, dim3(p.n_cells, 2, Bz), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);

@@ -85,6 +85,43 @@ def test_oversized_cell_paths(hip_lib, oracle_lib, kind):
     assert err == "" or "results unaffected" in err, err
 
 
+@pytest.mark.parametrize("kind", ["world", "tall_blobs", "blurred_noise"])
+def test_split_cell_routes(hip_lib, oracle_lib, kind):
+    """a single sequence's 250-row detection cells run as TWO co-operating workgroups of one k_cells launch (cells_work_split: AGAST's NMS of the
+    upper and the lower half with a 16-row halo, survivors merged, ANMS on the merged list).  An ordinary frame takes the split; noise stretched
+    a constructed corner blob 137 rows tall crosses the cut and both halos -- the strips cannot vouch and the main workgroup runs the whole cell alone (route 2003).
+    Key points, responses, descriptors and their ORDER against the oracle either way."""
+    from parity_util import make_case
+    from oracle import pyoracle
+    world, prm, _ = make_case("kitti", 4, 1.0)
+    H, W = world.H, world.W
+    rng = np.random.default_rng(11)
+    if kind == "world":
+        img = world.render_stereo(0)[0]
+    elif kind == "blurred_noise":
+        a = rng.integers(0, 256, size=(H + 2, W + 2)).astype(np.float32)
+        img = ((a[:-2, :-2] + a[:-2, 1:-1] + a[:-2, 2:] + a[1:-1, :-2] + a[1:-1, 1:-1] + a[1:-1, 2:] + a[2:, :-2] + a[2:, 1:-1] + a[2:, 2:]) / 9.0)
+        img = np.clip((img - 128.0) * 3.0 + 128.0, 0, 255).astype(np.uint8)
+    else:
+        # a 5 x 2 tile repeated down a column makes EVERY pixel of one image column a corner (found by search over small tiles with the oracle's score
+        # map): a 4-connected corner blob 137 rows tall in cell 0 -- through the cut between the two strips and both their halos
+        img = world.render_stereo(0)[0].copy()
+        img[50:210, 80:120] = 20
+        img[60:200, 96:101] = np.tile(np.array([[128, 128, 128, 128, 20], [128, 235, 128, 235, 128]], np.uint8), (70, 1))
+    img = np.ascontiguousarray(img)
+    hip = hip_lib.LvtSystem.create(prm, 1)
+    hip.track(img, img)
+    xo, ro, do, _ = pyoracle.compute_features(img, prm)
+    xh, rh, dh = hip.features(0)
+    assert np.array_equal(xh, xo) and np.array_equal(rh, ro) and np.array_equal(dh, do), (kind, len(xh), len(xo))
+    route = int(hip.debug_stamps()[10])
+    if kind == "world":
+        assert route != 2003 and len(xo) > 500, (route, len(xo))
+    if kind == "tall_blobs":
+        assert route == 2003, (route, len(xo))
+    assert hip.last_error() == "", hip.last_error()
+
+
 def _hamming_ref(O, qd, qxy, td, txy, tf, r2, mode, rows, cols):
     B, M = qd.shape[:2]
     out = np.zeros((B, M, 4), np.int32)

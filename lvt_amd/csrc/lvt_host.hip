@@ -752,7 +752,7 @@ static void enqueue_frame(Context *c) {
             // a single sequence's tall cells run as cell_split co-operating workgroups (cells_work_split); grid: helpers, main workgroups, pull, padded to 8
             const int ns = (B == 1 && !p.big_cell_strips) ? c->cell_split : 0;
             const int gx = (ns >= 2) ? ((((p.n_cells + 7) & ~7) * ns + pull_wgs + 7) & ~7) : p.n_cells + pull_wgs;
-            LAUNCH_S(3, sf, k_cells, (B == 1 ? dim3(gx, 2, 1) : dim3(p.n_cells * 2 * Bz, 1, 1)), dim3(1024), cells_lds_bytes(c->cells_raw_cap), pass, par, c->cell_order, 2 * Bz, c->cells_raw_cap, c->next_pull, ns, ++c->cell_token);
+            LAUNCH_S(3, sf, k_cells, (B == 1 ? dim3(gx, 2, 1) : dim3(p.n_cells * 2 * Bz, 1, 1)), dim3(1024), cells_lds_bytes(c->cells_raw_cap), pass, par, c->cell_order, 2 * Bz, c->cells_raw_cap, c->next_pull, ns, (++c->cell_token ? c->cell_token : ++c->cell_token));
             if (p.big_cell_strips) {  // oversized cells: NMS as row strips on several CUs, then ANMS of the merged survivors in three launches
                 hipLaunchKernelGGL(k_cells_strip, dim3(p.n_cells * STRIPS, 2, Bz), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);
                 hipLaunchKernelGGL(k_cells_big, dim3(p.n_cells, 2, Bz), dim3(1024), CELLS_LDS_BYTES, sf, S, pass, par);

@@ -1606,11 +1606,8 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
     int calls = 0;
     double n_border[1] = {0.0};
 
+    bool any_active = n > 0;  // every edge enters at level 0 (k_track_mid's bookkeeping / the stand-alone entry clear the levels); pass 2: the gate below tells
     for (int pass = 0; pass < 2; pass++) {
-        double na[1] = {0.0};
-        for (int i = tid; i < n; i += PNP_THREADS) na[0] += (level[i] == 0) ? 1.0 : 0.0;
-        block_sum<1>(na, red);
-        const bool any_active = na[0] > 0.0;
         bool ok = true;         // uniform across the block (decisions are broadcast through sh)
         bool have_sys = false;  // sh.sys holds chi2 / H / b at the current estimate
         for (int iter = 0; iter < 5 && ok && any_active; iter++) {
@@ -1749,6 +1746,7 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
         // px / pz - u gives.  A decision that close to the threshold is re-taken on the reference's own expression, IEEE divisions, at the
         // estimate the stored errors belong to -- and counted, so that tests see how often (and how near) that happens.
         {
+            int kept = 0;
             for (int i = tid; i < n; i += PNP_THREADS) {
                 if (level[i] != 0) continue;
                 const double e0 = err[2 * i], e1 = err[2 * i + 1];
@@ -1772,16 +1770,18 @@ __device__ __forceinline__ void pnp_run(const Params &prm, const Pose &prior, co
                     n_border[0] += 1.0;
                 }
                 if (out) level[i] = 1;
+                else kept = 1;
             }
+            any_active = __syncthreads_or(kept) != 0;  // (also the barrier behind the levels' update)
         }
-        __syncthreads();
     }
-    double inl[1] = {0.0};
-    for (int i = tid; i < n; i += PNP_THREADS) inl[0] += (level[i] == 0) ? 1.0 : 0.0;
-    block_sum<1>(inl, red);
-    inliers = (int)inl[0];
-    block_sum<1>(n_border, red);
-    borderline = (int)n_border[0];
+    {   // inliers and borderline decisions in ONE block-wide sum: both are small integers, inliers + 65536 borderline is exact in a double
+        double cnt[1] = {65536.0 * n_border[0]};
+        for (int i = tid; i < n; i += PNP_THREADS) cnt[0] += (level[i] == 0) ? 1.0 : 0.0;
+        block_sum<1>(cnt, red);
+        const long long packed = (long long)cnt[0];
+        inliers = (int)(packed & 65535), borderline = (int)(packed >> 16);
+    }
     solve_calls = calls;
     for (int k = 0; k < 4; k++) result.q[k] = sh.r[k];
     for (int k = 0; k < 3; k++) result.p[k] = sh.t[k];
@@ -1797,7 +1797,7 @@ constexpr int PNP_STAGE_MAX = 1536;
 constexpr int PNP_DYN_BYTES = PNP_STAGE_MAX * (24 + 16 + 8 + 1);
 
 __device__ __forceinline__ void pnp_solve(const Params &prm, const Pose &prior, const double *X, const float *obs, double *err, int8_t *level,
-                                          int n, PnpShared &sh, double *red, uint8_t *dyn, Pose &res, int &inliers, int &calls, int &borderline, long long *dbg) {
+                                          int n, PnpShared &sh, double *red, uint8_t *dyn, Pose &res, int &inliers, int &calls, int &borderline, long long *dbg, bool copy_out) {
     if (n <= PNP_STAGE_MAX) {
         double *sX = reinterpret_cast<double *>(dyn);
         double *sErr = sX + 3 * PNP_STAGE_MAX;
@@ -1808,8 +1808,10 @@ __device__ __forceinline__ void pnp_solve(const Params &prm, const Pose &prior, 
         for (int i = threadIdx.x; i < n; i += PNP_THREADS) sLvl[i] = level[i];
         __syncthreads();
         pnp_run(prm, prior, sX, sObs, sErr, red + PNP_RED - 2, sLvl, n, sh, red, res, inliers, calls, borderline, dbg);  // (the last two doubles of red: block_sum never touches them)
-        for (int i = threadIdx.x; i < 2 * n; i += PNP_THREADS) err[i] = sErr[i];
-        for (int i = threadIdx.x; i < n; i += PNP_THREADS) level[i] = sLvl[i];
+        if (copy_out) {  // (the stand-alone entry's caller reads errors and levels; nothing behind k_pnp does, and the pose waits for these stores)
+            for (int i = threadIdx.x; i < 2 * n; i += PNP_THREADS) err[i] = sErr[i];
+            for (int i = threadIdx.x; i < n; i += PNP_THREADS) level[i] = sLvl[i];
+        }
     } else
         pnp_run(prm, prior, X, obs, err, err + 2 * (size_t)n, level, n, sh, red, res, inliers, calls, borderline, dbg);  // the caller allocates 2 n + 2 doubles
 }
@@ -1840,7 +1842,7 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp(SeqArg<BV> sa, int par, seq
     int inliers, calls, borderline;
     if (threadIdx.x == 0) sh.trace = nullptr, sh.trace_cap = 0;
     // err must be defined for every edge before the first gate: all edges are active in pass 1
-    pnp_solve(S.prm, ctl.predicted, S.pnp_X, S.pnp_obs, S.pnp_err, S.pnp_level, ctl.n_matches, sh, red, pnp_dyn, res, inliers, calls, borderline, ctl.dbg);
+    pnp_solve(S.prm, ctl.predicted, S.pnp_X, S.pnp_obs, S.pnp_err, S.pnp_level, ctl.n_matches, sh, red, pnp_dyn, res, inliers, calls, borderline, ctl.dbg, false);
     if (threadIdx.x == 0) {
         ctl.optimized = res;
         ctl.last_pose = res;  // lvt_system.cpp:205
@@ -1881,7 +1883,7 @@ __global__ __launch_bounds__(PNP_THREADS) void k_pnp_standalone(Params prm, Pose
     __syncthreads();
     Pose res;
     int inliers, calls, borderline;
-    pnp_solve(prm, prior, X, obs, err, level, n, sh, red, pnp_dyn, res, inliers, calls, borderline, nullptr);
+    pnp_solve(prm, prior, X, obs, err, level, n, sh, red, pnp_dyn, res, inliers, calls, borderline, nullptr, true);
     if (threadIdx.x == 0) {
         *out = res;
         info[0] = calls;

@@ -15,7 +15,7 @@ prm = {"kitti": lvt_amd.kitti_params, "euroc": lvt_amd.euroc_params, "tum": lvt_
 sensor = 2 if kind == "tum" else 1
 vo = lvt_amd.LvtSystem.create(prm, sensor)
 # stamp k .. k+1 of k_cells (k_features.hip STAMP(k)); dbg[1] is taken right after the corner gather
-phases = ["gather segments", "(links start)", "links + union-find + component maxima", "replay of tied components", "survivors",
+phases = ["gather segments", "(links start)", "links + union-find + component maxima", "replay of tied components", "survivors (split cells: + waiting for the helper strip, merge)",
           "std::sort emulation", "rank", "radii", "decision radius", "emit", "done"]
 for i in range(int(sys.argv[2]) if len(sys.argv) > 2 else 4):
     L, R = w.render_rgbd(i) if sensor == 2 else w.render_stereo(i)

@@ -45,7 +45,7 @@ def pose_errors(Rh, th, Ro, to):
     return e_t, e_R
 
 
-def live_hamming_traffic(B, M, N, timeout=120):
+def live_hamming_traffic(B, M, N, timeout=120, mode=0):
     """HBM counters of the matcher launch, collected NOW: one `rocprofv3 --pmc <counter>` child per counter (FETCH_SIZE and WRITE_SIZE cannot share
     a pass; counters only, no trace domain) over tools/hamming_bench.py with the same B, M, N.  Returns {counter: KB per dispatch, n_counter: dispatches}
     or None (no rocprofv3, this process is itself under a profiler, or the tool failed) -- the caller then falls back to the committed passes."""
@@ -65,12 +65,12 @@ def live_hamming_traffic(B, M, N, timeout=120):
         try:
             env = dict(os.environ, TMPDIR=tmp)
             cmd = ["rocprofv3", "--pmc", ctr, "--output-format", "csv", "-d", d, "-o", "h", "--", sys.executable, os.path.join(HERE, "tools", "hamming_bench.py"),
-                   str(B), str(M), str(N), "0"]
+                   str(B), str(M), str(N), str(mode)]
             subprocess.run(cmd, cwd=tmp, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=timeout)
             vals = []
             for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if "k_hamming_batched<0" in r.get("Kernel_Name", "") and r.get("Counter_Name") == ctr:
+                    if ("k_hamming_batched<%d" % mode) in r.get("Kernel_Name", "") and r.get("Counter_Name") == ctr:
                         vals.append(float(r["Counter_Value"]))
             if not vals:
                 return None
@@ -357,35 +357,54 @@ class HipBackend:
         tf = torch.zeros((B, N), dtype=torch.uint8, device=dev)
         out = torch.zeros((B, M, 4), dtype=torch.int32, device=dev)
         torch.cuda.synchronize()
-        # warm-up with the ROW-mode instance of the kernel (a different template instance, so the rocprofv3 --stats row of the
-        # radius-mode instance holds the reported launches only): the clocks settle under the same kind of load
+        # warm-up with a THIRD template instance of the kernel (csr = 2: a 30-px radius), so the rocprofv3 --stats rows of the two
+        # reported instances hold 3 untimed + the 35 reported launches each: the clocks settle under the same kind of load
         for _ in range(8):
-            lvt.hamming_match_batched(qd, qxy, td, txy, tf, 0.0, 1, H, W, out, launches=10)
+            lvt.hamming_match_batched(qd, qxy, td, txy, tf, 900.0, 0, H, W, out, launches=10)
+        pop = np.array([bin(i).count("1") for i in range(256)], np.int64)
+
+        def sample_check(mode):
+            """a sample of the big launch against a numpy restatement of the matcher (three problems x their first 48 queries)"""
+            checked = 0
+            for b in (0, B // 2, B - 1):
+                Q = 48
+                qd_, td_ = qd[b, :Q].cpu().numpy(), td[b].cpu().numpy()
+                qx, tx = qxy[b, :Q].cpu().numpy(), txy[b].cpu().numpy()
+                got = out[b, :Q].cpu().numpy()
+                d = pop[qd_[:, None, :] ^ td_[None, :, :]].sum(axis=2)
+                if mode == 0:   # lvt_image_features_struct.cpp:84-99: squared distance below r^2 (fp32)
+                    dx = (tx[None, :, 0] - qx[:, None, 0]).astype(np.float32); dy = (tx[None, :, 1] - qx[:, None, 1]).astype(np.float32)
+                    mask = ((dx * dx).astype(np.float32) + (dy * dy).astype(np.float32)).astype(np.float32) < np.float32(625.0)
+                else:           # struct.cpp:124-140: rows int(y) - 2 .. int(y) + 2, clipped to [0, rows]
+                    qi = qx[:, 1].astype(np.int64)
+                    lo, hi = np.maximum(qi - 2, 0), np.minimum(qi + 2, H)
+                    ty = np.floor(tx[:, 1]).astype(np.int64)
+                    mask = (ty[None, :] >= lo[:, None]) & (ty[None, :] <= hi[:, None])
+                big = np.int64(1) << 40
+                key = np.where(mask, d * 65536 + np.arange(N)[None, :], big)
+                key = np.concatenate([key, np.full((Q, 2), big)], axis=1)
+                o = np.sort(key, axis=1)[:, :2]
+                ref = np.stack([np.where(o[:, 0] < big, o[:, 0] % 65536, -1), np.where(o[:, 0] < big, o[:, 0] // 65536, 0x7FFFFFFF),
+                                np.where(o[:, 1] < big, o[:, 1] % 65536, -1), np.where(o[:, 1] < big, o[:, 1] // 65536, 0x7FFFFFFF)], axis=1)
+                if not np.array_equal(got.astype(np.int64), ref):
+                    raise RuntimeError(f"matcher output (mode {mode}) of problem {b} differs from the numpy restatement")
+                checked += Q
+            return checked
+
+        byts = float(B) * bmatch(M, N)
         lvt.hamming_match_batched(qd, qxy, td, txy, tf, 625.0, 0, H, W, out, launches=3)     # instruction cache, not timed
         us = [lvt.hamming_match_batched(qd, qxy, td, txy, tf, 625.0, 0, H, W, out, launches=5) for _ in range(7)]
         mean = float(np.mean(us))          # = the mean over the 35 reported launches (what tools/profile.sh extracts from the trace)
-        byts = float(B) * bmatch(M, N)
         ach = byts / (mean * 1e-6) / 1e9
-        # a sample of the big launch against a numpy restatement of the matcher (three problems x their first 48 queries)
-        checked = 0
-        pop = np.array([bin(i).count("1") for i in range(256)], np.int64)
-        for b in (0, B // 2, B - 1):
-            Q = 48
-            qd_, td_ = qd[b, :Q].cpu().numpy(), td[b].cpu().numpy()
-            qx, tx = qxy[b, :Q].cpu().numpy(), txy[b].cpu().numpy()
-            got = out[b, :Q].cpu().numpy()
-            d = pop[qd_[:, None, :] ^ td_[None, :, :]].sum(axis=2)
-            dx = (tx[None, :, 0] - qx[:, None, 0]).astype(np.float32); dy = (tx[None, :, 1] - qx[:, None, 1]).astype(np.float32)
-            mask = ((dx * dx).astype(np.float32) + (dy * dy).astype(np.float32)).astype(np.float32) < np.float32(625.0)
-            big = np.int64(1) << 40
-            key = np.where(mask, d * 65536 + np.arange(N)[None, :], big)
-            key = np.concatenate([key, np.full((Q, 2), big)], axis=1)
-            o = np.sort(key, axis=1)[:, :2]
-            ref = np.stack([np.where(o[:, 0] < big, o[:, 0] % 65536, -1), np.where(o[:, 0] < big, o[:, 0] // 65536, 0x7FFFFFFF),
-                            np.where(o[:, 1] < big, o[:, 1] % 65536, -1), np.where(o[:, 1] < big, o[:, 1] // 65536, 0x7FFFFFFF)], axis=1)
-            if not np.array_equal(got.astype(np.int64), ref):
-                raise RuntimeError(f"matcher output of problem {b} differs from the numpy restatement")
-            checked += Q
+        checked = sample_check(0)
+        # the OTHER matcher north_star names: the row-band (left <-> right) instance, measured the same way right behind the radius mode
+        for _ in range(8):   # (the sample check above left the GPU idle for a second: settle the clocks again, same third instance)
+            lvt.hamming_match_batched(qd, qxy, td, txy, tf, 900.0, 0, H, W, out, launches=10)
+        lvt.hamming_match_batched(qd, qxy, td, txy, tf, 0.0, 1, H, W, out, launches=3)
+        us_row = [lvt.hamming_match_batched(qd, qxy, td, txy, tf, 0.0, 1, H, W, out, launches=5) for _ in range(7)]
+        mean_row = float(np.mean(us_row))
+        ach_row = byts / (mean_row * 1e-6) / 1e9
+        checked_row = sample_check(1)
         # HBM traffic of the same launch from the committed rocprofv3 PMC passes (tools/profile.sh; counters cannot be read from
         # inside this process).  FETCH_SIZE counts the 16-B-per-lane loads of this kernel at one half on gfx950
         # (MI355X_MICROARCH.md, HBM section): corrected bytes = 2 * FETCH_SIZE + WRITE_SIZE.
@@ -405,6 +424,13 @@ class HipBackend:
                     traffic_src = "profiles/hamming_pmc.json (%s)" % pm.get("source", "rocprofv3 --pmc")
         except Exception:  # noqa: BLE001
             pass
+        traffic_row, traffic_row_src = None, None
+        live_row = None if "pmc" in args.skip else live_hamming_traffic(B, M, N, mode=1)
+        if live_row is not None:
+            traffic_row = round(2.0 * live_row["FETCH_SIZE"] * 1024.0 + live_row["WRITE_SIZE"] * 1024.0, 1)
+            traffic_row_src = ("measured by THIS run: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE over `python tools/hamming_bench.py %d %d %d 1`, mean of %d + %d "
+                               "dispatches: FETCH_SIZE %.1f KB, WRITE_SIZE %.1f KB" % (B, M, N, live_row["n_FETCH_SIZE"], live_row["n_WRITE_SIZE"],
+                                                                                         live_row["FETCH_SIZE"], live_row["WRITE_SIZE"]))
         copy_gbs = None
         try:  # what a plain device copy of the same byte count reaches on this box (read half + write half)
             cx = torch.empty(int(byts) // 2, dtype=torch.uint8, device=dev)
@@ -428,9 +454,14 @@ class HipBackend:
             "traffic_source": traffic_src, "output_checked": f"{checked} queries of 3 problems == numpy restatement",
             "device_copy_same_bytes_GBs": None if copy_gbs is None else round(copy_gbs, 1),
             "frac_of_device_copy": None if copy_gbs is None else round(ach / copy_gbs, 4),
+            "row_mode": {"kernel": "lvt::k_hamming_batched<1,1,1,2> (the same matcher with the row-band mask of row_match, lvt_image_features_struct.cpp:122-148: "
+                                   "the stereo left <-> right instance)", "bound": "hbm", "achieved": round(ach_row, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(ach_row / HBM_PEAK_GBS, 4), "traffic": traffic_row, "avg_us": round(mean_row, 2), "median_us": round(float(np.median(us_row)), 2),
+                         "launch": {"B": B, "M": M, "N": N, "algorithmic_bytes": byts}, "traffic_source": traffic_row_src,
+                         "output_checked": f"{checked_row} queries of 3 problems == numpy restatement"},
             "note": "B independent KITTI-nominal problems per launch; algorithmic bytes 40(M+N)+N+16M each (SURVEY 8d); MEAN of 35 launches "
-                    "(7 x 5 back to back between two HIP events on the launch stream) after 80 warm-up launches of the kernel's row-mode "
-                    "instance; the rocprofv3 --stats average of this kernel over the same command is the same statistic (profiles/); "
+                    "(7 x 5 back to back between two HIP events on the launch stream) after 80 warm-up launches of a THIRD template instance "
+                    "(csr = 2) in front of each of the two reported instances (radius mode first, then `row_mode`); the rocprofv3 --stats average of this kernel over the same command is the same statistic (profiles/); "
                     "traffic = 2*FETCH_SIZE + WRITE_SIZE (gfx950 counts this kernel's 16-B-per-lane loads at one half) of the same launch: "
                     "collected by this run through rocprofv3 when the tool is there and this process is not itself being profiled, else the "
                     "committed passes of tools/profile.sh (traffic_source says which).  Ceiling of this access pattern on an MI355X, measured in round 4 "

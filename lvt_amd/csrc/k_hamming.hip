@@ -19,6 +19,7 @@
 //      index exactly as batchDistance does.
 // Algorithmic HBM bytes per problem: 40*(M+N) + N + 16*M; every byte is read or written exactly once.
 #include "lvt_dev.h"
+#include <type_traits>
 
 namespace lvt {
 
@@ -61,6 +62,26 @@ __device__ __forceinline__ void push_bit(uint32_t &mask, float d2, float r2) {
     asm("v_cmp_gt_f32 vcc, %2, %1\n\tv_addc_co_u32 %0, vcc, %0, %0, vcc" : "+v"(mask) : "v"(d2), "v"(r2) : "vcc");
 }
 
+// 256-bit Hamming distance as ONE chain of accumulating popcounts (v_bcnt_u32_b32 adds its third operand): 8 xor + 8 bcnt.  Left to itself the
+// compiler splits the sum of eight popcounts into four chains and adds them up again (8 + 8 + 3 instructions), and bcnt / add3 / min / lshl_or issue at
+// HALF the rate of xor / add / fma on this machine (4.2 against 2.3 cycles per wave64 instruction and SIMD: tools/lab/int_issue.hip)
+__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
+__device__ __forceinline__ uint32_t hamming256(uint64_t d0, uint64_t d1, uint64_t d2, uint64_t d3, const uint4 &a0, const uint4 &a1) {
+    uint32_t d = bcnt_acc((uint32_t)d0 ^ a0.x, 0u);
+    d = bcnt_acc((uint32_t)(d0 >> 32) ^ a0.y, d);
+    d = bcnt_acc((uint32_t)d1 ^ a0.z, d);
+    d = bcnt_acc((uint32_t)(d1 >> 32) ^ a0.w, d);
+    d = bcnt_acc((uint32_t)d2 ^ a1.x, d);
+    d = bcnt_acc((uint32_t)(d2 >> 32) ^ a1.y, d);
+    d = bcnt_acc((uint32_t)d3 ^ a1.z, d);
+    d = bcnt_acc((uint32_t)(d3 >> 32) ^ a1.w, d);
+    return d;
+}
+
 // NSP = number of candidate ranges a query keeps in registers: 1 (row mode), 3 (csr 1), 5 (csr 2); 0 = any csr, the
 // ranges are walked one after the other (no flattening)
 template <int MODE, int NSP, int QPT, int TPT>  // QPT = ceil(M / 512) rounds of queries, TPT = ceil(N / 512) train features per thread
@@ -81,6 +102,7 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     uint16_t *s_order = s_idx + ((N + 1) & ~1);
     __shared__ int s_scan[32];
     __shared__ int s_hist[HB_HIST];
+    __shared__ int s_recheck;  // row mode: some train feature sits in a row bin without being an in-range integer row (see the scatter)
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     const uint4 *td = reinterpret_cast<const uint4 *>(a.t_desc + (size_t)b * N * 4);
@@ -121,6 +143,7 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     for (int k = 0; k < TPT; k++) tv[k] = (tid + k * HB_THREADS < N) & (tfl[k] == 0);
     for (int i = tid; i <= nbins; i += HB_THREADS) s_start[i] = 0;
     if (tid < HB_HIST) s_hist[tid] = 0;
+    if (tid == 0) s_recheck = 0;
     __syncthreads();
     if (dbg) dbg[1] = clock64();
 
@@ -165,7 +188,13 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         if (tv[k]) {
             const int pos = s_start[tbin[k]] + trank[k];
             s_xy[pos] = tp[k];
-            s_idx[pos] = (uint16_t)(tid + k * HB_THREADS);
+            // row mode: a feature whose y IS its bin (an integer row inside the image: every key point the detector emits) passes
+            // struct.cpp:133 `y >= start_y && y <= end_y` for exactly the queries whose row range holds its bin -- the walk needs
+            // no comparison and no coordinates.  Any other y (fractional, clamped into an edge bin, NaN) is marked: bit 15 of its
+            // index entry (indices stay below HB_NMAX = 4096) sends the walk to the reference's own comparison.
+            const bool recheck = (MODE == 1) && !((float)tbin[k] == tp[k].y);
+            if (recheck) s_recheck = 1;
+            s_idx[pos] = (uint16_t)((tid + k * HB_THREADS) | (recheck ? 0x8000 : 0));
             s_dlo[pos] = tdlo[k];
             s_dhi[pos] = tdhi[k];
         }
@@ -302,32 +331,65 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         }                                                                      \
     }
     // all candidates of the ranges, filter and distance in one pass (row mode, any-csr mode, over-long windows)
-    auto walk_all = [&](float2 p, float fy0, float fy1, uint64_t d0, uint64_t d1, uint64_t d2, uint64_t d3, uint32_t &k1, uint32_t &k2,
+    auto walk_all = [&](auto recheck_tag, float2 p, float fy0, float fy1, uint64_t d0, uint64_t d1, uint64_t d2, uint64_t d3, uint32_t &k1, uint32_t &k2,
                         int total, int o0, int c1, int o1, int c2, int o2, int c3, int o3, int c4, int o4) {
+        constexpr bool RECHECK = decltype(recheck_tag)::value;  // row mode only: marked entries exist in this problem
+        constexpr bool NEED_XY = (MODE != 1) || RECHECK;
         if (total <= 0) return;
         int it;
         LVT_POS_OF(it, 0)
-        float2 r = s_xy[it];
+        float2 r = make_float2(0.f, 0.f);
+        if (NEED_XY) r = s_xy[it];
         uint4 a0 = s_dlo[it], a1 = s_dhi[it];
         uint32_t id = s_idx[it];
         for (int v = 0; v < total; v++) {  // software-pipelined by one candidate; the last prefetch reads one past (valid LDS)
             int itn;
             LVT_POS_OF(itn, v + 1)
-            const float2 rn = s_xy[itn];
+            float2 rn = make_float2(0.f, 0.f);
+            if (NEED_XY) rn = s_xy[itn];
             const uint4 b0 = s_dlo[itn], b1 = s_dhi[itn];
             const uint32_t idn = s_idx[itn];
-            bool ok;
-            if (MODE == 1) ok = (r.y >= fy0) && (r.y <= fy1);
-            else {
+            bool ok = true;
+            if (MODE == 1) {
+                if (RECHECK) ok = !(id & 0x8000u) || ((r.y >= fy0) && (r.y <= fy1));
+            } else {
                 const float dx = r.x - p.x, dy = r.y - p.y;
                 ok = (dx * dx + dy * dy) < a.r2;
             }
-            const int d = __popcll(d0 ^ (((uint64_t)a0.y << 32) | a0.x)) + __popcll(d1 ^ (((uint64_t)a0.w << 32) | a0.z)) +
-                          __popcll(d2 ^ (((uint64_t)a1.y << 32) | a1.x)) + __popcll(d3 ^ (((uint64_t)a1.w << 32) | a1.z));
-            const uint32_t key = ok ? (((uint32_t)d << 16) | id) : 0xFFFFFFFFu;
+            const uint32_t d = hamming256(d0, d1, d2, d3, a0, a1);
+            uint32_t key = ((uint32_t)d << 16) | (RECHECK ? (id & 0x7FFFu) : id);
+            if (NEED_XY) key = ok ? key : 0xFFFFFFFFu;
             k2 = min(k2, max(k1, key));
             k1 = min(k1, key);
             r = rn, a0 = b0, a1 = b1, id = idn;
+        }
+    };
+    // row mode, no marked entries in the problem: the one range, two candidates per trip, no coordinates, no comparison.  Hand-unrolled: the
+    // accumulating popcounts are inline asm, which the loop unroller leaves alone.
+    // (merging a sorted pair lo <= hi into the running top-2 k1 <= k2: k1' = min(k1, lo), k2' = min(max(k1, lo), k2, hi).)
+    auto row_walk_lean = [&](int s0, int len, uint64_t d0, uint64_t d1, uint64_t d2, uint64_t d3, uint32_t &k1, uint32_t &k2) {
+        const uint4 *plo = s_dlo + s0, *phi = s_dhi + s0;
+        const uint16_t *pid = s_idx + s0;
+        auto pair = [&](const uint4 &a0, const uint4 &a1, uint32_t ia, const uint4 &b0, const uint4 &b1, uint32_t ib) {
+            const uint32_t ka = (hamming256(d0, d1, d2, d3, a0, a1) << 16) | ia, kb = (hamming256(d0, d1, d2, d3, b0, b1) << 16) | ib;
+            const uint32_t lo = min(ka, kb), hi = max(ka, kb);
+            const uint32_t t = max(k1, lo);
+            k1 = min(k1, lo);
+            k2 = min(t, min(k2, hi));
+        };
+        int v = 0;
+        // two candidates per trip, loaded and ranked in the same trip (the CU's other wavefronts cover the LDS latency; a two-deep register
+        // ping-pong measured slower: 265 against 228 us at B = 8192)
+        for (; v + 2 <= len; v += 2) {
+            const uint4 a0 = plo[v], a1 = phi[v], b0 = plo[v + 1], b1 = phi[v + 1];  // (by value: ds_read_b128, not the b32 pairs a reference into LDS becomes)
+            const uint32_t ia = pid[v], ib = pid[v + 1];
+            pair(a0, a1, ia, b0, b1, ib);
+        }
+        if (v < len) {
+            const uint4 a0 = plo[v], a1 = phi[v];
+            const uint32_t ka = (hamming256(d0, d1, d2, d3, a0, a1) << 16) | pid[v];
+            k2 = min(k2, max(k1, ka));
+            k1 = min(k1, ka);
         }
     };
     auto match_all = [&](int q, float2 p, uint4 w0, uint4 w1, const Ranges &R) {
@@ -339,12 +401,17 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             if (R.x0 <= R.x1)
                 for (int by = R.y0; by <= R.y1; by++) {
                     const int s = s_start[by * a.nbx + R.x0];
-                    walk_all(p, fy0, fy1, d0, d1, d2, d3, k1, k2, s_start[by * a.nbx + R.x1 + 1] - s, s, 0, 0, 0, 0, 0, 0, 0, 0);
+                    walk_all(std::false_type{}, p, fy0, fy1, d0, d1, d2, d3, k1, k2, s_start[by * a.nbx + R.x1 + 1] - s, s, 0, 0, 0, 0, 0, 0, 0, 0);
                 }
         } else {
             static_assert(NS <= 5, "range registers");
             const int c1 = R.l0, c2 = c1 + R.l1, c3 = c2 + R.l2, c4 = c3 + R.l3;
-            walk_all(p, fy0, fy1, d0, d1, d2, d3, k1, k2, c4 + R.l4, R.s0, c1, R.s1 - c1, c2, R.s2 - c2, c3, R.s3 - c3, c4, R.s4 - c4);
+            if (MODE == 1 && s_recheck)  // (block-uniform)
+                walk_all(std::true_type{}, p, fy0, fy1, d0, d1, d2, d3, k1, k2, c4 + R.l4, R.s0, c1, R.s1 - c1, c2, R.s2 - c2, c3, R.s3 - c3, c4, R.s4 - c4);
+            else if (MODE == 1)
+                row_walk_lean(R.s0, R.l0, d0, d1, d2, d3, k1, k2);
+            else
+                walk_all(std::false_type{}, p, fy0, fy1, d0, d1, d2, d3, k1, k2, c4 + R.l4, R.s0, c1, R.s1 - c1, c2, R.s2 - c2, c3, R.s3 - c3, c4, R.s4 - c4);
         }
         int4 o;
         o.x = (k1 == 0xFFFFFFFFu) ? -1 : (int)(k1 & 0xFFFFu);
@@ -451,9 +518,8 @@ LVT_RADIUS_BITS(lo, 0, t0)
                         m &= m - 1;
                         const uint4 b0 = s_dlo[itn], b1 = s_dhi[itn];
                         const uint32_t idn = s_idx[itn];
-                        const int d = __popcll(d0 ^ (((uint64_t)a0.y << 32) | a0.x)) + __popcll(d1 ^ (((uint64_t)a0.w << 32) | a0.z)) +
-                                      __popcll(d2 ^ (((uint64_t)a1.y << 32) | a1.x)) + __popcll(d3 ^ (((uint64_t)a1.w << 32) | a1.z));
-                        const uint32_t key = ((uint32_t)d << 16) | id;
+                        const uint32_t d = hamming256(d0, d1, d2, d3, a0, a1);
+                        const uint32_t key = (d << 16) | id;
                         k2 = min(k2, max(k1, key));
                         k1 = min(k1, key);
                         if (!more) break;
@@ -572,9 +638,8 @@ LVT_RADIUS_BITS(lo, 0, t0)
                         m &= m - 1;
                         const uint4 b0 = s_dlo[itn], b1 = s_dhi[itn];
                         const uint32_t idn = s_idx[itn];
-                        const int d = __popcll(d0 ^ (((uint64_t)a0.y << 32) | a0.x)) + __popcll(d1 ^ (((uint64_t)a0.w << 32) | a0.z)) +
-                                      __popcll(d2 ^ (((uint64_t)a1.y << 32) | a1.x)) + __popcll(d3 ^ (((uint64_t)a1.w << 32) | a1.z));
-                        const uint32_t key = ((uint32_t)d << 16) | id;
+                        const uint32_t d = hamming256(d0, d1, d2, d3, a0, a1);
+                        const uint32_t key = (d << 16) | id;
                         k2 = min(k2, max(k1, key));
                         k1 = min(k1, key);
                         if (!more) break;

@@ -266,6 +266,37 @@ def test_hamming_match_batched_sparse_and_narrow(hip_lib, mode, M, N, cols, rows
     assert bad.size == 0, f"{len(bad)} queries differ, first {bad[:3]}: got {got[tuple(bad[0])]} ref {ref[tuple(bad[0])]}"
 
 
+@pytest.mark.parametrize("M,N", [(200, 700), (1000, 1500)])
+def test_hamming_row_mode_fractional_and_out_of_range_rows(hip_lib, M, N):
+    """row mode walks row BINS; a train feature whose y is not an in-range integer row (fractional, above / below the image, NaN) must still be
+    held to the reference's own comparison `y >= start_y && y <= end_y` (lvt_image_features_struct.cpp:133).  Problem 0: integer rows only (the
+    walk without comparisons), 1: every kind mixed, 2: all fractional, 3: one single marked feature"""
+    import torch
+    rng = np.random.default_rng(5 + M)
+    B, rows, cols = 4, 376, 1241
+    td = rng.integers(0, 256, (B, N, 32), dtype=np.uint8)
+    qd = rng.integers(0, 256, (B, M, 32), dtype=np.uint8)
+    txy = np.floor(rng.uniform(0, 1, (B, N, 2)) * [cols - 1, rows - 1]).astype(np.float32)
+    qxy = (rng.uniform(0, 1, (B, M, 2)) * [cols - 1, rows - 1]).astype(np.float32)
+    txy[1, : N // 3, 1] += rng.uniform(0, 1, N // 3).astype(np.float32)            # fractional
+    txy[1, N // 3: N // 3 + 40, 1] = rng.uniform(-9, 0, 40).astype(np.float32)     # above the image (bin 0)
+    txy[1, N // 3 + 40: N // 3 + 80, 1] = rng.uniform(rows, rows + 9, 40).astype(np.float32)   # below it (last bin)
+    txy[1, N // 3 + 80: N // 3 + 90, 1] = np.float32(np.nan)
+    txy[1, N // 3 + 90: N // 3 + 100, 1] = np.float32(rows)                        # the row `end_y` may reach
+    txy[2, :, 1] += rng.uniform(0.01, 0.99, N).astype(np.float32)
+    txy[3, 17, 1] += np.float32(0.5)
+    qxy[:, :30, 1] = rng.uniform(0, 4, (B, 30)).astype(np.float32)                 # queries at both image borders
+    qxy[:, 30:60, 1] = rng.uniform(rows - 4, rows + 3, (B, 30)).astype(np.float32)
+    tf = (rng.uniform(0, 1, (B, N)) < 0.1).astype(np.uint8)
+    ref = _hamming_ref_np(qd, qxy, td, txy, tf, 0.0, 1, rows)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    out = torch.zeros((B, M, 4), dtype=torch.int32, device="cuda")
+    hip_lib.hamming_match_batched(t(qd), t(qxy), t(td), t(txy), t(tf), 0.0, 1, rows, cols, out)
+    got = out.cpu().numpy()
+    bad = np.argwhere((got != ref).any(axis=2))
+    assert bad.size == 0, f"{len(bad)} queries differ, first {bad[:3]}: got {got[tuple(bad[0])]} ref {ref[tuple(bad[0])]}"
+
+
 def test_pnp_standalone(hip_lib, oracle_lib):
     """k_pnp vs the oracle's g2o-LM restatement on synthetic 2D-3D sets incl. outliers (chi2 gate exercised)"""
     import lvt_amd

@@ -11,6 +11,11 @@ ap.add_argument("B", nargs="?", type=int, default=8192)
 ap.add_argument("--instance", default="k_hamming_batched<0, 3, 1, 2>")
 ap.add_argument("--has-b", action="store_true")
 ap.add_argument("--band", action="store_true", help="the kernel takes BandArgs (k_hamming_band.hip)")
+ap.add_argument("--split", type=int, default=0, help="v6_split.hip: sub-problems per problem")
+ap.add_argument("--threads", type=int, default=512, help="v6_split.hip: threads per workgroup")
+ap.add_argument("--wpe", type=int, default=0, help="v6_split.hip: waves per SIMD the register allocation is held to (default: by LDS residency)")
+ap.add_argument("--mode", type=int, default=0, help="0 = radius mode (r = 25), 1 = row mode")
+ap.add_argument("--define", default="", help="extra -D for the build, e.g. LVT_ROW_WALK=2 (becomes part of the library's name)")
 ap.add_argument("--build-only", action="store_true")
 ap.add_argument("--ref", default=os.path.join(ROOT, "lvt_amd", "lib", "liblvt_c.so"), help="library whose matcher output is the reference (default: the shipped one)")
 ap.add_argument("--reps", type=int, default=3)
@@ -22,11 +27,16 @@ ap.add_argument("--coherent", type=int, default=0, help="experiment: 1 = every q
 a = ap.parse_args()
 kern = os.path.abspath(a.kernel)
 tag = os.path.splitext(os.path.basename(kern))[0]
-so = os.path.join(HERE, "_lab_%s%s.so" % (tag, "_stop%d" % a.stop if a.stop else ""))
+if a.mode == 1 and a.instance == "k_hamming_batched<0, 3, 1, 2>":
+    a.instance = "k_hamming_batched<1, 1, 1, 2>"
+if a.split and not a.wpe:
+    a.wpe = 6 if (a.mode == 0 and a.split == 2 and a.threads == 512) else 8   # (three 512-thread workgroups per CU: six waves per SIMD, 80 VGPRs)
+so = os.path.join(HERE, "_lab_%s%s%s.so" % (tag, "_stop%d" % a.stop if a.stop else "", ("_m%d_s%d_t%d_w%d" % (a.mode, a.split, a.threads, a.wpe) if (a.split or a.mode) else "") + ("_" + a.define.replace("=", "") if a.define else "")))
 if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(kern):
     cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wno-inline-asm", "-Wno-unused-value", "-shared",
            "-I" + os.path.join(ROOT, "lvt_amd", "csrc"), '-DLAB_KERNEL="%s"' % kern, "-DLAB_INSTANCE=" + a.instance.replace(" ", "")] + \
-          (["-DLAB_HAS_B"] if a.has_b else []) + (["-DLAB_BAND"] if a.band else []) + ["-DLAB_STOP=%d" % a.stop] + ["-o", so, os.path.join(HERE, "lab.hip")]
+          (["-DLAB_HAS_B"] if a.has_b else []) + (["-DLAB_BAND"] if a.band else []) + ["-DLAB_MODE=%d" % a.mode] + (["-D" + a.define] if a.define else []) + \
+          (["-DLAB_SPLIT=%d" % a.split, "-DLAB_THREADS=%d" % a.threads, "-DLAB_WPE=%d" % a.wpe] if a.split else []) + ["-DLAB_STOP=%d" % a.stop] + ["-o", so, os.path.join(HERE, "lab.hip")]
     subprocess.check_call(cmd)
 if a.build_only:
     sys.exit(0)
@@ -50,10 +60,11 @@ L = C.CDLL(so)
 L.lab_run.restype = C.c_float
 R = C.CDLL(a.ref)
 R.lvt_amd_hamming_match_batched_n.restype = C.c_float
-R.lvt_amd_hamming_match_batched_n(p(qd), p(qxy), p(td), p(txy), p(tf), B, M, N, C.c_float(625.0), 0, H, W, p(ref), None, 1)
+R.lvt_amd_hamming_match_batched_n(p(qd), p(qxy), p(td), p(txy), p(tf), B, M, N, C.c_float(625.0), a.mode, H, W, p(ref), None, 1)
 def run(n, dbg=None):
     return L.lab_run(p(qd), p(qxy), p(td), p(txy), p(tf), B, M, N, C.c_float(625.0), H, W, p(out), n, dbg)
-run(1)
+info = (C.c_longlong * 16)(); info[14] = 777
+run(1, info)
 torch.cuda.synchronize()
 same = bool(torch.equal(out, ref))
 print("%s: output == shipped library: %s" % (tag, same))

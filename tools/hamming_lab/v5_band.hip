@@ -46,12 +46,7 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
 typedef uint32_t v4u __attribute__((ext_vector_type(4)));  // (arrays of the native vector type are promoted to registers; HIP's uint4 struct was not)
 
-// popcount(x) + acc in one instruction (the compiler splits a sum of eight popcounts into four chains and adds them up: 11 instructions for 8)
-__device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
-    uint32_t r;
-    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
-    return r;
-}
+// (bcnt_acc: k_hamming.hip)
 // maximum over the wavefront (all lanes active), broadcast: DPP row shifts + row broadcasts, then lane 63
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t v) {
     v = max(v, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xf, 0xf, false));

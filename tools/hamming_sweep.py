@@ -1,11 +1,15 @@
 #!/usr/bin/env python3
-"""Sweep of the batched Hamming matcher over the micro-benchmark shapes of SURVEY 8(d): batch size, mask kind, descriptor
-statistics.  Prints a markdown table (committed as profiles/*_hamming_sweep.md).
-    python tools/hamming_sweep.py"""
+"""Sweep of the batched Hamming matcher over the micro-benchmark shapes of SURVEY 8(d): B in {1, 64, 1024, 8192} x (M, N) in
+{(256, 600), (1024, 1000), (1500, 1500)} (+ the KITTI-nominal (1000, 1500)) x mask {radius 25 px, row +-2, none} x descriptors
+{iid, planted, ties}.  Prints a markdown table (committed as profiles/r0N_hamming_sweep.md) with the template instance every row runs
+and whether that instance spills registers (profiles/r0N_hamming_instances_registers.txt, read when present).
+    python tools/hamming_sweep.py [--quick]"""
 import os
+import re
 import sys
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(HERE, ".."))
 import torch
 
 import lvt_amd
@@ -34,6 +38,26 @@ def make(B, M, N, variant, g):
     return qd.contiguous(), qxy, td.contiguous(), txy, tf, out
 
 
+def instance(mask, M, N):
+    """the template instance lvt_amd_hamming_match_batched picks (lvt_host.hip): <MODE, NSP, QPT, TPT>"""
+    qpt, tpt = -(-M // 1024), -(-N // 1024)
+    mode, nsp = (1, 1) if mask == "row+-2" else (0, 3) if mask == "radius25" else (0, 0)
+    return "<%d,%d,%d,%d>" % (mode, nsp, qpt, tpt)
+
+
+def spills():
+    """{instance: spilled VGPRs} from the newest profiles/r*_hamming_instances_registers.txt"""
+    pdir = os.path.join(HERE, "..", "profiles")
+    files = sorted(f for f in os.listdir(pdir) if f.endswith("_hamming_instances_registers.txt"))
+    out = {}
+    if files:
+        for line in open(os.path.join(pdir, files[-1])):
+            m = re.match(r"k_hamming_batched(<[0-9,]+>)\s+vgprs\s+(\d+)\s+spilled\s+(\d+)", line)
+            if m:
+                out[m.group(1)] = int(m.group(3))
+    return out
+
+
 def run(B, M, N, mask, variant):
     g = torch.Generator(device=dev)
     g.manual_seed(99)
@@ -44,26 +68,35 @@ def run(B, M, N, mask, variant):
         mode, r2 = 1, 0.0
     else:  # no mask: a radius that covers the image (every query sees every train feature)
         mode, r2 = 0, float((W + H) ** 2)
-    reps = 1 if mask == "none" else 5
-    us = sorted(lvt_amd.hamming_match_batched(qd, qxy, td, txy, tf, r2, mode, H, W, out, launches=reps) for _ in range(4))[1]
+    reps = 1 if mask == "none" else (5 if B >= 1024 else 20)
+    for _ in range(2 if mask == "none" else 4):
+        lvt_amd.hamming_match_batched(qd, qxy, td, txy, tf, r2, mode, H, W, out, launches=reps)
+    us = sorted(lvt_amd.hamming_match_batched(qd, qxy, td, txy, tf, r2, mode, H, W, out, launches=reps) for _ in range(5))[2]
     byts = B * (40.0 * (M + N) + N + 16.0 * M)
     cand = float((out[:, :, 0] >= 0).float().mean().item())
     return us, byts / us / 1e3, cand
 
 
 def main():
+    quick = "--quick" in sys.argv
+    shapes = [(256, 600), (1024, 1000), (1500, 1500), (1000, 1500)]
     rows = []
-    for B in (1, 64, 1024, 2048, 8192):
-        rows.append((B, 1000, 1500, "radius25", "iid"))
-    for B in (64, 2048):
-        rows.append((B, 1000, 1500, "row+-2", "iid"))
-    rows += [(2048, 1000, 1500, "radius25", "planted"), (2048, 1000, 1500, "radius25", "ties"), (2048, 256, 600, "radius25", "iid"),
-             (2048, 1024, 1000, "radius25", "iid"), (2048, 1500, 1500, "radius25", "iid"), (64, 1000, 1500, "none", "iid")]
-    print("| B | M | N | mask | descriptors | us / launch | algorithmic GB/s | % of 8 TB/s | queries with a match |")
-    print("|---|---|---|---|---|---|---|---|---|")
+    for B in (1, 64, 1024, 8192):
+        for M, N in shapes:
+            for mask in ("radius25", "row+-2", "none"):
+                if mask == "none" and B > 64:
+                    continue   # (2.25 M descriptor distances per problem: the no-mask rows stop at 64 problems)
+                for variant in ("iid", "planted", "ties"):
+                    if quick and (variant != "iid" or (M, N) != (1000, 1500)):
+                        continue
+                    rows.append((B, M, N, mask, variant))
+    sp = spills()
+    print("| B | M | N | mask | descriptors | instance | spilled VGPRs | us / launch | algorithmic GB/s | % of 8 TB/s | queries with a match |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
     for B, M, N, mask, variant in rows:
         us, gbs, cand = run(B, M, N, mask, variant)
-        print("| %d | %d | %d | %s | %s | %.1f | %.0f | %.1f | %.2f |" % (B, M, N, mask, variant, us, gbs, gbs / 80.0, cand))
+        inst = instance(mask, M, N)
+        print("| %d | %d | %d | %s | %s | `%s` | %s | %.1f | %.0f | %.1f | %.2f |" % (B, M, N, mask, variant, inst, sp.get(inst, "?"), us, gbs, gbs / 80.0, cand), flush=True)
 
 
 if __name__ == "__main__":

@@ -26,18 +26,20 @@ def stats(src, dst):
     csv.writer(open(dst, "w")).writerows(keep)
     print("==", dst); [print(",".join(r[:4])) for r in keep]
 stats("/tmp/prof_trace", out + "/kernel_stats_single.csv")
-# per-dispatch durations of the radius-mode matcher instance (bench.py warms the clocks up with 80 launches of the ROW-mode instance, so this
-# instance's --stats row holds 3 untimed + the 35 reported launches)
+# per-dispatch durations of the two reported matcher instances (bench.py warms the clocks up with launches of a THIRD instance, <0,5,1,2>, so each
+# reported instance's --stats row holds 3 untimed + the 35 reported launches)
 f = glob.glob("/tmp/prof_trace/**/*kernel_trace.csv", recursive=True)
 if f:
     rd = csv.DictReader(open(f[0]))
-    d = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rd if "k_hamming_batched<0" in r["Kernel_Name"]]
-    d.sort()
-    w = csv.writer(open(out + "/hamming_dispatch_durations.csv", "w")); w.writerow(["dispatch", "duration_ns"])
-    for i, (_, ns) in enumerate(d): w.writerow([i, ns])
-    if len(d) >= 35:
-        last = [ns for _, ns in d[-35:]]
-        print("== matcher dispatches:", len(d), "mean of all %.1f us, of the last 35 (the timed ones) %.1f us" % (sum(ns for _, ns in d) / len(d) / 1e3, sum(last) / 35e3))
+    rows = list(rd)
+    for tag, pat in (("", "k_hamming_batched<0, 3,"), ("_row_mode", "k_hamming_batched<1,")):   # (the warm-up instance is <0, 5, ...>)
+        d = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows if pat in r["Kernel_Name"].replace("<0,3,", "<0, 3,")]
+        d.sort()
+        w = csv.writer(open(out + "/hamming_dispatch_durations%s.csv" % tag, "w")); w.writerow(["dispatch", "duration_ns"])
+        for i, (_, ns) in enumerate(d): w.writerow([i, ns])
+        if len(d) >= 35:
+            last = [ns for _, ns in d[-35:]]
+            print("== matcher dispatches%s:" % tag, len(d), "mean of all %.1f us, of the last 35 (the timed ones) %.1f us" % (sum(ns for _, ns in d) / len(d) / 1e3, sum(last) / 35e3))
 stats("/tmp/prof_batch", out + "/kernel_stats_batch16.csv")
 def pmc(src, name, dst):
     f = glob.glob(src + "/**/*counter_collection.csv", recursive=True)

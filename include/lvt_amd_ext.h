@@ -61,10 +61,17 @@ LVT_API lvt_handle lvt_amd_create_on_device(const lvt_amd_params *p, int sensor_
 LVT_API int lvt_amd_get_device(lvt_handle h);
 /* POOLED handles: independent handles of one device folded into ONE lock-step launch chain by a per-device submission thread (lvt_pool.h).  Independent
  * handles with a launch chain each share the process's hardware queues badly -- 2 / 4 / 8 of them reach 0.95 x / 1.47 x / 0.65 x of one handle's frame
- * rate; as seats of a shared chain they reach what a lock-step batch of that size does.  A pooled handle takes lvt_track, lvt_amd_track_device[_async],
- * lvt_amd_track_async, lvt_amd_wait[_status], lvt_get_status, lvt_amd_reset, lvt_destroy and the per-frame introspection calls, from any thread (one
+ * rate; as seats of a shared chain they reach what a lock-step batch of that size does.  A pooled handle takes ALL FIVE reference entry points (lvt_track,
+ * lvt_track_with_external_corners -- the corner lists ride the frame's step --, lvt_get_status, lvt_create with LVT_AMD_POOL=1, lvt_destroy),
+ * lvt_amd_track_device[_async], lvt_amd_track_async, lvt_amd_wait[_status], lvt_amd_reset and the per-frame introspection calls, from any thread (one
  * thread per handle at a time, as for every handle); its results are those of a solo handle fed the same frames.  Stereo only; every handle of a pool has
- * the same parameters; at most 8 per device; 4 frames outstanding per handle.  Returns NULL when there is no seat or the parameters differ from the pool's.
+ * the same parameters; at most 16 per device; 4 frames deposited or in flight per handle (a fifth deposit waits for the oldest to complete -- never for the
+ * caller's own lvt_amd_wait: results not read yet do not count; beyond 7 un-read frames the oldest result is dropped, as on a solo handle).  A step that
+ * cannot be enqueued hands its frames back with lvt_amd_wait_status() == -1 and the reason in lvt_amd_last_error.  Returns NULL when there is no seat or the
+ * parameters differ from the pool's.
+ * Streams: a lock-step batch of 2 - 28 sequences -- hence every pool -- runs its feature stage on a CU-masked stream (7/8 of the CUs, spread over the XCDs
+ * by the driver's round-robin; LVT_AMD_FEATURE_CUS=0 turns the mask off).  HIP can only create such a stream with default flags: work a caller puts on the NULL
+ * stream synchronises with it (correct, but serialised) -- callers that overlap their own GPU work with tracking should use non-default streams.
  * LVT_AMD_POOL=1 makes lvt_create / lvt_amd_create / lvt_amd_create_on_device hand out pooled handles (falling back to solo ones);
  * lvt_amd_get_ordering() == 2 says a handle is pooled.  A lone synchronous caller pays two thread hand-overs and a chain launched eight sequences wide:
  * pooling is for processes that track several sequences at once. */

@@ -84,6 +84,7 @@ struct FrameArgs {
     const float *depth;
     int img_pitch, depth_pitch;
     int ext_corners, n_ext[2];
+    const float *ext_xy[2];  // external corner lists of THIS frame (a pooled handle's: every seat has its own); nullptr: the context's lists (FrameBuf::ext_xy as created)
     int absent;  // (pooled handles, lvt_host.hip) this sequence has no frame in this lock-step step: every kernel of the step leaves it exactly as it is
 };
 
@@ -99,6 +100,7 @@ __device__ __forceinline__ void feat_begin(Seq &S, const FrameArgs &f, int par) 
     c.absent = f.absent;
     if (c.poison) return;  // (k_gate_buf: the buffer still belongs to an older frame)
     c.ext_corners = f.ext_corners;
+    if (f.ext_corners && f.ext_xy[0]) FB.ext_xy[0] = f.ext_xy[0], FB.ext_xy[1] = f.ext_xy[1];
     c.n_ext[0] = f.n_ext[0];
     c.n_ext[1] = f.n_ext[1];
     c.n_detected[0] = c.n_detected[1] = 0;

@@ -720,7 +720,7 @@ static void enqueue_frame(Context *c) {
         c->switched_at = (long)c->enq;
     }
     const FrameArgs *fa = c->h_fargs + (size_t)slot * B;
-    const int ext = fa[0].ext_corners;
+    const int ext = (B == 1) ? fa[0].ext_corners : 0;  // (a pool's step may mix seats with and without external corners: k_cells is launched, cell_begin skips the seats that bring their own)
     hipStream_t sf = c->stream_f, st = c->stream;
     for (int i = 0; i < Context::PROF_SLOTS; i++) c->ev_used[i] = false;
     // ---- feature stage (stream_f): may start as soon as the tracking chain of frame enq-NPAR released this buffer
@@ -1403,6 +1403,7 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
     }
     // (the previous synchronous call may have returned on its early pose: its frame's tail -- staged update, triangulation -- runs
     //  while this call copies the new images into the staging buffer of THIS frame's feature buffer; the drain comes after)
+    flush_pending(c);  // a held lvt_amd_track_async frame goes out FIRST: it takes a frame number, and this frame's buffers (images, corner lists) are chosen by number
     const int par = (int)(c->enq % NPAR);
     hipStream_t sf = c->stream_f;
     const size_t nbytes = (size_t)n_rows * n_cols;
@@ -1471,6 +1472,7 @@ static void upload_and_track(Context *c, const unsigned char *left, const void *
         };
     }
     f.ext_corners = ext;
+    f.ext_xy[0] = f.ext_xy[1] = nullptr;  // (the context's own lists, d_ext[par])
     f.absent = 0;
     f.n_ext[0] = ncl;
     f.n_ext[1] = ncr;
@@ -1645,18 +1647,13 @@ LVT_API void lvt_amd_track_rgbd(lvt_handle h, const unsigned char *gray, const f
 LVT_API void lvt_track_with_external_corners(lvt_handle h, unsigned char *left, unsigned char *right, int n_rows, int n_cols,
                                              double corners_left[][2], int n_corners_left, double corners_right[][2],
                                              int n_corners_right, double R[3][3], double t[3]) {
-    if (!is_ctx(h)) return;  // (not offered on pooled handles)
-    Context *c = static_cast<Context *>(h);
-    DeviceGuard guard(c);
+    if (!is_ctx(h) && !is_slot(h)) return;
     try {
-        if (c->sensor != 1) return;
         if (n_corners_left < 0 || n_corners_right < 0) return;
-        if (n_corners_left > EXT_MAX || n_corners_right > EXT_MAX) {  // (the reference takes any number; here the lists are cut -- never silently)
-            char buf[160];
-            std::snprintf(buf, sizeof(buf), "lvt_track_with_external_corners: %d / %d corners, only the first %d of a list are used", n_corners_left,
+        char cut[160] = "";
+        if (n_corners_left > EXT_MAX || n_corners_right > EXT_MAX)  // (the reference takes any number; here the lists are cut -- never silently)
+            std::snprintf(cut, sizeof(cut), "lvt_track_with_external_corners: %d / %d corners, only the first %d of a list are used", n_corners_left,
                           n_corners_right, EXT_MAX);
-            c->set_error(buf);
-        }
         const int ncl = std::min(n_corners_left, EXT_MAX), ncr = std::min(n_corners_right, EXT_MAX);
         std::vector<float> cl(2 * (size_t)ncl + 2), cr(2 * (size_t)ncr + 2);
         for (int i = 0; i < ncl; i++) {  // doubles narrowed to float (lvt_c.cpp:104-117)
@@ -1667,6 +1664,24 @@ LVT_API void lvt_track_with_external_corners(lvt_handle h, unsigned char *left, 
             cr[2 * i] = (float)corners_right[i][0];
             cr[2 * i + 1] = (float)corners_right[i][1];
         }
+        if (is_slot(h)) {  // a pooled handle: the lists are deposited with the frame and ride its lock-step step (lvt_pool.h)
+            PoolSlot *S = static_cast<PoolSlot *>(h);
+            slot_drain(S);
+            const float *const lists[2] = {cl.data(), cr.data()};
+            const int counts[2] = {ncl, ncr};
+            if (slot_submit(S, left, right, n_rows, n_cols, 0, true, lists, counts) != 0) return;
+            if (cut[0]) {
+                std::lock_guard<std::mutex> g(S->pool->mu);
+                S->err = cut;
+            }
+            (void)slot_collect(S);
+            slot_result(S, R, t);
+            return;
+        }
+        Context *c = static_cast<Context *>(h);
+        DeviceGuard guard(c);
+        if (c->sensor != 1) return;
+        if (cut[0]) c->set_error(cut);
         upload_and_track(c, left, right, false, n_rows, n_cols, 1, cl.data(), ncl, cr.data(), ncr, R, t);
     } catch (...) {
     }

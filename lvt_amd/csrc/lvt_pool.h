@@ -21,9 +21,10 @@
 
 namespace lvt {
 
-constexpr int POOL_SLOTS = 8;   // sequences of the shared batch context
+constexpr int POOL_SLOTS = 16;  // sequences of the shared batch context (a step is launched for the seats in use: empty upper seats cost memory only)
 constexpr int POOL_DEPTH = 3;   // lock-step steps in flight (bench.py's batch leg: 3 beats 2 and 4)
-constexpr int POOL_SLOT_QUEUE = 4;  // frames one slot may have deposited + in flight (a fifth deposit waits)
+constexpr int POOL_SLOT_QUEUE = 4;  // frames one slot may have deposited + in flight (a fifth deposit waits); collected, un-read results do not count --
+                                    // but a slot keeps at most RING - 1 frames un-read in all, like a solo handle (make_room)
 
 struct Pool;
 struct SlotFrame {   // a collected frame of one slot
@@ -39,6 +40,8 @@ struct PoolSlot {
         int pitch;
         bool host;
         int stage;
+        bool ext = false;        // lvt_track_with_external_corners: the lists lie in this slot's pinned h_ext[stage] ([left | right], EXT_MAX corners each)
+        int n_ext[2] = {0, 0};
     };
     std::deque<Pending> pending;       // deposited, not yet in a step
     int in_flight = 0;                 // ... inside enqueued steps
@@ -48,6 +51,8 @@ struct PoolSlot {
     std::string err;
     uint8_t *h_stage[POOL_SLOT_QUEUE] = {}, *h_stage_dev[POOL_SLOT_QUEUE] = {};   // pinned staging of host images [left | right]
     uint8_t *d_img[POOL_SLOT_QUEUE][2] = {};                                        // their pitched device planes
+    float *h_ext[POOL_SLOT_QUEUE] = {};                                             // pinned external-corner lists (first use of lvt_track_with_external_corners)
+    float *d_ext[POOL_SLOT_QUEUE][2] = {};
     size_t stage_img = 0;
 };
 
@@ -98,6 +103,8 @@ static void pool_enqueue_step(Pool *P, std::unique_lock<std::mutex> &lk) {
     P->slot_frames += __builtin_popcount(mask);
     P->busy = true;
     lk.unlock();
+    const unsigned long long enq_before = c->enq;
+    bool failed = false;
     try {
         make_room(c);  // (POOL_DEPTH < RING - 1: never blocks)
         const int par_slot = (int)(c->enq % RING);
@@ -120,12 +127,40 @@ static void pool_enqueue_step(Pool *P, std::unique_lock<std::mutex> &lk) {
                 f.img[0] = p.img[0], f.img[1] = p.img[1];
                 f.img_pitch = p.pitch;
             }
+            if (p.ext) {  // the corner lists travel with the frame: copied from the slot's pinned list into its device lists in front of the feature stage
+                PoolSlot *S = P->slots[s];
+                f.ext_corners = 1;
+                for (int e = 0; e < 2; e++) {
+                    f.n_ext[e] = p.n_ext[e];
+                    f.ext_xy[e] = S->d_ext[p.stage][e];
+                    if (p.n_ext[e])
+                        HIPCHK(c, hipMemcpyAsync(S->d_ext[p.stage][e], S->h_ext[p.stage] + (size_t)e * 2 * EXT_MAX, sizeof(float) * 2 * (size_t)p.n_ext[e],
+                                                 hipMemcpyHostToDevice, c->stream_f));
+                }
+            }
         }
         enqueue_frame(c);
     } catch (...) {
+        failed = true;
     }
     lk.lock();
     P->busy = false;
+    if (failed && c->enq == enq_before) {
+        // the step never reached the launch chain: nothing will complete for it.  Its frames are handed back as FAILED records (state -1: what
+        // lvt_amd_wait_status returns for an error) with the reason on every handle that had a frame in it -- never the previous step's record.
+        P->inflight.pop_back();
+        P->steps--;
+        P->slot_frames -= __builtin_popcount(mask);
+        for (int s = 0; s < POOL_SLOTS; s++) {
+            PoolSlot *S = P->slots[s];
+            if (!S || !(mask & (1u << s))) continue;
+            SlotFrame fr = S->last;
+            fr.rec.state = -1;
+            S->results.push_back(fr);
+            S->in_flight--;
+            S->err = c->err.empty() ? std::string("a pooled step could not be enqueued (the frame was NOT tracked)") : c->err;
+        }
+    }
     P->cv_done.notify_all();
 }
 
@@ -265,8 +300,11 @@ static void pool_leave(PoolSlot *S) {
         DeviceGuard guard(P->ctx);
         for (int k = 0; k < POOL_SLOT_QUEUE; k++) {
             if (S->h_stage[k]) (void)hipHostFree(S->h_stage[k]);
-            for (int e = 0; e < 2; e++)
+            if (S->h_ext[k]) (void)hipHostFree(S->h_ext[k]);
+            for (int e = 0; e < 2; e++) {
                 if (S->d_img[k][e]) (void)hipFree(S->d_img[k][e]);
+                if (S->d_ext[k][e]) (void)hipFree(S->d_ext[k][e]);
+            }
         }
     }
     const bool last = P->live == 0;
@@ -288,7 +326,9 @@ static void pool_leave(PoolSlot *S) {
 }
 
 // ---- a slot's tracking calls ---------------------------------------------------------------------------------------------------------------
-static int slot_submit(PoolSlot *S, const uint8_t *l, const uint8_t *r, int rows, int cols, int pitch, bool host) {
+// corners: nullptr, or {left list, right list} as x y floats with their counts (lvt_track_with_external_corners; host frames only)
+static int slot_submit(PoolSlot *S, const uint8_t *l, const uint8_t *r, int rows, int cols, int pitch, bool host, const float *const corners[2] = nullptr,
+                       const int n_corners[2] = nullptr) {
     Pool *P = S->pool;
     Context *c = P->ctx;
     if (rows != c->prm.H || cols != c->prm.W || (!host && (pitch & 15)) || !l || !r) {
@@ -297,31 +337,68 @@ static int slot_submit(PoolSlot *S, const uint8_t *l, const uint8_t *r, int rows
         return -1;
     }
     std::unique_lock<std::mutex> lk(P->mu);
-    P->cv_done.wait(lk, [&] { return (int)S->pending.size() + S->in_flight + (int)S->results.size() < POOL_SLOT_QUEUE; });
+    // A staging slot is free again once its frame's step has been collected, so only frames deposited or in flight count here.  Collected results the
+    // caller has not read yet do NOT: a single-threaded caller that enqueues a fifth frame before its first lvt_amd_wait must not wait for itself.  Like a
+    // solo handle (make_room collects its oldest frame), a slot that runs further ahead than RING - 1 frames loses its oldest un-read result.
+    P->cv_done.wait(lk, [&] { return (int)S->pending.size() + S->in_flight < POOL_SLOT_QUEUE; });
+    while (!S->results.empty() && (int)S->results.size() + (int)S->pending.size() + S->in_flight + 1 > RING - 1) {
+        S->last = S->results.front();
+        S->results.pop_front();
+    }
     PoolSlot::Pending p;
     p.img[0] = l, p.img[1] = r, p.pitch = pitch, p.host = host, p.stage = (int)(S->submitted % POOL_SLOT_QUEUE);
+    S->submitted++;  // (the staging slot is reserved before the lock is dropped for the copy: a second thread depositing on this handle takes the next one)
     if (host) {
         const size_t nbytes = (size_t)rows * cols;
-        if (!S->h_stage[p.stage]) {  // (first use of this staging slot; HIP allocations under the pool's lock: the submission thread is not inside the chain's calls for long)
+        if (!S->d_img[p.stage][1]) {  // (first use of this staging slot; HIP allocations under the pool's lock: the submission thread is not inside the chain's calls for long)
             DeviceGuard guard(c);
             S->stage_img = (nbytes + 15) & ~(size_t)15;
             if (hipHostMalloc((void **)&S->h_stage[p.stage], 2 * S->stage_img, hipHostMallocDefault) != hipSuccess ||
                 hipHostGetDevicePointer((void **)&S->h_stage_dev[p.stage], S->h_stage[p.stage], 0) != hipSuccess ||
                 hipMalloc((void **)&S->d_img[p.stage][0], (size_t)c->pitch * rows + 64) != hipSuccess ||
                 hipMalloc((void **)&S->d_img[p.stage][1], (size_t)c->pitch * rows + 64) != hipSuccess) {
-                S->err = "out of memory for a pooled handle's staging buffers";
+                // nothing half-built stays behind: the next deposit on this staging slot starts over
+                if (S->h_stage[p.stage]) (void)hipHostFree(S->h_stage[p.stage]);
+                if (S->d_img[p.stage][0]) (void)hipFree(S->d_img[p.stage][0]);
+                if (S->d_img[p.stage][1]) (void)hipFree(S->d_img[p.stage][1]);
+                S->h_stage[p.stage] = S->h_stage_dev[p.stage] = nullptr;
+                S->d_img[p.stage][0] = S->d_img[p.stage][1] = nullptr;
+                (void)hipGetLastError();
+                S->err = "out of memory for a pooled handle's staging buffers (the frame was NOT enqueued)";
                 return -1;
             }
         }
+        if (corners) {
+            if (!S->d_ext[p.stage][1]) {
+                DeviceGuard guard(c);
+                if (hipHostMalloc((void **)&S->h_ext[p.stage], sizeof(float) * 4 * (size_t)EXT_MAX, hipHostMallocDefault) != hipSuccess ||
+                    hipMalloc((void **)&S->d_ext[p.stage][0], sizeof(float) * 2 * (size_t)EXT_MAX) != hipSuccess ||
+                    hipMalloc((void **)&S->d_ext[p.stage][1], sizeof(float) * 2 * (size_t)EXT_MAX) != hipSuccess) {
+                    if (S->h_ext[p.stage]) (void)hipHostFree(S->h_ext[p.stage]);
+                    if (S->d_ext[p.stage][0]) (void)hipFree(S->d_ext[p.stage][0]);
+                    if (S->d_ext[p.stage][1]) (void)hipFree(S->d_ext[p.stage][1]);
+                    S->h_ext[p.stage] = nullptr;
+                    S->d_ext[p.stage][0] = S->d_ext[p.stage][1] = nullptr;
+                    (void)hipGetLastError();
+                    S->err = "out of memory for a pooled handle's corner lists (the frame was NOT enqueued)";
+                    return -1;
+                }
+            }
+            p.ext = true;
+            p.n_ext[0] = n_corners[0], p.n_ext[1] = n_corners[1];
+        }
         uint8_t *dst = S->h_stage[p.stage];
+        float *cdst = S->h_ext[p.stage];
         const size_t simg = S->stage_img;
         lk.unlock();  // (the copy of 0.9 MB does not hold the pool up: this staging slot is ours -- at most POOL_SLOT_QUEUE frames of a slot exist)
         std::memcpy(dst, l, nbytes);
         std::memcpy(dst + simg, r, nbytes);
+        if (corners)
+            for (int e = 0; e < 2; e++)
+                if (n_corners[e]) std::memcpy(cdst + (size_t)e * 2 * EXT_MAX, corners[e], sizeof(float) * 2 * (size_t)n_corners[e]);
         lk.lock();
     }
     S->pending.push_back(p);
-    S->submitted++;
     P->cv_work.notify_one();
     return 0;
 }

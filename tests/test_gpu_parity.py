@@ -495,6 +495,102 @@ def test_pooled_handles_equal_the_oracle(hip_lib, oracle_lib):
     h.close()
 
 
+def test_all_five_reference_symbols_on_pooled_handles(hip_lib, oracle_lib, tmp_path, monkeypatch):
+    """LVT_AMD_POOL=1: every handle lvt_create returns is a seat of the device's shared chain -- and the reference's five entry points
+    (lvt_c.h:57-62: lvt_create, lvt_track, lvt_track_with_external_corners, lvt_get_status, lvt_destroy) all work on it.  Two handles side by side,
+    one alternating lvt_track and lvt_track_with_external_corners (the corner lists ride the frame's step), the other plain lvt_track: every frame
+    of both against its own oracle with the full stage diff."""
+    import threading
+    from oracle import pyoracle as O
+    from parity_util import pose_errors
+    cases = [make_case("kitti", 70 + k, 0.5) for k in range(2)]
+    prm = cases[0][1]
+    prm.write_yaml(str(tmp_path / "vo_config.yaml"))
+    monkeypatch.setenv("LVT_AMD_POOL", "1")
+    hs = [hip_lib.LvtSystem.create_from_file(str(tmp_path / "vo_config.yaml"), 1) for _ in range(2)]   # lvt_create
+    assert all(h.ordering() == "pooled" for h in hs)
+    fprm = hip_lib.LvtParameters.from_file(str(tmp_path / "vo_config.yaml"))
+    orcs = [O.Oracle(fprm, 1) for _ in range(2)]
+    frames = [[cases[k][0].render_stereo(i) for i in range(12)] for k in range(2)]
+    fails = [[], []]
+    rng = np.random.default_rng(11)
+
+    def work(k):
+        for i in range(12):
+            L, R = frames[k][i]
+            if k == 0 and i % 2 == 1:   # external corners: the oracle's own detections, some moved to fractional positions
+                xl, _, _, _ = O.compute_features(L, fprm)
+                xr, _, _, _ = O.compute_features(R, fprm)
+                cl = xl.astype(np.float64); cr = xr.astype(np.float64)
+                cl[::7] += rng.uniform(-0.5, 0.5, size=cl[::7].shape)
+                cr[::5] += 0.5
+                Ro, to = orcs[k].track_with_external_corners(L, R, cl, cr)
+                Rh, th = hs[k].track_with_external_corners(L, R, cl, cr)     # lvt_track_with_external_corners
+            else:
+                Ro, to = orcs[k].track(L, R)
+                Rh, th = hs[k].track(L, R)                                   # lvt_track
+            msgs = diff_frame(hs[k], orcs[k])
+            e_t, e_R = pose_errors(Rh, th, Ro, to)
+            if e_t > POSE_TOL or e_R > POSE_TOL:
+                msgs.append(f"pose e_t={e_t:.3e} e_R={e_R:.3e}")
+            if hs[k].get_state() != orcs[k].status:                          # lvt_get_status
+                msgs.append(f"status {hs[k].get_state()} != {orcs[k].status}")
+            if hs[k].last_error():
+                msgs.append(hs[k].last_error())
+            if msgs:
+                fails[k].append((i, msgs[:4]))
+                return
+    ths = [threading.Thread(target=work, args=(k,)) for k in range(2)]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    assert fails == [[], []], fails
+    # too many corners: cut, and SAID so (never silent) -- on a pooled handle as on a solo one
+    L, R = frames[0][0]
+    many = np.stack(np.meshgrid(np.arange(30, 230, dtype=np.float64), np.arange(30, 130, dtype=np.float64)), -1).reshape(-1, 2)   # 20 000 > 16 384
+    hs[0].track_with_external_corners(L, R, many, many[:100])
+    err = hs[0].last_error()                    # (the cut is reported at the call, the feature-slot overflow of the 16 384 corners behind it: either way not silent)
+    assert "only the first" in err or "capacity" in err, err
+    for h in hs: h.close()                                                   # lvt_destroy
+
+
+def test_a_pooled_handle_takes_more_frames_than_its_queue_before_the_first_wait(hip_lib):
+    """one thread enqueues SEVEN asynchronous frames on a pooled handle before it collects the first (the queue bound is four frames deposited or in
+    flight: results not read yet must not count, or the caller waits for itself); the poses equal a solo handle's, frame for frame"""
+    import threading
+    import torch
+    world, prm, sensor = make_case("kitti", 33, 0.5)
+    n = 14
+    H, W = world.H, world.W
+    pitch = ((W + 63) // 64) * 64
+    fr = torch.zeros((n, 2, H, pitch), dtype=torch.uint8, device="cuda")
+    for i in range(n):
+        fr[i, :, :, :W] = world.render_stereo_torch(i, device="cuda")
+    torch.cuda.synchronize()
+    solo = hip_lib.LvtSystem.create(prm, 1)
+    ref = [solo.track_device(fr[i, 0].data_ptr(), fr[i, 1].data_ptr(), H, W, pitch) for i in range(n)]
+    solo.close()
+    h = hip_lib.LvtSystem.create(prm, 1, pooled=True)
+    got = []
+
+    def work():
+        for i in range(7):
+            h.track_device_async(fr[i, 0].data_ptr(), fr[i, 1].data_ptr(), H, W, pitch)
+        for i in range(7, n):
+            got.append(h.wait())
+            h.track_device_async(fr[i, 0].data_ptr(), fr[i, 1].data_ptr(), H, W, pitch)
+        for _ in range(7):
+            got.append(h.wait())
+    t = threading.Thread(target=work, daemon=True)
+    t.start()
+    t.join(timeout=60)
+    assert not t.is_alive(), "the depositor waits for its own lvt_amd_wait (deadlock)"
+    assert len(got) == n
+    for i in range(n):
+        assert np.array_equal(got[i][0], ref[i][0]) and np.array_equal(got[i][1], ref[i][1]), f"frame {i}"
+    assert h.last_error() == ""
+    h.close()
+
+
 def test_pooled_async_handles_equal_a_solo_handle(hip_lib):
     """four pooled handles fed the SAME device-resident sequence asynchronously (three frames in flight each) from four threads that start and stop
     at different times: every handle's poses equal a solo handle's, bit for bit"""

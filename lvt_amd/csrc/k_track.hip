@@ -2092,6 +2092,9 @@ __device__ bool triangulate_pair(const Params &p, const double *cml, const doubl
     rhs[3] = -(a2y * cmr[11] - cmr[7]);
     double x[3];
     if (!ls_solve_4x3(A, rhs, x)) return false;
+    // the two camera matrices are read from LDS AGAIN for the visibility tests (the pointers are laundered: the compiler would otherwise keep all 24
+    // doubles in registers across the least-squares solve, and a 1024-thread workgroup has 128 VGPRs per lane: 19 of them went to scratch)
+    asm volatile("" : "+v"(cml), "+v"(cmr));
     double ul, vl, ur, vr;
     if (!is_point_visible(x, cml, p, ul, vl) || !is_point_visible(x, cmr, p, ur, vr)) return false;
     {

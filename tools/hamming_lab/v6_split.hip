@@ -304,21 +304,30 @@ __global__ __launch_bounds__(T) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) v
                 const int s0 = (int)(W & 0xFFFFu), len = (int)(W >> 16);
                 uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
                 if (len > 0) {
-                    uint4 a0 = s_dlo[s0], a1 = s_dhi[s0];
-                    uint32_t id = s_idx[s0];
-                    if (!recheck) {
-#pragma unroll 2
-                        for (int v = 0; v < len; v++) {  // software-pipelined by one candidate; the last prefetch reads one past (valid LDS)
-                            const uint4 b0 = s_dlo[s0 + v + 1], b1 = s_dhi[s0 + v + 1];
-                            const uint32_t idn = s_idx[s0 + v + 1];
-                            const uint32_t key = (hamming256(d0, d1, d2, d3, a0, a1) << 16) | id;
-                            k2 = min(k2, max(k1, key));
-                            k1 = min(k1, key);
-                            a0 = b0, a1 = b1, id = idn;
+                    if (!recheck) {  // two candidates per trip, by value (k_hamming.hip: row_walk_lean)
+                        const uint4 *plo = s_dlo + s0, *phi = s_dhi + s0;
+                        const uint16_t *pid = s_idx + s0;
+                        int v = 0;
+                        for (; v + 2 <= len; v += 2) {
+                            const uint4 a0 = plo[v], a1 = phi[v], b0 = plo[v + 1], b1 = phi[v + 1];
+                            const uint32_t ia = pid[v], ib = pid[v + 1];
+                            const uint32_t ka = (hamming256(d0, d1, d2, d3, a0, a1) << 16) | ia, kb = (hamming256(d0, d1, d2, d3, b0, b1) << 16) | ib;
+                            const uint32_t lo = min(ka, kb), hi = max(ka, kb);
+                            const uint32_t t = max(k1, lo);
+                            k1 = min(k1, lo);
+                            k2 = min(t, min(k2, hi));
+                        }
+                        if (v < len) {
+                            const uint4 a0 = plo[v], a1 = phi[v];
+                            const uint32_t ka = (hamming256(d0, d1, d2, d3, a0, a1) << 16) | pid[v];
+                            k2 = min(k2, max(k1, ka));
+                            k1 = min(k1, ka);
                         }
                     } else {
                         const float2 p = qxy[q];
                         const float fy0 = (float)max((int)p.y - ROW_RADIUS, 0), fy1 = (float)min((int)p.y + ROW_RADIUS, a.img_rows);
+                        uint4 a0 = s_dlo[s0], a1 = s_dhi[s0];
+                        uint32_t id = s_idx[s0];
                         for (int v = 0; v < len; v++) {
                             const uint4 b0 = s_dlo[s0 + v + 1], b1 = s_dhi[s0 + v + 1];
                             const uint32_t idn = s_idx[s0 + v + 1];

@@ -547,7 +547,7 @@ class HipBackend:
         S0, n = args.batch_seqs, args.batch_frames
         if S0 <= 1 or n <= 4:
             return {}
-        sweep_sizes = sorted(set([12, 16, 24, 32, S0]))
+        sweep_sizes = sorted(set([12, 16, 24, 32, 48, S0]))
         Smax = max(sweep_sizes + [64])
         worlds = [self.make_world("kitti", seed=100 + s) for s in range(Smax)]
         fr, H, W, pitch = self._render(worlds, n)

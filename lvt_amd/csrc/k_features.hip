@@ -114,7 +114,7 @@ __device__ __forceinline__ void feat_begin(Seq &S, const FrameArgs &f, int par) 
 
 // BEGIN = single sequence: `fa` carries the frame's inputs, block (0, 0, 0) publishes them for the later kernels
 template <bool BEGIN>
-__global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par, int z0) {  // z0: first image of this launch (a batch's images may come in several launches)
+__global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par, int z0, int box) {  // z0: first image of this launch (a batch's images may come in several launches); box: 0 = no box-sum plane (k_brief_img builds the sums from the image)
     const int seq = (blockIdx.z + z0) >> 1, eye = (blockIdx.z + z0) & 1;
     Seq &S = seqs[seq];
     FrameBuf &FB = S.fb[par];
@@ -168,7 +168,7 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par,
     }
     __syncthreads();
     // ---- horizontal 9-sums of four adjacent columns from one 12-byte segment: v_sad_u8 against 0 adds the four bytes of a word
-    for (int idx = tid; idx < TILE_H * (TS_W / 4); idx += 256) {
+    for (int idx = tid; box && idx < TILE_H * (TS_W / 4); idx += 256) {
         const int r = idx >> 4, j = idx & 15;
         const uint32_t w0 = tile[r][j], w1 = tile[r][j + 1], w2 = tile[r][j + 2];
         const uint32_t s0 = __builtin_amdgcn_sad_u8(w0, 0u, __builtin_amdgcn_sad_u8(w1, 0u, w2 & 255u));
@@ -330,14 +330,16 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par,
     if (gy < H) {
         const int pp = S.plane_pitch;
         *reinterpret_cast<uint32_t *>(FB.score[eye] + (size_t)gy * pp + x0 + 4 * tx) = packed;
-        uint2 o = make_uint2(0u, 0u);  // four u16 sums; 81 * 255 < 2^16, so whole-word adds never carry between the halves
+        if (box) {
+            uint2 o = make_uint2(0u, 0u);  // four u16 sums; 81 * 255 < 2^16, so whole-word adds never carry between the halves
 #pragma unroll
-        for (int d = 0; d < 9; d++) {
-            const uint2 h = hs[ty + d][tx];
-            o.x += h.x;
-            o.y += h.y;
+            for (int d = 0; d < 9; d++) {
+                const uint2 h = hs[ty + d][tx];
+                o.x += h.x;
+                o.y += h.y;
+            }
+            *reinterpret_cast<uint2 *>(FB.boxsum[eye] + (size_t)gy * pp + x0 + 4 * tx) = o;
         }
-        *reinterpret_cast<uint2 *>(FB.boxsum[eye] + (size_t)gy * pp + x0 + 4 * tx) = o;
     }
 }
 
@@ -1978,6 +1980,163 @@ __global__ __launch_bounds__(256) void k_brief(SeqArg<BV> sa, const Seq *seqs, i
                     fc.poison = 0;
                 }
                 S.ctl->dbg[47] = (long long)wall_clock64();  // (written from the feature stream: the frame it belongs to may differ)
+                __threadfence();
+                atomicExch(&fc.feat_seq, publish_seq);
+            }
+        }
+    }
+}
+
+
+// =================================================================================================
+// k_brief_img : BRIEF-256 WITHOUT the box-sum plane (LVT_AMD_BRIEF_FROM_IMAGE=1; verdict r4 item 2).  The wave copies the key point's 57 x 57 u8 patch
+// (the 49 x 49 sample window + the 9 x 9 kernel's margin) into LDS, builds the horizontal 9-sums of all its rows there (v_sad_u8 on whole words, as
+// k_score does), and every test adds nine of them per box.  Same sums of the same 81 pixels as the plane holds: descriptors bit-identical.
+// =================================================================================================
+constexpr int BI_R = BR_R + 4, BI_ROWS = 2 * BI_R + 1;   // patch rows (57)
+constexpr int BI_DW = 16;                               // dwords per patch row: columns x0 .. x0 + 63, x0 = (cx - 28) & ~3 (57 + 3 <= 60 used)
+constexpr int BI_G = 13;                                // groups of four horizontal sums per row: local columns 0 .. 51
+constexpr int BI_PATCH_DW = BI_ROWS * BI_DW, BI_LOADS = (BI_PATCH_DW + 63) / 64;
+constexpr int BI_GROUPS = BI_ROWS * BI_G, BI_GLOOPS = (BI_GROUPS + 63) / 64;
+template <bool BV>
+__global__ __launch_bounds__(256) void k_brief_img(SeqArg<BV> sa, const Seq *seqs, int par, seq_t publish_seq) {
+    const int planes = gridDim.y * gridDim.z;
+    int lid = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    int plane = lid / gridDim.x, bx = lid % gridDim.x;
+    if ((planes & 7) == 0) {
+        const int j = lid >> 3;
+        plane = (lid & 7) + 8 * (j / gridDim.x);
+        bx = j % gridDim.x;
+    }
+    const Seq &S = BV ? sa.get() : seqs[plane / gridDim.y];
+    const FrameBuf &FBd = seqs[plane / gridDim.y].fb[par];  // per-frame image pointers
+    const int eye = plane % gridDim.y;
+    const FrameBuf &FB = S.fb[par];
+    const Feat &F = FB.feat[eye];
+    const bool poison = FB.fc->poison != 0;
+    const int n = poison ? 0 : *F.n;
+    const int lane = lane_id();
+    const int wpb = blockDim.x >> 6;
+    __shared__ uint32_t s_patch[4][BI_PATCH_DW + 64];
+    __shared__ __attribute__((aligned(8))) uint2 s_hs[4][BI_GROUPS + 64];
+    uint32_t *pat = s_patch[wave_id()];
+    uint2 *hs = s_hs[wave_id()];
+    typedef uint16_t __attribute__((may_alias)) u16_alias;
+    const u16_alias *hs16 = reinterpret_cast<const u16_alias *>(hs);   // [row][52] horizontal sums
+    const int W = S.prm.W, H = S.prm.H;
+    const uint8_t *img = FBd.img[eye];
+    const int pitch = FBd.img_pitch;  // (a multiple of 16: rows are word-aligned)
+    int goff[BI_LOADS];
+#pragma unroll
+    for (int i = 0; i < BI_LOADS; i++) {
+        const int e = min(lane + 64 * i, BI_PATCH_DW - 1);
+        goff[i] = (e / BI_DW) * (pitch >> 2) + (e % BI_DW);
+    }
+    int ta[4], tb[4];
+    signed char tq[4][4];
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+        const signed char *t = c_brief[64 * w + 8 * (lane >> 3) + 7 - (lane & 7)];
+        tq[w][0] = t[0], tq[w][1] = t[1], tq[w][2] = t[2], tq[w][3] = t[3];
+        // box (dy, dx): rows cy + dy - 4 .. + 4 = patch rows dy + 24 .. dy + 32; left column cx + dx - 4 = local column dx + 24 + (cx - 28 - x0)
+        ta[w] = (t[0] + BR_R) * (4 * BI_G) + t[1] + BR_R;
+        tb[w] = (t[2] + BR_R) * (4 * BI_G) + t[3] + BR_R;
+    }
+    auto centre = [&](int i, int &cy, int &cx) {
+        cy = (int)((double)F.by[i] + 0.5), cx = (int)((double)F.bx[i] + 0.5);
+    };
+    // the patch's 64 columns must lie inside the row pitch and its rows inside the image
+    auto inside = [&](int cy, int cx) { return cx - BI_R >= 0 && ((cx - BI_R) & ~3) + 64 <= pitch && cx + BI_R < W && cy - BI_R >= 0 && cy + BI_R < H; };
+    int stride = gridDim.x * wpb;
+    int i = bx * wpb + wave_id();
+    int i_end = n;
+    if ((planes & 7) != 0 && (gridDim.x & 7) == 0) {
+        const int eighth = (n + 7) >> 3, x = bx & 7;
+        stride = (gridDim.x >> 3) * wpb;
+        i = x * eighth + (bx >> 3) * wpb + wave_id();
+        i_end = min(n, (x + 1) * eighth);
+    }
+    uint32_t v[BI_LOADS];
+    int cy = 0, cx = 0;
+    bool fast = false;
+    auto fetch = [&](int cy_, int cx_) {
+        typedef const uint32_t __attribute__((address_space(1))) gu32;
+        gu32 *src = (gu32 *)(reinterpret_cast<const uint32_t *>(img + (size_t)(cy_ - BI_R) * pitch) + (((cx_ - BI_R) & ~3) >> 2));
+#pragma unroll
+        for (int k = 0; k < BI_LOADS; k++) v[k] = src[goff[k]];
+    };
+    // clipped 9 x 9 sum around (iy, ix) straight from the image (key points whose patch leaves the image: external corners at the border only)
+    auto box_slow = [&](int iy, int ix) -> int {
+        int sum = 0;
+        for (int y = max(iy - 4, 0); y <= min(iy + 4, H - 1); y++)
+            for (int x = max(ix - 4, 0); x <= min(ix + 4, W - 1); x++) sum += img[(size_t)y * pitch + x];
+        return sum;
+    };
+    if (i < i_end) {
+        centre(i, cy, cx);
+        fast = inside(cy, cx);
+        if (fast) fetch(cy, cx);
+    }
+    for (; i < i_end; i += stride) {
+        uint64_t word[4];
+        const int inext = i + stride;
+        int ncy = 0, ncx = 0;
+        bool nfast = false;
+        if (inext < i_end) {
+            centre(inext, ncy, ncx);
+            nfast = inside(ncy, ncx);
+        }
+        if (fast) {
+#pragma unroll
+            for (int k = 0; k < BI_LOADS; k++) pat[lane + 64 * k] = v[k];
+            if (nfast) fetch(ncy, ncx);  // in flight while this key point is evaluated
+            // horizontal 9-sums: group g = (row, four local columns 4 j .. 4 j + 3) from the 12-byte segment at word j
+#pragma unroll
+            for (int k = 0; k < BI_GLOOPS; k++) {
+                const int g = min(lane + 64 * k, BI_GROUPS - 1);
+                const int r = g / BI_G, j = g - r * BI_G;
+                const uint32_t w0 = pat[r * BI_DW + j], w1 = pat[r * BI_DW + j + 1], w2 = pat[r * BI_DW + j + 2];
+                const uint32_t s0 = __builtin_amdgcn_sad_u8(w0, 0u, __builtin_amdgcn_sad_u8(w1, 0u, w2 & 255u));
+                const uint32_t s1 = s0 - (w0 & 255u) + ((w2 >> 8) & 255u);
+                const uint32_t s2 = s1 - ((w0 >> 8) & 255u) + ((w2 >> 16) & 255u);
+                const uint32_t s3 = s2 - ((w0 >> 16) & 255u) + (w2 >> 24);
+                hs[lane + 64 * k] = make_uint2(s0 | (s1 << 16), s2 | (s3 << 16));  // (the tail of the last round lands in the 64 spare entries)
+            }
+            const int off = (cx - BI_R) & 3;
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                int a = 0, b = 0;
+#pragma unroll
+                for (int r = 0; r < 9; r++) {
+                    a += hs16[ta[w] + off + r * (4 * BI_G)];
+                    b += hs16[tb[w] + off + r * (4 * BI_G)];
+                }
+                word[w] = __ballot(a < b);
+            }
+        } else {
+            if (nfast) fetch(ncy, ncx);
+#pragma unroll
+            for (int w = 0; w < 4; w++) {
+                const int a = box_slow(cy + tq[w][0], cx + tq[w][1]);
+                const int b = box_slow(cy + tq[w][2], cx + tq[w][3]);
+                word[w] = __ballot(a < b);
+            }
+        }
+        if (lane < 4) F.desc[(size_t)i * 4 + lane] = (lane == 0) ? word[0] : (lane == 1) ? word[1] : (lane == 2) ? word[2] : word[3];
+        cy = ncy, cx = ncx, fast = nfast;
+    }
+    if (publish_seq) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            FeatCtl &fc = *FB.fc;
+            __threadfence();
+            if (atomicAdd(&fc.done_blocks, 1u) == gridDim.x * gridDim.y - 1) {
+                fc.done_blocks = 0;
+                if (poison) {
+                    fc.skip_seq = publish_seq;
+                    fc.poison = 0;
+                }
+                S.ctl->dbg[47] = (long long)wall_clock64();
                 __threadfence();
                 atomicExch(&fc.feat_seq, publish_seq);
             }

@@ -151,6 +151,7 @@ struct Context {
     // In TWO launches the chip drains once in the middle and they get in: +4 .. 8 % for 8 - 24 KITTI-shaped sequences, -6 % from 28 on, where the feature
     // stage is the longer chain and the drain is pure loss.  Which side a batch is on shows in its own early gate (Ctl::dbg[32 / 35 / 33]: start, features
     // seen, pose seen): a gate that mostly waits for the previous pose says the feature stream is ahead.  LVT_AMD_SCORE_PIECES=1 / 2 fixes the choice.
+    int brief_from_image = 0;  // LVT_AMD_BRIEF_FROM_IMAGE=1: no box-sum plane; k_brief_img builds the 9 x 9 sums of a key point's patch in LDS (k_features.hip)
     int score_pieces = 1;
     bool score_pieces_auto = true;
     double gate_balance_us = 0;  // running mean of (wait for the pose) - (wait for the features)
@@ -532,6 +533,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
             std::stable_sort(idx, idx + prm.n_cells, [&](int a, int b) { return area[a] > area[b]; });
             for (int cc = 0; cc < CELLS_MAX; cc++) c->cell_order.v[cc] = (uint8_t)(cc < prm.n_cells ? idx[cc] : 0);
         }
+        if (const char *e = std::getenv("LVT_AMD_BRIEF_FROM_IMAGE")) c->brief_from_image = std::atoi(e) ? 1 : 0;
         if (const char *e = std::getenv("LVT_AMD_SCORE_PIECES")) c->score_pieces = std::max(1, std::min(8, std::atoi(e))), c->score_pieces_auto = false;
         {
             int n_cu = 256;
@@ -732,15 +734,15 @@ static void enqueue_frame(Context *c) {
             (void)hipStreamWaitEvent(sf, c->ev_done[(int)((c->enq - NPAR) % RING)], 0);
     }
     if (B == 1) {  // the frame's inputs travel as a kernel argument: no separate "begin" launch, no device read of pinned host memory
-        LAUNCH(2, sf, k_score<true>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2), dim3(256), 0, S, c->h_fargs[slot], par, 0);
+        LAUNCH(2, sf, k_score<true>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2), dim3(256), 0, S, c->h_fargs[slot], par, 0, c->brief_from_image ? 0 : 1);
     } else {
         LAUNCH(0, sf, k_feat_begin, dim3(Bz), dim3(64), 0, S, fa, par);
         {   // the batch's images in score_pieces launches: see Context::score_pieces
             const int P = std::max(1, std::min(c->score_pieces, Bz));
             for (int q = 0; q < P; q++) {
                 const int z0 = 2 * (int)((long)Bz * q / P), z1 = 2 * (int)((long)Bz * (q + 1) / P);
-                if (q == 0) LAUNCH(2, sf, k_score<false>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, z1 - z0), dim3(256), 0, S, FrameArgs{}, par, z0);
-                else hipLaunchKernelGGL(k_score<false>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, z1 - z0), dim3(256), 0, sf, S, FrameArgs{}, par, z0);
+                if (q == 0) LAUNCH(2, sf, k_score<false>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, z1 - z0), dim3(256), 0, S, FrameArgs{}, par, z0, c->brief_from_image ? 0 : 1);
+                else hipLaunchKernelGGL(k_score<false>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, z1 - z0), dim3(256), 0, sf, S, FrameArgs{}, par, z0, c->brief_from_image ? 0 : 1);
             }
         }
     }
@@ -772,7 +774,8 @@ static void enqueue_frame(Context *c) {
     }
     LAUNCH_S(5, sf, k_gather, dim3(1, 2, Bz), dim3(1024), CELLS_LDS_BYTES, (const Seq *)S, par);
     const bool brief_publishes = !evo && B == 1;  // (single sequence: k_brief's last workgroup publishes feat_seq; see k_feat_done)
-    LAUNCH_S(6, sf, k_brief, dim3(64, 2, Bz), dim3(256), 0, (const Seq *)S, par, brief_publishes ? (seq_t)(c->enq + 1) : (seq_t)0);
+    if (c->brief_from_image) LAUNCH_S(6, sf, k_brief_img, dim3(64, 2, Bz), dim3(256), 0, (const Seq *)S, par, brief_publishes ? (seq_t)(c->enq + 1) : (seq_t)0);
+    else LAUNCH_S(6, sf, k_brief, dim3(64, 2, Bz), dim3(256), 0, (const Seq *)S, par, brief_publishes ? (seq_t)(c->enq + 1) : (seq_t)0);
     if (!evo && !brief_publishes) hipLaunchKernelGGL(k_feat_done, dim3(Bz), dim3(64), 0, sf, S, par, (seq_t)(c->enq + 1));
     const int bl = c->binned_lists ? 1 : 0;
     if (evo && bl && c->sensor == 1) LAUNCH_SM(19, sf, k_hamming_batched_lists, MODE_ROW, dim3(c->lists_wgs_row, 1, Bz), dim3(LS_THREADS), LS_LDS_BYTES, par, (seq_t)0);

@@ -77,6 +77,34 @@ def test_binned_list_kernel_on_a_single_handle(hip_lib, oracle_lib, monkeypatch,
     assert not bad, f"{name}: first divergence at frame {bad[0][0]}: {bad[0][1][:6]}"
 
 
+def test_brief_without_the_box_sum_plane(hip_lib, oracle_lib, monkeypatch):
+    """LVT_AMD_BRIEF_FROM_IMAGE=1: k_score writes no box-sum plane, k_brief_img builds the 9 x 9 sums of every key point's 57 x 57 patch in LDS straight
+    from the image.  Same pixels, same sums: descriptors -- hence every later stage -- stay bit-identical to the oracle's, on detected corners and on
+    external (fractional, border) corners, which take the clipped element-wise path"""
+    from oracle import pyoracle as O
+    monkeypatch.setenv("LVT_AMD_BRIEF_FROM_IMAGE", "1")
+    world, prm, sensor = make_case("kitti", 21, 0.5)
+    hip = hip_lib.LvtSystem.create(prm, 1)
+    orc = O.Oracle(prm, 1)
+    rng = np.random.default_rng(9)
+    for i in range(14):
+        a, b = world.render_stereo(i)
+        if i % 5 == 3:
+            xl, _, _, _ = O.compute_features(a, prm)
+            xr, _, _, _ = O.compute_features(b, prm)
+            cl = xl.astype(np.float64); cr = xr.astype(np.float64)
+            cl[::7] += rng.uniform(-0.5, 0.5, size=cl[::7].shape)
+            cl = np.vstack([cl, [[3.0, 3.0], [world.W - 28.5, world.H - 28.5], [27.5, 27.5]]])
+            orc.track_with_external_corners(a, b, cl, cr)
+            hip.track_with_external_corners(a, b, cl, cr)
+        else:
+            orc.track(a, b)
+            hip.track(a, b)
+        msgs = diff_frame(hip, orc)
+        assert not msgs, f"frame {i}: {msgs[:5]}"
+    assert hip.last_error() == ""
+
+
 @pytest.mark.parametrize("binned", ["0", "1"], ids=["wave_per_query_lists", "binned_list_kernel"])
 def test_row_lists_built_twice_at_once(hip_lib, oracle_lib, monkeypatch, binned):
     """k_triangulate's fallback for late row-match lists (the early stream's gate stood down: 5-ms time-out) builds the lists itself --

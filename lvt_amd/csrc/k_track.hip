@@ -1022,80 +1022,9 @@ __device__ __forceinline__ void resolve_body(const Seq &S, Ctl &ctl, int pass2, 
 }
 
 // =================================================================================================
-// bookkeeping of find_matches + LOST decision : lvt_local_map.cpp:201-224 + lvt_system.cpp:266-274
+// bookkeeping of find_matches + LOST decision + clean_untracked_points : lvt_local_map.cpp:201-224, lvt_system.cpp:266-274, lvt_local_map.cpp:393-413
+// (the clean-up does not depend on the pose, so it runs here, ahead of the pose refinement; the reference runs it right after)
 // =================================================================================================
-__device__ __forceinline__ void bookkeep_body(const Seq &S, Ctl &ctl, int par, int *scan) {
-    const int tid = threadIdx.x;
-    const int M = *S.map_n;
-    const MapSoA &P = S.map[*S.map_cur];
-    const Feat &F = S.fb[par].feat[0];
-    int n_out = 0;
-    for (int base = 0; base < M; base += RES_THREADS) {
-        const int i = base + tid;
-        int m = -2;
-        if (i < M) {
-            m = S.match[i];
-            P.match_idx[i] = m;
-            if (m == -1) P.counter[i] += 1;
-            else if (m >= 0) P.age[i] += 1;
-        }
-        int total;
-        const int off = n_out + block_excl_scan(m >= 0 ? 1 : 0, scan, &total);
-        if (m >= 0 && off < NF_MAX) {
-            S.pnp_X[3 * off] = P.pos[3 * i];
-            S.pnp_X[3 * off + 1] = P.pos[3 * i + 1];
-            S.pnp_X[3 * off + 2] = P.pos[3 * i + 2];
-            S.pnp_obs[2 * off] = F.x[m];
-            S.pnp_obs[2 * off + 1] = F.y[m];
-            S.pnp_feat[off] = m;
-            S.pnp_level[off] = 0;
-        }
-        n_out += total;
-    }
-    if (tid == 0) {
-        ctl.n_matches = n_out;
-        ctl.counts[C_N_MATCHES] = n_out;
-        if (n_out < S.prm.min_matches) {  // lvt_system.cpp:267-272, :199-204
-            ctl.lost_now = 1;
-            ctl.state = 3;
-            pose_to_Rt(ctl.last_pose, ctl.out_R, ctl.out_t);
-            ctl.out_status = 3;
-        } else {  // push_back / pop_front
-            ctl.last_matches[0] = ctl.last_matches[1];
-            ctl.last_matches[1] = ctl.last_matches[2];
-            ctl.last_matches[2] = n_out;
-        }
-    }
-}
-
-// clean_untracked_points (lvt_local_map.cpp:393-413): stable compaction into the other buffer.  It does not depend
-// on the pose, so it runs here, ahead of the pose refinement (the reference runs it right after).
-__device__ __forceinline__ void cull_body(const Seq &S, Ctl &ctl, int par, int *scan) {
-    const int tid = threadIdx.x;
-    const int cur = *S.map_cur, M = *S.map_n;
-    const MapSoA &A = S.map[cur], &B = S.map[cur ^ 1];
-    const int th = S.prm.untracked_th;
-    int n_out = 0;
-    for (int base = 0; base < M; base += RES_THREADS) {
-        const int i = base + tid;
-        bool keep = false;
-        if (i < M) {
-            keep = A.counter[i] < th;
-            if (!keep && A.match_idx[i] >= 0) S.fb[par].feat[0].flag[A.match_idx[i]] = 0;  // :402-405
-        }
-        int total;
-        const int off = n_out + block_excl_scan(keep ? 1 : 0, scan, &total);
-        if (keep) copy_point(A, i, B, off);
-        n_out += total;
-    }
-    __syncthreads();
-    if (tid == 0) {
-        ctl.counts[C_N_CULLED] = M - n_out;
-        *S.map_cur = cur ^ 1;
-        *S.map_n = n_out;
-    }
-}
-
 // bookkeeping + LOST decision + clean_untracked_points in ONE pass for maps of up to RES_THREADS points (the map of a
 // KITTI sequence holds ~800): every field of a point is loaded once (independent loads: one memory round trip), both
 // compactions (PnP input = matched points, surviving map = counter < untracked_th) come from one packed scan, and the
@@ -1173,6 +1102,100 @@ __device__ __forceinline__ bool bookkeep_cull_small(const Seq &S, Ctl &ctl, int 
     return false;
 }
 
+// The same for maps of any size (a TUM-shaped map holds ~9 000 points).  bookkeep_body + cull_body of rounds 1-4 scanned every chunk of 1024 points on
+// its own: 2 x ceil(M / 1024) block scans, each behind its own memory round trip (57 us of k_track_mid on such a map).  Here the chunks keep their coalesced
+// layout (point k 1024 + t belongs to thread t), pass 1 only COUNTS -- a wavefront's ballots give its matched / surviving points per chunk, no barrier between
+// chunks --, ONE block scan over the (chunk, wavefront) counts places both compactions in storage order, and pass 2 reads every field once and writes the PnP
+// input and the surviving map, again without a barrier between chunks.  `cnts`: >= 2 * 32 * 16 words of LDS scratch.  Returns true when the frame is LOST.
+__device__ __forceinline__ bool bookkeep_cull_large(const Seq &S, Ctl &ctl, int par, int *scan, uint32_t *cnts) {
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    constexpr int NWV = RES_THREADS / 64;
+    const int cur = *S.map_cur, M = *S.map_n;
+    const MapSoA &A = S.map[cur], &B = S.map[cur ^ 1];
+    const Feat &F = S.fb[par].feat[0];
+    const int th = S.prm.untracked_th;
+    const int c = (M + RES_THREADS - 1) / RES_THREADS;  // <= MAP_MAX / 1024 = 32 chunks
+    const uint64_t lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    uint32_t mbits = 0, kbits = 0;  // this thread's point of chunk k: matched / survives
+    for (int k = 0; k < c; k++) {
+        const int i = k * RES_THREADS + tid;
+        int m = -2, cnt = 0;
+        if (i < M) m = S.match[i], cnt = A.counter[i];
+        const bool mt = m >= 0, kp = (i < M) && ((cnt + (m == -1 ? 1 : 0)) < th);
+        mbits |= (mt ? 1u : 0u) << k, kbits |= (kp ? 1u : 0u) << k;
+        const uint64_t bm = __ballot(mt), bk = __ballot(kp);
+        if (lane == 0) cnts[k * NWV + wv] = (uint32_t)__popcll(bm) | ((uint32_t)__popcll(bk) << 16);
+    }
+    __syncthreads();
+    uint32_t base = 0;
+    int total;
+    {   // exclusive scan over the (chunk, wavefront) counts in storage order: c * 16 <= 512 entries, one per thread
+        const int v = (tid < c * NWV) ? (int)cnts[tid] : 0;
+        const int ex = block_excl_scan(v, scan, &total);
+        if (tid < c * NWV) cnts[tid] = (uint32_t)ex;
+    }
+    __syncthreads();
+    const int n_match = (int)((unsigned)total & 0xFFFFu), n_keep = (int)((unsigned)total >> 16);  // (MAP_MAX = 32768 survivors reach bit 31)
+    const bool lost = n_match < S.prm.min_matches;  // lvt_system.cpp:267-272, :199-204
+    if (tid == 0) {
+        ctl.n_matches = n_match;
+        ctl.counts[C_N_MATCHES] = n_match;
+        if (lost) {
+            ctl.lost_now = 1;
+            ctl.state = 3;
+            pose_to_Rt(ctl.last_pose, ctl.out_R, ctl.out_t);
+            ctl.out_status = 3;
+        } else {  // push_back / pop_front
+            ctl.last_matches[0] = ctl.last_matches[1];
+            ctl.last_matches[1] = ctl.last_matches[2];
+            ctl.last_matches[2] = n_match;
+        }
+    }
+    for (int k = 0; k < c; k++) {
+        const int i = k * RES_THREADS + tid;
+        const bool mt = (mbits >> k) & 1u, kp = (kbits >> k) & 1u;
+        const uint64_t bm = __ballot(mt), bk = __ballot(kp);
+        base = cnts[k * NWV + wv];
+        const int offm = (int)(base & 0xFFFFu) + __popcll(bm & lt), offk = (int)(base >> 16) + __popcll(bk & lt);
+        if (i >= M) continue;
+        int m = S.match[i], cnt = A.counter[i], ag = A.age[i];
+        if (m == -1) cnt += 1;  // lvt_local_map.cpp:201-224
+        else if (m >= 0) ag += 1;
+        if (lost) {  // the map stays where it is, with the bookkeeping applied
+            A.match_idx[i] = m, A.counter[i] = cnt, A.age[i] = ag;
+            continue;
+        }
+        if (!mt && !kp) continue;
+        const double p0 = A.pos[3 * i], p1 = A.pos[3 * i + 1], p2 = A.pos[3 * i + 2];
+        if (mt && offm < NF_MAX) {
+            S.pnp_X[3 * offm] = p0;
+            S.pnp_X[3 * offm + 1] = p1;
+            S.pnp_X[3 * offm + 2] = p2;
+            S.pnp_obs[2 * offm] = F.x[m];
+            S.pnp_obs[2 * offm + 1] = F.y[m];
+            S.pnp_feat[offm] = m;
+            S.pnp_level[offm] = 0;
+        }
+        if (kp) {  // clean_untracked_points (lvt_local_map.cpp:393-413): stable compaction into the other buffer
+            B.pos[3 * offk] = p0, B.pos[3 * offk + 1] = p1, B.pos[3 * offk + 2] = p2;
+#pragma unroll
+            for (int q = 0; q < 4; q++) B.desc[(size_t)offk * 4 + q] = A.desc[(size_t)i * 4 + q];
+            B.counter[offk] = cnt;
+            B.age[offk] = ag;
+            B.match_idx[offk] = m;
+        } else if (mt)
+            S.fb[par].feat[0].flag[m] = 0;  // :402-405
+    }
+    if (lost) return true;
+    __syncthreads();
+    if (tid == 0) {
+        ctl.counts[C_N_CULLED] = M - n_keep;
+        *S.map_cur = cur ^ 1;
+        *S.map_n = n_keep;
+    }
+    return false;
+}
+
 // =================================================================================================
 // k_track_mid : find_matches pass 1 [+ second pass, if pass 1 found < 50] + bookkeeping + LOST decision + cull
 // =================================================================================================
@@ -1213,10 +1236,7 @@ __global__ __launch_bounds__(RES_THREADS) void k_track_mid(SeqArg<BV> sa, int pa
         bookkeep_cull_small(S, ctl, par, L.scan);
         return;
     }
-    bookkeep_body(S, ctl, par, L.scan);
-    __syncthreads();
-    if (ctl.lost_now) return;
-    cull_body(S, ctl, par, L.scan);
+    bookkeep_cull_large(S, ctl, par, L.scan, L.lists);
 }
 
 // k_early_mid : the greedy resolution of find_matches for the map points [0, early_done) (storage order: their decisions do

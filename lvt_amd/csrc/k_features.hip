@@ -186,7 +186,12 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par,
     const int cs = S.prm.cell_size;
     const int t_low = S.prm.agast_th_low;
     const int t_hi = S.prm.agast_th;
-    const int cell_x0 = x0 / cs;  // cell of the tile's first pixel; at most one cell boundary inside a tile when cs >= 64
+    // A runtime integer division is ~20 VALU instructions, and every thread did four or five of them (its row's and its pixels' cells): a fifth of the
+    // kernel's issue.  x / cs is one v_mul_hi_u32 with the host's ceil(2^32 / cs) (exact while x * cs < 2^32: pixel coordinates).
+    const uint32_t cmag = S.prm.cell_magic;
+    auto cell_of_x = [&](int gx) -> int { return cmag ? (int)__umulhi((uint32_t)gx, cmag) : gx; };  // (cell size 1: 2^32 does not fit, the host stores 0)
+    auto cell_of_y = cell_of_x;
+    const int cell_x0 = cell_of_x(x0);  // cell of the tile's first pixel; at most one cell boundary inside a tile when cs >= 64
     __shared__ uint16_t s_item[2 * 256];                                    // passing pairs: thread << 1 | pair
     __shared__ __attribute__((aligned(4))) uint8_t s_sc[TS_H][TS_W];        // thresholded scores of the tile
     __shared__ int s_wcnt[4];
@@ -197,7 +202,7 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par,
         const int gx0 = x0 + 4 * tx;
         bool row_ok = false;
         if (gy < H) {
-            const int cy = gy / cs, ly = gy - cy * cs, ch = min(cs, H - cy * cs);
+            const int cy = cell_of_y(gy), ly = gy - cy * cs, ch = min(cs, H - cy * cs);
             row_ok = (ly >= 3) && (ly <= ch - 4) && gx0 < W;
         }
         if (row_ok) {
@@ -241,7 +246,7 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par,
         const int it = s_item[e], t = it >> 1, q = it & 1;
         const int itx = t & 15, ity = t >> 4;
         const int igy = y0 + ity, gx0 = x0 + 4 * itx;
-        const int cx0 = gx0 / cs, lx0 = gx0 - cx0 * cs;
+        const int cx0 = cell_of_x(gx0), lx0 = gx0 - cx0 * cs;
         uint32_t w[7][3];  // rows r0-3 .. r0+3, byte columns 4 tx .. 4 tx + 11 of the tile (pixel k's centre is byte 4 + k)
 #pragma unroll
         for (int dy = 0; dy < 7; dy++) {
@@ -275,7 +280,7 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par,
             const int k = 2 * q + h, sv = h ? (int)s2.y : (int)s2.x;
             int cx = cx0, lx = lx0 + k;
             if (lx >= cs) {
-                const int qq = lx / cs;
+                const int qq = cell_of_x(lx);
                 cx += qq;
                 lx -= qq * cs;
             }
@@ -294,16 +299,16 @@ __global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par,
     uint32_t cvalid = 0;  // bit k: pixel k of this thread is a pass-0 corner
     int ncl = 0;
     if (gy < H && packed != 0) {
-        const int cy = gy / cs, ly = gy - cy * cs;
+        const int cy = cell_of_y(gy), ly = gy - cy * cs;
         const int gx0 = x0 + 4 * tx;
-        const int cx0 = gx0 / cs, lx0 = gx0 - cx0 * cs;
+        const int cx0 = cell_of_x(gx0), lx0 = gx0 - cx0 * cs;
 #pragma unroll
         for (int k = 0; k < 4; k++) {
             const int sv = (int)((packed >> (8 * k)) & 255u);
             if (sv >= t_hi) {
                 int cx = cx0, lx = lx0 + k;
                 if (lx >= cs) {
-                    const int qq = lx / cs;
+                    const int qq = cell_of_x(lx);
                     cx += qq;
                     lx -= qq * cs;
                 }

@@ -57,6 +57,7 @@ struct Params {  // lvt_parameters.h:29-64 + derived values
     int hash_ccx, hash_ccy, cell_search_radius;  // lvt_image_features_struct.cpp:48-53
     int sensor;                             // 1 stereo, 2 rgbd
     int undistort;                          // |k1| > 1e-5 (handler.cpp:268)
+    unsigned cell_magic;                    // ceil(2^32 / cell_size): x / cell_size == __umulhi(x, cell_magic) for x * cell_size < 2^32 (pixel coordinates)
     int big_cell_strips;                    // detection cells taller than 256 px: an oversized cell's NMS runs as row strips on several CUs (k_cells_strip)
 };
 

@@ -333,6 +333,7 @@ static bool derive_params(const lvt_amd_params &in, int sensor, Params &p) {
         p.max_y = std::max(y[2], y[3]);
     }
     p.undistort = (std::fabs(p.k1) > 1e-5) ? 1 : 0;
+    p.cell_magic = (unsigned)((0x100000000ull + (unsigned long long)p.cell_size - 1) / (unsigned long long)p.cell_size);
     p.big_cell_strips = (p.cell_size > 256) ? 1 : 0;  // (TUM's single 2000-px cell; the 250-px cells of KITTI / EuRoC keep the two-launch feature chain)
     return true;
 }

@@ -266,7 +266,12 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
                 s_q[3 * q] = fits ? ((uint32_t)R.s0 | ((uint32_t)R.s1 << 11) | ((uint32_t)R.l0 << 22)) : 0xFFFFFFFFu;
                 s_q[3 * q + 1] = (uint32_t)R.s2 | ((uint32_t)R.l1 << 11) | ((uint32_t)R.l2 << 17);
             } else {
-                qkey[k] = HB_HIST - 1 - min(count_of(qp[k]), HB_HIST - 1);
+                if (MODE == 1) {  // the one range travels with the query (the per-query words of the radius mode are unused here): start | length << 16
+                    const Ranges R = ranges(qp[k]);
+                    s_q[q] = (uint32_t)R.s0 | ((uint32_t)R.l0 << 16);
+                    qkey[k] = HB_HIST - 1 - min(R.l0, HB_HIST - 1);
+                } else
+                    qkey[k] = HB_HIST - 1 - min(count_of(qp[k]), HB_HIST - 1);
                 // stage 4a visits the queries in sorted order: it finds the coordinates in the query's (still unused) mask
                 // slot instead of going back to HBM for them
                 if (MODE == 0 && NSP > 0) s_mask[q] = make_uint2(__float_as_uint(qp[k].x), __float_as_uint(qp[k].y));
@@ -289,6 +294,9 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
     __syncthreads();
     if (dbg) dbg[5] = clock64();
 
+#if defined(LAB_STOP) && LAB_STOP == 1   // (tools/hamming_lab/lab.py --stop 1: counters of the load / sort phases alone)
+    return;
+#endif
     __builtin_amdgcn_s_setprio(0);
     // ---- 4. rounds of 512 queries in sorted order; odd rounds reverse the wave order so every wave gets a similar sum
     constexpr int rounds = QPT;
@@ -528,6 +536,31 @@ LVT_RADIUS_BITS(lo, 0, t0)
                 };
                 walk_bits(W2, 0);
                 walk_bits(W1 >> 23, 32);
+                int4 o;
+                o.x = (k1 == 0xFFFFFFFFu) ? -1 : (int)(k1 & 0xFFFFu);
+                o.y = (k1 == 0xFFFFFFFFu) ? 0x7FFFFFFF : (int)(k1 >> 16);
+                o.z = (k2 == 0xFFFFFFFFu) ? -1 : (int)(k2 & 0xFFFFu);
+                o.w = (k2 == 0xFFFFFFFFu) ? 0x7FFFFFFF : (int)(k2 >> 16);
+                out[q] = o;
+            }
+            q = qn, w0 = nw0, w1 = nw1;
+        }
+    } else if (MODE == 1 && !s_recheck) {
+        // Row mode without marked entries (block-uniform): the range travels with the query (stage 3), the walk needs neither coordinates nor bin starts.
+        // (Re-dealing a wavefront's 64 queries among its lanes by range start mod 16 -- 16 ballots, rank k to lane (k % 4) * 16 + k / 4, which halves the
+        //  conflicts of random starts in tools/lab/lds_b128_groups.hip -- was built and changed nothing here: queries of one image row share their range,
+        //  the sorted order keeps them in one wavefront, and equal addresses broadcast; the walk's ds_read_b128 already run at the dealt pattern's ~10 cycles.)
+        int q = slot_query(0, M);
+        uint4 w0 = qd[2 * max(q, 0)], w1 = qd[2 * max(q, 0) + 1];
+        for (int j = 0; j < rounds; j++) {
+            const int qn = slot_query(j + 1, M);
+            const uint4 nw0 = qd[2 * max(qn, 0)], nw1 = qd[2 * max(qn, 0) + 1];  // next round's query: in flight during this round
+            if (q >= 0) {
+                const uint32_t W = s_q[q];
+                const uint64_t d0 = ((uint64_t)w0.y << 32) | w0.x, d1 = ((uint64_t)w0.w << 32) | w0.z;
+                const uint64_t d2 = ((uint64_t)w1.y << 32) | w1.x, d3 = ((uint64_t)w1.w << 32) | w1.z;
+                uint32_t k1 = 0xFFFFFFFFu, k2 = 0xFFFFFFFFu;
+                row_walk_lean((int)(W & 0xFFFFu), (int)(W >> 16), d0, d1, d2, d3, k1, k2);
                 int4 o;
                 o.x = (k1 == 0xFFFFFFFFu) ? -1 : (int)(k1 & 0xFFFFu);
                 o.y = (k1 == 0xFFFFFFFFu) ? 0x7FFFFFFF : (int)(k1 >> 16);

@@ -39,7 +39,7 @@ int main() {
     (void)hipMalloc(&d_pos, 1024 * 4), (void)hipMalloc(&d_out, 512 * 1024 * 16), (void)hipMalloc(&d_cyc, 8);
     const int rep = 512;
     srand(7);
-    for (int pat = 0; pat < 6; pat++) {
+    for (int pat = 0; pat < 9; pat++) {
         std::vector<int> pos(1024);
         for (int w = 0; w < 16; w++) {
             int cnt[4] = {0, 0, 0, 0};
@@ -53,6 +53,19 @@ int main() {
                 if (pat == 4) pos[t] = rand() % 3200;
                 if (pat == 5) pos[t] = row + (l & 15) / 2 * 2;                   // two lanes per residue inside contiguous blocks (a 2-way conflict if they share a cycle)
             }
+            if (pat >= 6) {  // 64 random residues, ranked, rank k -> lane (k % 4) * 16 + k / 4 (pat 6); the same through the (7 s + 3) % 16 slot order (pat 7); undealt (pat 8)
+                int res[64], ord[64];
+                for (int l = 0; l < 64; l++) res[l] = rand() % 16, ord[l] = l;
+                for (int a = 0; a < 64; a++)
+                    for (int b = a + 1; b < 64; b++)
+                        if (res[ord[b]] < res[ord[a]]) { int tmp = ord[a]; ord[a] = ord[b]; ord[b] = tmp; }
+                for (int k = 0; k < 64; k++) {
+                    const int slot = k >> 2, blk = k & 3;
+                    const int lane = (pat == 6) ? blk * 16 + slot : (pat == 7) ? blk * 16 + ((7 * slot + 3) & 15) : k;
+                    const int r = (pat == 8) ? res[k] : res[ord[k]];
+                    pos[w * 64 + lane] = 16 * (rand() % 200) + r;
+                }
+            }
         }
         (void)hipMemcpy(d_pos, pos.data(), 4096, hipMemcpyHostToDevice);
         for (int blocks : {1, 512}) {
@@ -60,7 +73,7 @@ int main() {
             hipLaunchKernelGGL(k, dim3(blocks), dim3(1024), 65536, 0, d_pos, d_out, d_cyc, rep);
             long long c = 0;
             (void)hipMemcpy(&c, d_cyc, 8, hipMemcpyDeviceToHost);
-            const char *names[] = {"same address", "pos = thread", "distinct residues / contiguous 16", "distinct residues / guide's groups", "random", "pairs share a residue / contiguous 16"};
+            const char *names[] = {"same address", "pos = thread", "distinct residues / contiguous 16", "distinct residues / guide's groups", "random", "pairs share a residue / contiguous 16", "random residues dealt by rank", "random residues dealt, slots permuted", "random residues undealt"};
             std::printf("%-40s blocks %3d: %.1f cycles per ds_read_b128 wave-instruction (CU-wide: 16 waves issue %d each)\n", names[pat], blocks, (double)c / (rep * 8.0 * 16.0), rep * 8);
         }
     }

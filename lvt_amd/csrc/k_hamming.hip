@@ -70,6 +70,13 @@ __device__ __forceinline__ uint32_t bcnt_acc(uint32_t x, uint32_t acc) {
     asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
     return r;
 }
+// the running top-2 (k1 <= k2) takes a new key: k2' is the MEDIAN of (k1, k2, key) -- one v_med3_u32 where min(k2, max(k1, key)) is two half-rate instructions
+__device__ __forceinline__ void top2_insert(uint32_t &k1, uint32_t &k2, uint32_t key) {
+    uint32_t m;
+    asm("v_med3_u32 %0, %1, %2, %3" : "=v"(m) : "v"(k1), "v"(k2), "v"(key));
+    k2 = m;
+    k1 = min(k1, key);
+}
 __device__ __forceinline__ uint32_t hamming256(uint64_t d0, uint64_t d1, uint64_t d2, uint64_t d3, const uint4 &a0, const uint4 &a1) {
     uint32_t d = bcnt_acc((uint32_t)d0 ^ a0.x, 0u);
     d = bcnt_acc((uint32_t)(d0 >> 32) ^ a0.y, d);
@@ -367,8 +374,7 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
             const uint32_t d = hamming256(d0, d1, d2, d3, a0, a1);
             uint32_t key = ((uint32_t)d << 16) | (RECHECK ? (id & 0x7FFFu) : id);
             if (NEED_XY) key = ok ? key : 0xFFFFFFFFu;
-            k2 = min(k2, max(k1, key));
-            k1 = min(k1, key);
+            top2_insert(k1, k2, key);
             r = rn, a0 = b0, a1 = b1, id = idn;
         }
     };
@@ -396,8 +402,7 @@ __global__ __launch_bounds__(HB_THREADS) __attribute__((amdgpu_waves_per_eu(8, 8
         if (v < len) {
             const uint4 a0 = plo[v], a1 = phi[v];
             const uint32_t ka = (hamming256(d0, d1, d2, d3, a0, a1) << 16) | pid[v];
-            k2 = min(k2, max(k1, ka));
-            k1 = min(k1, ka);
+            top2_insert(k1, k2, ka);
         }
     };
     auto match_all = [&](int q, float2 p, uint4 w0, uint4 w1, const Ranges &R) {
@@ -528,8 +533,7 @@ LVT_RADIUS_BITS(lo, 0, t0)
                         const uint32_t idn = s_idx[itn];
                         const uint32_t d = hamming256(d0, d1, d2, d3, a0, a1);
                         const uint32_t key = (d << 16) | id;
-                        k2 = min(k2, max(k1, key));
-                        k1 = min(k1, key);
+                        top2_insert(k1, k2, key);
                         if (!more) break;
                         a0 = b0, a1 = b1, id = idn;
                     }
@@ -673,8 +677,7 @@ LVT_RADIUS_BITS(lo, 0, t0)
                         const uint32_t idn = s_idx[itn];
                         const uint32_t d = hamming256(d0, d1, d2, d3, a0, a1);
                         const uint32_t key = (d << 16) | id;
-                        k2 = min(k2, max(k1, key));
-                        k1 = min(k1, key);
+                        top2_insert(k1, k2, key);
                         if (!more) break;
                         a0 = b0, a1 = b1, id = idn;
                     }

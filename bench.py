@@ -363,7 +363,7 @@ class HipBackend:
             lvt.hamming_match_batched(qd, qxy, td, txy, tf, 900.0, 0, H, W, out, launches=10)
         pop = np.array([bin(i).count("1") for i in range(256)], np.int64)
 
-        def sample_check(mode):
+        def sample_check(mode, txy=txy):
             """a sample of the big launch against a numpy restatement of the matcher (three problems x their first 48 queries)"""
             checked = 0
             for b in (0, B // 2, B - 1):
@@ -376,9 +376,9 @@ class HipBackend:
                     dx = (tx[None, :, 0] - qx[:, None, 0]).astype(np.float32); dy = (tx[None, :, 1] - qx[:, None, 1]).astype(np.float32)
                     mask = ((dx * dx).astype(np.float32) + (dy * dy).astype(np.float32)).astype(np.float32) < np.float32(625.0)
                 else:           # struct.cpp:124-140: rows int(y) - 2 .. int(y) + 2, clipped to [0, rows]
-                    qi = qx[:, 1].astype(np.int64)
-                    lo, hi = np.maximum(qi - 2, 0), np.minimum(qi + 2, H)
-                    ty = np.floor(tx[:, 1]).astype(np.int64)
+                    qi = qx[:, 1].astype(np.int64)   # the reference compares the train feature's FLOAT y with the integer bounds: kp.y >= start_y && kp.y <= end_y
+                    lo, hi = np.maximum(qi - 2, 0).astype(np.float32), np.minimum(qi + 2, H).astype(np.float32)
+                    ty = tx[:, 1].astype(np.float32)
                     mask = (ty[None, :] >= lo[:, None]) & (ty[None, :] <= hi[:, None])
                 big = np.int64(1) << 40
                 key = np.where(mask, d * 65536 + np.arange(N)[None, :], big)
@@ -405,6 +405,14 @@ class HipBackend:
         mean_row = float(np.mean(us_row))
         ach_row = byts / (mean_row * 1e-6) / 1e9
         checked_row = sample_check(1)
+        # the row mode's OTHER walk: a train feature whose y is not an in-range integer row (external corners, sub-pixel detectors) sends its problem to the
+        # reference's float comparison for every candidate.  Same launch with un-floored train coordinates: every problem takes that walk.
+        txy_frac = (torch.rand((B, N, 2), device=dev, generator=g) * torch.tensor([W - 1.0, H - 1.0], device=dev)).contiguous()
+        lvt.hamming_match_batched(qd, qxy, td, txy_frac, tf, 0.0, 1, H, W, out, launches=3)
+        us_frac = [lvt.hamming_match_batched(qd, qxy, td, txy_frac, tf, 0.0, 1, H, W, out, launches=5) for _ in range(3)]
+        mean_frac = float(np.mean(us_frac))
+        checked_frac = sample_check(1, txy_frac)
+        del txy_frac
         # HBM traffic of the same launch from the committed rocprofv3 PMC passes (tools/profile.sh; counters cannot be read from
         # inside this process).  FETCH_SIZE counts the 16-B-per-lane loads of this kernel at one half on gfx950
         # (MI355X_MICROARCH.md, HBM section): corrected bytes = 2 * FETCH_SIZE + WRITE_SIZE.
@@ -458,7 +466,11 @@ class HipBackend:
                                    "the stereo left <-> right instance)", "bound": "hbm", "achieved": round(ach_row, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(ach_row / HBM_PEAK_GBS, 4), "traffic": traffic_row, "avg_us": round(mean_row, 2), "median_us": round(float(np.median(us_row)), 2),
                          "launch": {"B": B, "M": M, "N": N, "algorithmic_bytes": byts}, "traffic_source": traffic_row_src,
-                         "output_checked": f"{checked_row} queries of 3 problems == numpy restatement"},
+                         "output_checked": f"{checked_row} queries of 3 problems == numpy restatement",
+                         "fractional_rows": {"what": "the same launch with FRACTIONAL train rows (external corners): every problem takes the walk that re-checks "
+                                                     "kp.y >= start_y && kp.y <= end_y per candidate; integer rows (every detector output) take the lean walk priced above",
+                                             "avg_us": round(mean_frac, 2), "frac": round(byts / (mean_frac * 1e-6) / 1e9 / HBM_PEAK_GBS, 4),
+                                             "output_checked": f"{checked_frac} queries of 3 problems == numpy restatement (float row compare)"}},
             "note": "B independent KITTI-nominal problems per launch; algorithmic bytes 40(M+N)+N+16M each (SURVEY 8d); MEAN of 35 launches "
                     "(7 x 5 back to back between two HIP events on the launch stream) after 80 warm-up launches of a THIRD template instance "
                     "(csr = 2) in front of each of the two reported instances (radius mode first, then `row_mode`); the rocprofv3 --stats average of this kernel over the same command is the same statistic (profiles/); "

@@ -100,7 +100,10 @@ __device__ __forceinline__ void feat_begin(Seq &S, const FrameArgs &f, int par) 
     c.absent = f.absent;
     if (c.poison) return;  // (k_gate_buf: the buffer still belongs to an older frame)
     c.ext_corners = f.ext_corners;
-    if (f.ext_corners && f.ext_xy[0]) FB.ext_xy[0] = f.ext_xy[0], FB.ext_xy[1] = f.ext_xy[1];
+    if (f.ext_corners) {  // a pooled seat's frame brings its own lists (freed with the seat: never kept beyond the frame); any other frame reads the context's
+        FB.ext_xy[0] = f.ext_xy[0] ? f.ext_xy[0] : FB.ext_xy_own[0];
+        FB.ext_xy[1] = f.ext_xy[0] ? f.ext_xy[1] : FB.ext_xy_own[1];
+    }
     c.n_ext[0] = f.n_ext[0];
     c.n_ext[1] = f.n_ext[1];
     c.n_detected[0] = c.n_detected[1] = 0;
@@ -116,10 +119,10 @@ __device__ __forceinline__ void feat_begin(Seq &S, const FrameArgs &f, int par) 
 template <bool BEGIN>
 __global__ __launch_bounds__(256) void k_score(Seq *seqs, FrameArgs fa, int par, int z0, int box) {  // z0: first image of this launch (a batch's images may come in several launches); box: 0 = no box-sum plane (k_brief_img builds the sums from the image)
     const int seq = (blockIdx.z + z0) >> 1, eye = (blockIdx.z + z0) & 1;
-    Seq &S = seqs[seq];
-    FrameBuf &FB = S.fb[par];
+    const Seq &S = seq_const(seqs, seq);  // (read through the constant address space: global, not flat, accesses -- lvt_dev.h; the fields written below are not read here)
+    const FrameBuf &FB = S.fb[par];
     if (FB.fc->poison) return;
-    if (BEGIN && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) feat_begin(S, fa, par);
+    if (BEGIN && blockIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) feat_begin(seqs[seq], fa, par);
     if (eye == 1 && S.prm.sensor == 2) return;
     const int W = S.prm.W, H = S.prm.H;
     // workgroups go to the 8 XCDs round-robin by their linear id and every XCD has its own L2: with the plain mapping the four neighbours of a
@@ -1539,7 +1542,7 @@ __device__ __forceinline__ void cells_entry(const SeqArg<BV> &sa, int pass, int 
     } else {  // lanes = 2 x sequences: workgroup L is (cell ord[L / lanes], eye L & 1, sequence (L % lanes) >> 1)
         const int slot = (int)blockIdx.x / lanes, r = (int)blockIdx.x - slot * lanes;
         cell = ord.v[slot], eye = r & 1;
-        Sp = sa.p + (r >> 1);
+        Sp = &seq_const(sa.p, r >> 1);
     }
     const Seq &S = *Sp;
     const FrameBuf &FB = S.fb[par];
@@ -1570,9 +1573,9 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) vo
 // instead, as before.  Survivors of the strips, concatenated in strip order, ARE the cell's survivors in raster order.
 constexpr int STRIP_HALO = 16;
 __global__ __launch_bounds__(1024) void k_cells_strip(Seq *seqs, int pass, int par) {
-    Seq &S = seqs[blockIdx.z];
+    const Seq &S = seq_const(seqs, blockIdx.z);
     const int eye = blockIdx.y, cell = blockIdx.x / STRIPS, strip = blockIdx.x % STRIPS;
-    FrameBuf &FB = S.fb[par];
+    const FrameBuf &FB = S.fb[par];
     CellGeom g;
     int cxi;
     if (!cell_begin(S, FB, eye, cell, pass, g, cxi)) return;
@@ -1634,9 +1637,9 @@ __global__ __launch_bounds__(1024) void k_cells_strip(Seq *seqs, int pass, int p
 
 // the oversized cell's second half: its strips' survivors, merged in LDS, through LVT's ANMS (or the whole cell on the old path)
 __global__ __launch_bounds__(1024) void k_cells_big(Seq *seqs, int pass, int par) {
-    Seq &S = seqs[blockIdx.z];
+    const Seq &S = seq_const(seqs, blockIdx.z);
     const int eye = blockIdx.y, cell = blockIdx.x;
-    FrameBuf &FB = S.fb[par];
+    const FrameBuf &FB = S.fb[par];
     CellGeom g;
     int cxi;
     if (!cell_begin(S, FB, eye, cell, pass, g, cxi)) return;
@@ -1691,9 +1694,9 @@ __global__ __launch_bounds__(1024) void k_cells_big(Seq *seqs, int pass, int par
 constexpr int RADII_WGS = 16;
 static_assert(STRIPS >= 2, "the ANMS launches pass sorted[] and r2[] through the first two strip buffers");
 __global__ __launch_bounds__(1024) void k_cells_radii(Seq *seqs, int pass, int par) {
-    Seq &S = seqs[blockIdx.z];
+    const Seq &S = seq_const(seqs, blockIdx.z);
     const int eye = blockIdx.y, cell = blockIdx.x / RADII_WGS, wg = blockIdx.x % RADII_WGS;
-    FrameBuf &FB = S.fb[par];
+    const FrameBuf &FB = S.fb[par];
     CellGeom g;
     int cxi;
     if (!cell_begin(S, FB, eye, cell, pass, g, cxi)) return;
@@ -1711,9 +1714,9 @@ __global__ __launch_bounds__(1024) void k_cells_radii(Seq *seqs, int pass, int p
 }
 
 __global__ __launch_bounds__(1024) void k_cells_select(Seq *seqs, int pass, int par) {
-    Seq &S = seqs[blockIdx.z];
+    const Seq &S = seq_const(seqs, blockIdx.z);
     const int eye = blockIdx.y, cell = blockIdx.x;
-    FrameBuf &FB = S.fb[par];
+    const FrameBuf &FB = S.fb[par];
     CellGeom g;
     int cxi;
     if (!cell_begin(S, FB, eye, cell, pass, g, cxi)) return;
@@ -1751,7 +1754,7 @@ __global__ __launch_bounds__(1024) void k_gather(SeqArg<BV> sa, const Seq *seqs,
     const Seq &S = sa.get();
     const int eye = blockIdx.y;
     const FrameBuf &FB = S.fb[par];
-    const FrameBuf &FBd = seqs[blockIdx.z].fb[par];
+    const FrameBuf &FBd = seq_const(seqs, blockIdx.z).fb[par];
     FeatCtl &ctl = *FB.fc;
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     const CellLds L = carve_cell_lds(smem);
@@ -1880,8 +1883,8 @@ __global__ __launch_bounds__(256) void k_brief(SeqArg<BV> sa, const Seq *seqs, i
         plane = (lid & 7) + 8 * (j / gridDim.x);
         bx = j % gridDim.x;
     }
-    const Seq &S = BV ? sa.get() : seqs[plane / gridDim.y];  // (sa.get() indexes by blockIdx.z: the batch form picks its plane's sequence itself)
-    const FrameBuf &FBd = seqs[plane / gridDim.y].fb[par];  // per-frame image pointers (border fall-back only)
+    const Seq &S = BV ? sa.get() : seq_const(seqs, plane / gridDim.y);  // (sa.get() indexes by blockIdx.z: the batch form picks its plane's sequence itself)
+    const FrameBuf &FBd = seq_const(seqs, plane / gridDim.y).fb[par];  // per-frame image pointers (border fall-back only)
     const int eye = plane % gridDim.y;
     const FrameBuf &FB = S.fb[par];
     const Feat &F = FB.feat[eye];
@@ -2013,8 +2016,8 @@ __global__ __launch_bounds__(256) void k_brief_img(SeqArg<BV> sa, const Seq *seq
         plane = (lid & 7) + 8 * (j / gridDim.x);
         bx = j % gridDim.x;
     }
-    const Seq &S = BV ? sa.get() : seqs[plane / gridDim.y];
-    const FrameBuf &FBd = seqs[plane / gridDim.y].fb[par];  // per-frame image pointers
+    const Seq &S = BV ? sa.get() : seq_const(seqs, plane / gridDim.y);
+    const FrameBuf &FBd = seq_const(seqs, plane / gridDim.y).fb[par];  // per-frame image pointers
     const int eye = plane % gridDim.y;
     const FrameBuf &FB = S.fb[par];
     const Feat &F = FB.feat[eye];

@@ -1,20 +1,26 @@
-// k_lists.hip -- k_hamming_batched_lists: the pipeline's candidate LISTS from the binned matcher (round 2).
+// k_lists.hip -- k_hamming_batched_lists: the pipeline's candidate LISTS from the binned matcher (round 2; rebuilt in round 6).
 //
 // The greedy accept / mark scans of find_matches and row_match (k_early_mid / k_track_mid / k_triangulate) walk, per query, the
 // candidates of lvt_image_features_struct.cpp:68-148 sorted by (Hamming distance, index).  k_candidates / k_early_map build those
-// lists with one WAVEFRONT per query scanning ALL train features (64 lanes x N / 64 trips of predicate tests per query): in a
-// lock-step batch of 16 sequences that is 95 + 103 us of kernels per frame.  This kernel builds the same lists the way
-// k_hamming_batched finds its top-2 (k_hamming.hip): ONE 1024-thread workgroup per sequence stages the train set once in LDS,
-// counting-sorted into the reference's own 25-px hash cells (tracking) or image rows (row matching); ONE LANE per query then walks
-// only its window's contiguous LDS ranges -- ~18 candidates instead of N -- twice: first counting the hits of the exact
-// predicate, so that a block scan can hand every query its own segment of an LDS arena, then computing the 256-bit distances
-// into that segment as packed (distance << 16 | index) keys, and finally ranking every key among its segment's keys: the rank is its
-// place in the list.
+// lists with one WAVEFRONT per query scanning ALL train features (64 lanes x N / 64 trips of predicate tests per query).  This kernel
+// stages the train set once per workgroup in LDS, counting-sorted into the reference's own 25-px hash cells (tracking) or image rows
+// (row matching), exactly as k_hamming_batched does (k_hamming.hip) -- a query's candidates are then <= 5 CONTIGUOUS LDS ranges.
 //
-// Output contract = k_candidates': cand[q][0 .. min(n, KC)) ascending, ncand[q] = n (n > KC: the resolvers' exact slow path);
-// map mode also projects the point first (is_point_visible, lvt_local_map.cpp:62-82,152-156) and leaves proj / vis / match /
-// counter exactly as k_early_map does.  The bins ARE the reference's hash cells (Feat::hcx / hcy), so "candidate in the window's
-// cells" is decided by the range bounds and the walk only evaluates the radius; row mode evaluates the band test itself.
+// Round 6: ONE WAVEFRONT PER QUERY, ONE LANE PER CANDIDATE.  (Rounds 2 - 5 gave every query one lane that walked its ~20 candidates
+// serially -- twice, to size an arena segment first -- and ranked them by counting, (n / 4)^2 trips per lane: 89 us for the row lists of a
+// 16-sequence batch, the kernel ending with its longest list.)  Now
+//   1. every global load of the train set is in flight before the counting sort starts (one round trip, not two);
+//   2. one thread per query of a chunk of <= 512 projects the point (map mode: is_point_visible, lvt_local_map.cpp:62-82,152-156, leaving
+//      proj / vis / match / counter exactly as k_early_map does) and packs the window's ranges into eight LDS words; the chunk's query
+//      descriptors are copied to LDS with coalesced loads;
+//   3. a wavefront takes a query: lane v evaluates candidate v of the flattened ranges -- predicate, 256-bit distance, key
+//      (distance << 16 | index) -- the keys that pass are compacted into the wavefront's own LDS segment (ballot prefix), and every lane
+//      ranks its key among them with broadcast reads of four keys at a time: the rank is the key's place in the list.  Neighbouring
+//      lanes read neighbouring descriptors: no bank conflicts, no serial chain longer than n / 4 trips.
+//
+// Output contract = k_candidates': cand[q][0 .. min(n, KC)) ascending, ncand[q] = n (n > KC: the resolvers' exact slow path).
+// The bins ARE the reference's hash cells (Feat::hcx / hcy), so "candidate in the window's cells" is decided by the range bounds and the
+// wavefront only evaluates the radius; row mode evaluates the band test itself (struct.cpp:132-134).
 // Capacity: 2048 train features and 4100 bins per LDS image; beyond that (or for a cell search radius above 2) the kernel does
 // NOTHING and raises Seq::lists_fb, and the wave-per-query kernel launched behind it does the work as before.
 #include "lvt_dev.h"
@@ -23,20 +29,26 @@
 namespace lvt {
 
 constexpr int LS_THREADS = 1024;
+constexpr int LS_WAVES = LS_THREADS / 64;
 constexpr int LS_NMAX = 2048;   // train features of one LDS image
 constexpr int LS_BINS = 4100;   // hash cells / image rows + 1
-constexpr int LS_ARENA = 11776; // list entries in flight (one chunk of <= 1024 queries; larger chunks are cut)
-constexpr int LS_WORK = 1024;   // ... and behind them the work list of the lists a whole wavefront ranks (one word per thread at most)
-constexpr int LS_COOP_MIN = 20; // lists at least this long are ranked by a wavefront: a lane's rank-by-counting is (n / 4)^2 trips and the kernel ends with its longest list
-constexpr int LS_STARTS = (LS_BINS + 4) & ~3;  // (the arena behind the bin starts is 16-byte aligned)
-constexpr int LS_LDS_BYTES = LS_NMAX * 42 + LS_STARTS * 4 + (LS_ARENA + LS_WORK) * 4 + 256;
+constexpr int LS_QCH = 512;     // queries of one chunk: descriptors and window words in LDS
+constexpr int LS_SEG = KC + 64; // keys a wavefront collects for one query (past KC only the count matters)
+constexpr int LS_STARTS = (LS_BINS + 4) & ~3;
+constexpr int LS_LDS_BYTES = LS_NMAX * 42 + LS_STARTS * 4 + LS_QCH * 64 + LS_WAVES * LS_SEG * 4 + 256;
 typedef unsigned int ls_u32x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ uint32_t ls_bcnt(uint32_t x, uint32_t acc) {  // acc + popcount(x): one instruction
+    uint32_t r;
+    asm("v_bcnt_u32_b32 %0, %1, %2" : "=v"(r) : "v"(x), "v"(acc));
+    return r;
+}
 
 template <int MODE, bool BV>
 __global__ __launch_bounds__(LS_THREADS) void k_hamming_batched_lists(SeqArg<BV> sa, int par, seq_t seq) {
     const Seq &S = sa.get();
     Ctl &ctl = *S.ctl;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
     int *fb = S.lists_fb + (MODE == MODE_ROW ? 1 : 0);
     // ---- what there is to do (block-uniform), exactly as the kernel this one stands in for decides it
     int q_end = 0;
@@ -65,35 +77,42 @@ __global__ __launch_bounds__(LS_THREADS) void k_hamming_batched_lists(SeqArg<BV>
     float2 *s_xy = reinterpret_cast<float2 *>(s_dhi + LS_NMAX);
     uint16_t *s_idx = reinterpret_cast<uint16_t *>(s_xy + LS_NMAX);
     int *s_start = reinterpret_cast<int *>(s_idx + LS_NMAX);
-    uint32_t *s_arena = reinterpret_cast<uint32_t *>(s_start + LS_STARTS);
-    uint32_t *s_work = s_arena + LS_ARENA;
-    __shared__ int s_work_n;
+    ls_u32x4 *s_qd = reinterpret_cast<ls_u32x4 *>(s_start + LS_STARTS);  // [LS_QCH][2]: the chunk's query descriptors
+    ls_u32x4 *s_qw = s_qd + 2 * LS_QCH;                                  // [LS_QCH][2]: live | x | y | - , five ranges (start | length << 16) (three used words spare)
+    uint32_t *s_seg = reinterpret_cast<uint32_t *>(s_qw + 2 * LS_QCH) + wv * LS_SEG;
     __shared__ int s_scan[32];
-    __shared__ int s_next;
     __shared__ double w2c[12];
 
     long long *stamp = (MODE == MODE_ROW && blockIdx.x == 0 && tid == 0) ? ctl.dbg + 26 : nullptr;  // (tools/lists_phases.py)
     if (stamp) stamp[0] = clock64();
+    // ---- 1. everything the counting sort needs from HBM / L2, issued back to back (two train features per thread at most; indices clamped)
+    float tx[2], ty[2];
+    int tbin[2], trank[2];
+    ls_u32x4 tlo[2], thi[2];
+#pragma unroll
+    for (int k = 0; k < 2; k++) {
+        const int jc = max(min(tid + k * LS_THREADS, N - 1), 0);
+        tx[k] = ty[k] = 0.f, tbin[k] = trank[k] = 0;
+        tlo[k] = thi[k] = ls_u32x4{0, 0, 0, 0};
+        if (N > 0) {
+            tx[k] = T.x[jc], ty[k] = T.y[jc];
+            if (MODE != MODE_ROW) tbin[k] = min(max((int)T.hcy[jc], 0), ccy - 1) * ccx + min(max((int)T.hcx[jc], 0), ccx - 1);
+            const ls_u32x4 *d = reinterpret_cast<const ls_u32x4 *>(T.desc + (size_t)jc * 4);
+            tlo[k] = d[0], thi[k] = d[1];
+        }
+    }
     if (MODE == MODE_MAP && tid == 0) {  // the prediction, recomputed from the persistent state (k_early_map does the same)
         Pose predicted;
         double mmn[14];
         motion_predict(ctl, ctl.last_pose, predicted, mmn);
         world_to_camera(predicted, w2c);
     }
-    // ---- the train set, counting-sorted into the reference's hash cells / image rows (two features per thread at most)
-    if (tid == 0) s_work_n = 0;
     for (int i = tid; i <= nbins; i += LS_THREADS) s_start[i] = 0;
     __syncthreads();
-    int tbin[2], trank[2];
 #pragma unroll
     for (int k = 0; k < 2; k++) {
-        const int j = tid + k * LS_THREADS;
-        tbin[k] = 0, trank[k] = 0;
-        if (j < N) {
-            if (MODE == MODE_ROW) tbin[k] = min(max((int)floorf(T.y[j]), 0), nbins - 1);
-            else tbin[k] = min(max((int)T.hcy[j], 0), ccy - 1) * ccx + min(max((int)T.hcx[j], 0), ccx - 1);
-            trank[k] = atomicAdd(&s_start[tbin[k]], 1);
-        }
+        if (MODE == MODE_ROW) tbin[k] = min(max((int)floorf(ty[k]), 0), nbins - 1);
+        if (tid + k * LS_THREADS < N) trank[k] = atomicAdd(&s_start[tbin[k]], 1);
     }
     __syncthreads();
     {
@@ -115,33 +134,34 @@ __global__ __launch_bounds__(LS_THREADS) void k_hamming_batched_lists(SeqArg<BV>
         const int j = tid + k * LS_THREADS;
         if (j < N) {
             const int pos = s_start[tbin[k]] + trank[k];
-            s_xy[pos] = make_float2(T.x[j], T.y[j]);
+            s_xy[pos] = make_float2(tx[k], ty[k]);
             s_idx[pos] = (uint16_t)j;
-            const ls_u32x4 *d = reinterpret_cast<const ls_u32x4 *>(T.desc + (size_t)j * 4);
-            s_dlo[pos] = d[0];
-            s_dhi[pos] = d[1];
+            s_dlo[pos] = tlo[k];
+            s_dhi[pos] = thi[k];
         }
     }
-    __syncthreads();
-
     if (stamp) stamp[1] = clock64();
+
     const uint64_t *qdesc = (MODE == MODE_MAP) ? S.map[*S.map_cur].desc : S.fb[par].feat[0].desc;
     uint32_t *cand = (MODE == MODE_MAP) ? S.cand : S.rcand + (size_t)par * NF_MAX * KC;
     int *ncand = (MODE == MODE_MAP) ? S.ncand : S.rncand + par * NF_MAX;
     const int radius = S.prm.tracking_radius;
+    const float r2 = (float)(radius * radius);
 
-    // gridDim.x workgroups per sequence share the queries in EQUAL contiguous parts (whole wavefronts; each stages the train set itself): a list is one
-    // lane's serial walk, so what a second workgroup buys is issue slots and LDS bandwidth -- 1 000 row lists on one CU are 16 wavefronts on 4 SIMDs
-    // (117 us in a batch of 64 sequences), on eight CUs two wavefronts each
+    // gridDim.x workgroups per sequence share the queries in EQUAL contiguous parts (whole wavefronts; each stages the train set itself)
     const int part = (((q_end + (int)gridDim.x - 1) / (int)gridDim.x) + 63) & ~63;
     const int q_lo = (int)blockIdx.x * part, q_hi = min(q_end, q_lo + part);
-    for (int q0 = q_lo; q0 < q_hi; q0 += LS_THREADS) {
-        const int q = q0 + tid;
-        bool live = q < q_hi;
-        Query Q;
-        Q.x = Q.y = Q.r2 = 0.f;
-        Q.sy = Q.sx = 0, Q.ey = Q.ex = 0;
-        if (live) {
+    for (int q0 = q_lo; q0 < q_hi; q0 += LS_QCH) {
+        const int nq = min(LS_QCH, q_hi - q0);
+        // ---- 2. the chunk's queries: descriptors by coalesced loads, one thread per query for the projection and the window's ranges
+        __syncthreads();  // the bin starts are final (first chunk) / every wavefront is done with the previous chunk's words
+        if (tid < 2 * nq) s_qd[tid] = reinterpret_cast<const ls_u32x4 *>(qdesc + (size_t)q0 * 4)[tid];
+        if (tid < nq) {
+            const int q = q0 + tid;
+            bool live = true;
+            Query Q;
+            Q.x = Q.y = Q.r2 = 0.f;
+            Q.sy = Q.sx = 0, Q.ey = Q.ex = 0;
             if (MODE == MODE_MAP) {  // candidates_body<MODE_MAP, PROJECT>, one lane per point
                 const MapSoA &P = S.map[*S.map_cur];
                 const double X[3] = {P.pos[3 * q], P.pos[3 * q + 1], P.pos[3 * q + 2]};
@@ -156,151 +176,137 @@ __global__ __launch_bounds__(LS_THREADS) void k_hamming_batched_lists(SeqArg<BV>
                     S.vis[q] = 0;
                     P.counter[q] += 1;  // lvt_local_map.cpp:154
                     S.match[q] = -2;
-                    ncand[q] = 0;
                     live = false;
                 }
             } else {
                 make_query_row(S.prm, S.fb[par].feat[0].x[q], S.fb[par].feat[0].y[q], Q);
             }
-        }
-        // the window as contiguous LDS ranges: one per hash row of the window (tracking), one in all (row band)
-        int rs[5], rl[5];
+            // the window as contiguous LDS ranges: one per hash row of the window (tracking), one in all (row band)
+            uint32_t rg[5] = {0, 0, 0, 0, 0};
+            int total = 0;
+            if (live) {
+                if (MODE == MODE_ROW) {
+                    const int y0 = min(Q.sy, nbins - 1), y1 = min(Q.ey, nbins - 1);  // rows [sy, ey], both inside [0, H]
+                    if (y0 <= y1) {
+                        const int s0 = s_start[y0], l0 = s_start[y1 + 1] - s0;
+                        rg[0] = (uint32_t)s0 | ((uint32_t)l0 << 16), total = l0;
+                    }
+                } else if (Q.sx < Q.ex) {
 #pragma unroll
-        for (int k = 0; k < 5; k++) rs[k] = rl[k] = 0;
-        if (live) {
-            if (MODE == MODE_ROW) {
-                const int y0 = min(Q.sy, nbins - 1), y1 = min(Q.ey, nbins - 1);  // rows [sy, ey], both inside [0, H]
-                if (y0 <= y1) rs[0] = s_start[y0], rl[0] = s_start[y1 + 1] - rs[0];
-            } else if (Q.sx < Q.ex) {
-#pragma unroll
-                for (int k = 0; k < 5; k++) {
-                    const int r = Q.sy + k;  // cells [sy, ey) x [sx, ex), already clipped to the grid by make_query_track
-                    if (r < Q.ey) rs[k] = s_start[r * ccx + Q.sx], rl[k] = s_start[r * ccx + Q.ex] - rs[k];
+                    for (int k = 0; k < 5; k++) {
+                        const int r = Q.sy + k;  // cells [sy, ey) x [sx, ex), already clipped to the grid by make_query_track
+                        if (r < Q.ey) {
+                            const int s0 = s_start[r * ccx + Q.sx], l0 = s_start[r * ccx + Q.ex] - s0;
+                            rg[k] = (uint32_t)s0 | ((uint32_t)l0 << 16), total += l0;
+                        }
+                    }
                 }
             }
+            if (total == 0) ncand[q] = 0;  // (not visible, or an empty window: nothing for a wavefront to do)
+            s_qw[2 * tid] = ls_u32x4{(uint32_t)total, __float_as_uint(Q.x), __float_as_uint(Q.y), rg[0]};
+            s_qw[2 * tid + 1] = ls_u32x4{rg[1], rg[2], rg[3], rg[4]};
         }
-        const float fsy = (float)Q.sy, fey = (float)Q.ey;
-        // ---- pass 1: how many candidates satisfy the reference's predicate
-        int cnt = 0;
-#pragma unroll
-        for (int k = 0; k < 5; k++)
-            for (int pos = rs[k]; pos < rs[k] + rl[k]; pos++) {
-                const float2 c = s_xy[pos];
-                bool ok;
-                if (MODE == MODE_ROW) ok = c.y >= fsy && c.y <= fey;  // struct.cpp:132-134
-                else {
-                    const float dx = c.x - Q.x, dy = c.y - Q.y;
-                    ok = (dx * dx + dy * dy) < Q.r2;  // struct.cpp:95-99
-                }
-                cnt += ok ? 1 : 0;
-            }
+        __syncthreads();  // (... and the train set is in place)
         if (stamp) stamp[2] = clock64();
-        int total;
-        const int cnt4 = (cnt + 3) & ~3;  // segments start on 16-byte boundaries: the ranking below reads four keys per LDS access
-        const int off = block_excl_scan(cnt4, s_scan, &total);
-        uint64_t qd[4] = {0, 0, 0, 0};
-        if (live && cnt > 0) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) qd[k] = qdesc[(size_t)q * 4 + k];
-        }
-        // ---- pass 2: distances, insertion-sorted into the query's arena segment; chunks whose lists exceed the arena are cut at a query
-        int base = 0;
-        bool done = !live;
-        if (live && cnt == 0) {
-            ncand[q] = 0;
-            done = true;
-        }
-        for (;;) {
-            const bool mine = !done && (off + cnt4 - base <= LS_ARENA);  // (monotone in tid: the threads that fit are a prefix of those left)
-            if (mine) {
-                uint32_t *seg = s_arena + (off - base);
-                int n = 0;
-#pragma unroll
-                for (int k = 0; k < 5; k++)
-                    for (int pos = rs[k]; pos < rs[k] + rl[k]; pos++) {
-                        const float2 c = s_xy[pos];
+        // ---- 3. a wavefront per query, a lane per candidate; the next query's words are read while this one is worked on
+        ls_u32x4 W0 = s_qw[2 * min(wv, nq - 1)], W1 = s_qw[2 * min(wv, nq - 1) + 1], d0 = s_qd[2 * min(wv, nq - 1)], d1 = s_qd[2 * min(wv, nq - 1) + 1];
+        for (int ql = wv; ql < nq; ql += LS_WAVES) {
+            const int qn = min(ql + LS_WAVES, nq - 1);
+            const ls_u32x4 nW0 = s_qw[2 * qn], nW1 = s_qw[2 * qn + 1], nd0 = s_qd[2 * qn], nd1 = s_qd[2 * qn + 1];
+            const int total = __builtin_amdgcn_readfirstlane((int)W0.x);
+            if (total > 0) {
+                const int q = q0 + ql;
+                const float qx = __uint_as_float(W0.y), qy = __uint_as_float(W0.z);
+                // flattened index space: v in [c_k, c_{k+1}) is position v + o_k
+                const int l0 = (int)(W0.w >> 16), l1 = (int)(W1.x >> 16), l2 = (int)(W1.y >> 16), l3 = (int)(W1.z >> 16);
+                const int c1 = l0, c2 = c1 + l1, c3 = c2 + l2, c4 = c3 + l3;
+                const int o0 = (int)(W0.w & 0xFFFFu), o1 = (int)(W1.x & 0xFFFFu) - c1, o2 = (int)(W1.y & 0xFFFFu) - c2, o3 = (int)(W1.z & 0xFFFFu) - c3,
+                          o4 = (int)(W1.w & 0xFFFFu) - c4;
+                float fsy = 0.f, fey = 0.f;
+                if (MODE == MODE_ROW) {  // make_query_row's band again (struct.cpp:124-131)
+                    fsy = (float)max((int)qy - ROW_RADIUS, 0);
+                    fey = (float)min((int)qy + ROW_RADIUS, nbins - 1);  // (nbins - 1 = Params::H, kept in a register: a load from the Seq record here is a global round trip per query)
+                }
+                uint32_t *dst = cand + (size_t)q * KC;
+                // candidate v of the flattened ranges: predicate, distance, key
+                auto evaluate = [&](int v, bool &ok) -> uint32_t {
+                    const bool in = v < total;
+                    int pos = v + o0;
+                    if (MODE != MODE_ROW) {
+                        pos = (v >= c1) ? v + o1 : pos;
+                        pos = (v >= c2) ? v + o2 : pos;
+                        pos = (v >= c3) ? v + o3 : pos;
+                        pos = (v >= c4) ? v + o4 : pos;
+                    }
+                    pos = in ? pos : 0;
+                    const float2 c = s_xy[pos];
+                    const uint32_t id = s_idx[pos];
+                    const ls_u32x4 a0 = s_dlo[pos], a1 = s_dhi[pos];
+                    if (MODE == MODE_ROW) ok = c.y >= fsy && c.y <= fey;  // struct.cpp:132-134
+                    else {
+                        const float dx = c.x - qx, dy = c.y - qy;
+                        ok = (dx * dx + dy * dy) < r2;  // struct.cpp:95-99
+                    }
+                    ok = ok && in;
+                    uint32_t d = ls_bcnt(d0.x ^ a0.x, 0u);
+                    d = ls_bcnt(d0.y ^ a0.y, d);
+                    d = ls_bcnt(d0.z ^ a0.z, d);
+                    d = ls_bcnt(d0.w ^ a0.w, d);
+                    d = ls_bcnt(d1.x ^ a1.x, d);
+                    d = ls_bcnt(d1.y ^ a1.y, d);
+                    d = ls_bcnt(d1.z ^ a1.z, d);
+                    d = ls_bcnt(d1.w ^ a1.w, d);
+                    return (d << 16) | id;
+                };
+                if (total <= 64) {
+                    // (the usual case) the whole window in one pass: the keys never leave the registers.  rank = number of smaller keys among those that
+                    // passed (keys are unique: they carry the index), one v_readlane + compare + add-with-carry per key
+                    bool ok;
+                    const uint32_t key = evaluate(lane, ok);
+                    uint64_t bal = __ballot(ok);
+                    if (lane == 0) ncand[q] = __popcll(bal);
+                    int rank = 0;
+                    while (bal) {
+                        const int j = __builtin_ctzll(bal);
+                        bal &= bal - 1;
+                        rank += ((uint32_t)__builtin_amdgcn_readlane((int)key, j) < key) ? 1 : 0;
+                    }
+                    if (ok) dst[rank] = key;
+                } else {
+                    // a window of more than 64 features: the keys that pass are compacted into the wavefront's LDS segment (ballot prefix), then ranked with
+                    // broadcast reads of four keys at a time
+                    int n = 0;
+                    for (int vb = 0; vb < total; vb += 64) {
                         bool ok;
-                        if (MODE == MODE_ROW) ok = c.y >= fsy && c.y <= fey;
-                        else {
-                            const float dx = c.x - Q.x, dy = c.y - Q.y;
-                            ok = (dx * dx + dy * dy) < Q.r2;
-                        }
-                        if (ok) {
-                            const ls_u32x4 a0 = s_dlo[pos], a1 = s_dhi[pos];
-                            const int d = __popcll(qd[0] ^ (((uint64_t)a0.y << 32) | a0.x)) + __popcll(qd[1] ^ (((uint64_t)a0.w << 32) | a0.z)) +
-                                          __popcll(qd[2] ^ (((uint64_t)a1.y << 32) | a1.x)) + __popcll(qd[3] ^ (((uint64_t)a1.w << 32) | a1.z));
-                            seg[n++] = ((uint32_t)d << 16) | (uint32_t)s_idx[pos];
-                        }
+                        const uint32_t key = evaluate(vb + lane, ok);
+                        const uint64_t bal = __ballot(ok);
+                        const int slot = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                        if (ok && slot < LS_SEG) s_seg[slot] = key;
+                        n += __popcll(bal);
                     }
-                // rank = number of smaller keys (keys are unique: they carry the index): n^2 INDEPENDENT LDS reads and compares per lane,
-                // where an insertion sort is a chain of dependent read-modify-writes as long as its longest list in the wavefront
-                // (measured: 400 us for the row lists of a 16-sequence batch with the insertion sort)
-                if (n <= KC && n >= LS_COOP_MIN) {
-                    // a long list: a whole wavefront ranks it below (one key per lane, every comparison partner a broadcast read)
-                    for (int e = n; e < cnt4; e++) seg[e] = 0xFFFFFFFFu;
-                    s_work[atomicAdd(&s_work_n, 1)] = (uint32_t)tid | ((uint32_t)(off - base) << 10) | ((uint32_t)(n - 1) << 24);
-                } else if (n <= KC) {
-                    for (int e = n; e < cnt4; e++) seg[e] = 0xFFFFFFFFu;  // padding: never smaller than a key
-                    const uint4 *seg4 = reinterpret_cast<const uint4 *>(seg);
-                    for (int e = 0; e < n; e += 4) {  // four keys against every vector of four: n^2 / 16 LDS reads
-                        const uint4 k4 = seg4[e >> 2];
-                        int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-                        for (int o = 0; o < cnt4; o += 4) {
-                            const uint4 v = seg4[o >> 2];
-                            r0 += (v.x < k4.x) + (v.y < k4.x) + (v.z < k4.x) + (v.w < k4.x);
-                            r1 += (v.x < k4.y) + (v.y < k4.y) + (v.z < k4.y) + (v.w < k4.y);
-                            r2 += (v.x < k4.z) + (v.y < k4.z) + (v.z < k4.z) + (v.w < k4.z);
-                            r3 += (v.x < k4.w) + (v.y < k4.w) + (v.z < k4.w) + (v.w < k4.w);
+                    if (lane == 0) ncand[q] = n;  // (> KC: the resolvers take the exact slow path, as with k_candidates)
+                    if (n > 0 && n <= KC) {
+                        if (lane < ((n + 3) & ~3) - n) s_seg[n + lane] = 0xFFFFFFFFu;  // padded to whole vectors of four
+                        __builtin_amdgcn_wave_barrier();  // (LDS operations of one wavefront complete in order: no hardware barrier needed)
+                        const uint4 *seg4 = reinterpret_cast<const uint4 *>(s_seg);
+                        const uint32_t ka = lane < n ? s_seg[lane] : 0xFFFFFFFFu, kb = lane + 64 < n ? s_seg[lane + 64] : 0xFFFFFFFFu;
+                        int ra = 0, rb = 0;
+                        for (int o = 0; o < n; o += 4) {
+                            const uint4 kv = seg4[o >> 2];
+                            ra += (kv.x < ka) + (kv.y < ka) + (kv.z < ka) + (kv.w < ka);
+                            rb += (kv.x < kb) + (kv.y < kb) + (kv.z < kb) + (kv.w < kb);
                         }
-                        uint32_t *dst = cand + (size_t)q * KC;
-                        dst[r0] = k4.x;
-                        if (e + 1 < n) dst[r1] = k4.y;
-                        if (e + 2 < n) dst[r2] = k4.z;
-                        if (e + 3 < n) dst[r3] = k4.w;
+                        if (lane < n) dst[ra] = ka;
+                        if (lane + 64 < n) dst[rb] = kb;
+                        __builtin_amdgcn_wave_barrier();  // the segment is rewritten by this wavefront's next long window
                     }
                 }
-                ncand[q] = n;  // (> KC: the resolvers take the exact slow path, as with k_candidates)
-                done = true;
             }
-            if (stamp) stamp[3] = clock64();
-            // ---- the long lists of this pass, one per wavefront at a time: lane l owns keys l and l + 64 (n <= KC = 128), counts the smaller ones
-            //      among all n (four per broadcast read) and stores its keys at their ranks -- ~n / 4 trips where a single lane needs (n / 4)^2
-            __syncthreads();
-            if (stamp) stamp[4] = clock64();
-            {
-                const int nwork = s_work_n, lane = tid & 63;
-                for (int w = tid >> 6; w < nwork; w += LS_THREADS / 64) {
-                    const uint32_t e = s_work[w];
-                    const int qw = q0 + (int)(e & 1023u), n = (int)(e >> 24) + 1;
-                    const uint32_t *seg = s_arena + ((e >> 10) & 16383u);
-                    const uint4 *seg4 = reinterpret_cast<const uint4 *>(seg);
-                    const uint32_t ka = lane < n ? seg[lane] : 0xFFFFFFFFu, kb = lane + 64 < n ? seg[lane + 64] : 0xFFFFFFFFu;
-                    int ra = 0, rb = 0;
-                    for (int o = 0; o < n; o += 4) {  // (the segment is padded with 0xFFFFFFFF up to a multiple of four)
-                        const uint4 v = seg4[o >> 2];
-                        ra += (v.x < ka) + (v.y < ka) + (v.z < ka) + (v.w < ka);
-                        rb += (v.x < kb) + (v.y < kb) + (v.z < kb) + (v.w < kb);
-                    }
-                    uint32_t *dst = cand + (size_t)qw * KC;
-                    if (lane < n) dst[ra] = ka;
-                    if (lane + 64 < n) dst[rb] = kb;
-                }
-            }
-            __syncthreads();
-            if (stamp) stamp[5] = clock64();
-            if (tid == 0) s_work_n = 0;
-            if (total <= LS_ARENA) break;  // (block-uniform: everything fitted in one go)
-            __syncthreads();
-            if (tid == 0) s_next = 0x7FFFFFFF;
-            __syncthreads();
-            if (!done) atomicMin(&s_next, off);
-            __syncthreads();
-            const int nb = s_next;
-            if (nb == 0x7FFFFFFF) break;
-            base = nb;
+            W0 = nW0, W1 = nW1, d0 = nd0, d1 = nd1;
         }
-        __syncthreads();  // the arena is reused by the next chunk
+        if (stamp) stamp[3] = clock64();
     }
+    if (stamp) stamp[4] = stamp[5] = clock64();
 }
 
 }  // namespace lvt

@@ -422,7 +422,7 @@ __global__ __launch_bounds__(256) void k_match_map(SeqArg<BV> sa, int par, seq_t
 // the barrier, SHORTENING the feature chain made the whole pipeline slower -- and the event record costs the tracking stream
 // 3-4 us per frame.  (LVT_AMD_ORDERING=events uses the barrier instead of this kernel.)
 __global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, seq_t want, int par) {
-    Ctl &ctl = *seqs[blockIdx.z].ctl;
+    Ctl &ctl = *seq_const(seqs, blockIdx.z).ctl;
     if (threadIdx.x != 0) return;
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(&ctl.track_done_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, seq_t want, int par)
             // (FeatCtl::poison), k_brief publishes "no features" (skip_seq) and the tracking chain SKIPS the frame -- last pose
             // returned, state kept, reported through lvt_amd_last_error.  Never LOST: that state is sticky and, in the reference,
             // a matter of match counts only.
-            seqs[blockIdx.z].fb[par].fc->poison = 1;
+            seq_const(seqs, blockIdx.z).fb[par].fc->poison = 1;
             atomicAdd(&ctl.gate_fatal, 1);
             __threadfence();
             break;
@@ -445,8 +445,8 @@ __global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, seq_t want, int par)
 // every workgroup's release fence is an L2 write-back.)
 __global__ void k_feat_done(Seq *seqs, int par, seq_t seq) {
     if (threadIdx.x != 0) return;
-    FeatCtl &fc = *seqs[blockIdx.x].fb[par].fc;
-    seqs[blockIdx.x].ctl->dbg[47] = (long long)wall_clock64();  // (written from the feature stream: the frame it belongs to may differ)
+    FeatCtl &fc = *seq_const(seqs, blockIdx.x).fb[par].fc;
+    seq_const(seqs, blockIdx.x).ctl->dbg[47] = (long long)wall_clock64();  // (written from the feature stream: the frame it belongs to may differ)
     if (fc.poison) {  // the frame has no features (k_gate_buf timed out): say so to the gates of the other streams, then release the flag
         fc.skip_seq = seq;
         fc.poison = 0;
@@ -458,7 +458,7 @@ __global__ void k_feat_done(Seq *seqs, int par, seq_t seq) {
 // behind k_candidates<ROW>: this frame's row-match candidate lists are complete (k_triangulate's head polls the word)
 __global__ void k_row_done(Seq *seqs, int par, seq_t seq) {
     if (threadIdx.x != 0) return;
-    FeatCtl &fc = *seqs[blockIdx.x].fb[par].fc;
+    FeatCtl &fc = *seq_const(seqs, blockIdx.x).fb[par].fc;
     if (__hip_atomic_load(&fc.feat_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < seq) return;  // (see k_candidates)
     __threadfence();
     atomicExch(&fc.row_seq, seq);
@@ -1304,7 +1304,7 @@ __device__ __forceinline__ void deliver_record(const Ctl &ctl, Ctl *rec_out, seq
 }
 // (the last enqueued frame has no successor: the host launches this when it is asked for that frame's result)
 __global__ __launch_bounds__(64) void k_deliver(Seq *seqs, Ctl *rec_out, seq_t *done_out, seq_t seq) {
-    deliver_record(*seqs[blockIdx.z].ctl, rec_out + blockIdx.z, done_out + blockIdx.z, seq, 64);
+    deliver_record(*seq_const(seqs, blockIdx.z).ctl, rec_out + blockIdx.z, done_out + blockIdx.z, seq, 64);
 }
 
 // the tracking stream's wait for the early stream (one thread; see k_gate_late / k_match_map)

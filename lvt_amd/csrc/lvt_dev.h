@@ -165,6 +165,7 @@ struct FrameBuf {
     float *cell_kp[2];          // [CELLS_MAX][CELL_OUT_CAP][3] (x, y, response)
     int *cell_n[2];             // [CELLS_MAX]
     const float *ext_xy[2];     // external corners (n_ext x 2, f32) for track_with_external_corners
+    const float *ext_xy_own[2]; // the lists the context was created with (ext_xy points at them again whenever a frame brings none of its own)
     Feat feat[2];
     FeatCtl *fc;
 };
@@ -255,10 +256,18 @@ __device__ __forceinline__ int block_excl_scan(int v, int *scratch, int *total) 
 // which only the feature stage writes and reads.
 template <bool BYVAL>
 struct SeqArg;
+// Round 6: the element of the device array is read through the CONSTANT address space.  A pointer loaded from generic / global memory is a FLAT pointer to the
+// compiler, and every access through it a flat_load / flat_store: those count on lgkmcnt as well as vmcnt, so each wait for an LDS read also waited for every
+// global load and store in flight (the LDS-latency-bound kernels of a batch -- k_cells, the resolvers, k_triangulate, the list kernels -- paid a memory round trip
+// per LDS access; the by-value form never did: its pointers come out of the kernel arguments).  A pointer loaded from constant memory is taken to be a global one
+// (AMDGPUTargetMachine::getAssumedAddrSpace), the loads of the record's fields become scalar loads.  Valid here: the fields these kernels read are written
+// by the host at creation and by kernels that finished before this one started (never during it).
+typedef const __attribute__((address_space(4))) Seq *SeqConstPtr;
+__device__ __forceinline__ const Seq &seq_const(const Seq *p, unsigned i) { return *(const Seq *)((SeqConstPtr)p + i); }
 template <>
 struct SeqArg<false> {
     const Seq *p;
-    __device__ __forceinline__ const Seq &get() const { return p[blockIdx.z]; }
+    __device__ __forceinline__ const Seq &get() const { return seq_const(p, blockIdx.z); }
 };
 template <>
 struct SeqArg<true> {

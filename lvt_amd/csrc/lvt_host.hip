@@ -544,6 +544,9 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         if (const char *e = std::getenv("LVT_AMD_CELL_SPLIT")) c->cell_split = std::max(0, std::min(SPLIT_MAX, std::atoi(e)));
         if (const char *e = std::getenv("LVT_AMD_CELLS_RAW_CAP")) c->cells_raw_cap = std::max(RAW_CAP_SMALL, std::min(RAW_CAP, std::atoi(e) & ~1));
         if (const char *e = std::getenv("LVT_AMD_FUSED_PULL")) c->fuse_pull = std::atoi(e) != 0;
+        // list kernels: a workgroup works its queries off 16 at a time (a wavefront per query), so a sequence wants many workgroups -- but every one of them
+        // stages the train set in 148 KB of LDS (one per CU) and the other streams' kernels need CUs at the same time: half a round of workgroups over the chip for the whole batch
+        c->lists_wgs_row = c->lists_wgs_map = std::max(1, std::min(8, 128 / std::max(1, B)));
         if (const char *e = std::getenv("LVT_AMD_LISTS_WGS")) {
             int r = 0, m = 0;
             const int got = std::sscanf(e, "%d,%d", &r, &m);
@@ -595,7 +598,7 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
                         c->d_ext[par][e] = c->dalloc<float>((size_t)EXT_MAX * 2);
                         c->d_img[par][e] = c->dalloc<uint8_t>(plane + 64);
                     }
-                    FB.ext_xy[e] = c->d_ext[par][e];
+                    FB.ext_xy[e] = FB.ext_xy_own[e] = c->d_ext[par][e];
                 }
                 if (s == 0 && sensor == 2) c->d_depth[par] = c->dalloc<float>((size_t)prm.W * prm.H + 4);
             }

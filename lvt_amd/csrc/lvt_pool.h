@@ -145,6 +145,9 @@ static void pool_enqueue_step(Pool *P, std::unique_lock<std::mutex> &lk) {
     }
     lk.lock();
     P->busy = false;
+    // (enqueue_frame advances c->enq with its LAST statement: an exception always leaves c->enq == enq_before -- a partly launched chain included; the
+    //  kernels already enqueued for it find the same frame number again with the next step and redo the buffers, the step's frames are handed back here.
+    //  R / t of such a record are the previous frame's: only `state` = -1 and the handle's error text describe the failed frame.)
     if (failed && c->enq == enq_before) {
         // the step never reached the launch chain: nothing will complete for it.  Its frames are handed back as FAILED records (state -1: what
         // lvt_amd_wait_status returns for an error) with the reason on every handle that had a frame in it -- never the previous step's record.
@@ -365,6 +368,7 @@ static int slot_submit(PoolSlot *S, const uint8_t *l, const uint8_t *r, int rows
                 S->d_img[p.stage][0] = S->d_img[p.stage][1] = nullptr;
                 (void)hipGetLastError();
                 S->err = "out of memory for a pooled handle's staging buffers (the frame was NOT enqueued)";
+                S->submitted--;  // (still under the lock: the staging rotation must not run ahead of the frames really queued)
                 return -1;
             }
         }
@@ -381,6 +385,7 @@ static int slot_submit(PoolSlot *S, const uint8_t *l, const uint8_t *r, int rows
                     S->d_ext[p.stage][0] = S->d_ext[p.stage][1] = nullptr;
                     (void)hipGetLastError();
                     S->err = "out of memory for a pooled handle's corner lists (the frame was NOT enqueued)";
+                    S->submitted--;
                     return -1;
                 }
             }

@@ -162,6 +162,14 @@ class SynthWorld:
     def render_stereo_torch(self, i: int, device="cuda"):
         """Returns a (2, H, W) uint8 tensor on `device` (left, right).  Same math as render(); used by
         bench.py to pre-render hundreds of full-size frames directly into HBM."""
+        return self._render_torch(i, (0, 1), device, False)
+
+    def render_rgbd_torch(self, i: int, device="cuda"):
+        """(gray u8 (H, W), depth f32 (H, W)) tensors on `device`: render_rgbd()'s math (the full-length RGB-D parity test renders 573 frames this way)"""
+        g, d = self._render_torch(i, (0,), device, True)
+        return g[0], d
+
+    def _render_torch(self, i: int, eyes, device, want_depth):
         import torch
         if self._torch_cache is None or self._torch_cache[0] != str(device):
             lay = [(torch.from_numpy(L.tex).to(device), torch.from_numpy(L.alpha).to(device)) for L in self.layers]
@@ -170,8 +178,11 @@ class SynthWorld:
             self._torch_cache = (str(device), lay, u, v)
         _, lay, u, v = self._torch_cache
         outs = []
-        for eye in (0, 1):
+        depth = None
+        for eye in eyes:
             img = torch.zeros((self.H, self.W), dtype=torch.float64, device=device)
+            if want_depth:
+                depth = torch.zeros((self.H, self.W), dtype=torch.float64, device=device)
             for L, (tex, alpha), (Hi, R, c) in zip(self.layers, lay, self._homographies(i, eye)):
                 th, tw = L.tex.shape
                 wq = Hi[2, 0] * u + Hi[2, 1] * v + Hi[2, 2]
@@ -187,11 +198,18 @@ class SynthWorld:
                 ar = torch.floor(a + 0.5).clamp(0, tw - 1).long(); br = torch.floor(b + 0.5).clamp(0, th - 1).long()
                 ok = ok & alpha[br, ar]
                 img = torch.where(ok, val, img)
+                if want_depth:
+                    Xw = (a - tw / 2.0) * L.scale - c[0]
+                    Yw = (b - th / 2.0) * L.scale - c[1]
+                    Zw = L.depth - c[2]
+                    depth = torch.where(ok, R[0, 2] * Xw + R[1, 2] * Yw + R[2, 2] * Zw, depth)
             if self.noise > 0:
                 rng = np.random.Generator(np.random.PCG64([0x4E4F495345, self.seed, int(i), int(eye)]))
                 nz = torch.from_numpy(rng.integers(-self.noise, self.noise + 1, size=(self.H, self.W)).astype(np.float64))
                 img = img + nz.to(device)
             outs.append(torch.floor(img + 0.5).clamp(0, 255).to(torch.uint8))
+        if want_depth:
+            return torch.stack(outs, 0), depth.to(torch.float32)
         return torch.stack(outs, 0)
 
 

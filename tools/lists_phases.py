@@ -22,9 +22,9 @@ for i in range(n):
     d = vo.debug_stamps()[26:32]
     c = vo.counts(0)
     if i >= 5 and d[0] and c["n_row_matches"]:
-        acc.append([d[1] - d[0], d[2] - d[1], d[3] - d[2], d[4] - d[3], d[5] - d[4], d[5] - d[0], c["n_left"], c["n_right"]])
+        acc.append([d[1] - d[0], d[2] - d[1], d[3] - d[2], d[3] - d[0], c["n_left"], c["n_right"]])
 a = np.array(acc, dtype=np.float64)
 print("frames with row lists:", len(a))
 if len(a):
     m = a.mean(axis=0)
-    print("cycles: staging %.0f  pass1 (count) %.0f  scan + pass2 (distances) + lane ranking %.0f  barrier %.0f  wave ranking %.0f  total %.0f   (n_left %.0f n_right %.0f)" % tuple(m))
+    print("cycles: loads + counting sort + scatter %.0f  query words + descriptors %.0f  wavefront-per-query lists %.0f  total %.0f   (n_left %.0f n_right %.0f)" % tuple(m))

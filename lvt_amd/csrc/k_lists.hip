@@ -6,36 +6,39 @@
 // stages the train set once per workgroup in LDS, counting-sorted into the reference's own 25-px hash cells (tracking) or image rows
 // (row matching), exactly as k_hamming_batched does (k_hamming.hip) -- a query's candidates are then <= 5 CONTIGUOUS LDS ranges.
 //
-// Round 6: ONE WAVEFRONT PER QUERY, ONE LANE PER CANDIDATE.  (Rounds 2 - 5 gave every query one lane that walked its ~20 candidates
+// Round 6: A LANE PER CANDIDATE, FOUR QUERIES PER WAVEFRONT (one per DPP row of 16 lanes).  (Rounds 2 - 5 gave every query one lane that walked its ~20 candidates
 // serially -- twice, to size an arena segment first -- and ranked them by counting, (n / 4)^2 trips per lane: 89 us for the row lists of a
 // 16-sequence batch, the kernel ending with its longest list.)  Now
 //   1. every global load of the train set is in flight before the counting sort starts (one round trip, not two);
 //   2. one thread per query of a chunk of <= 512 projects the point (map mode: is_point_visible, lvt_local_map.cpp:62-82,152-156, leaving
 //      proj / vis / match / counter exactly as k_early_map does) and packs the window's ranges into eight LDS words; the chunk's query
 //      descriptors are copied to LDS with coalesced loads;
-//   3. a wavefront takes a query: lane v evaluates candidate v of the flattened ranges -- predicate, 256-bit distance, key
-//      (distance << 16 | index) -- the keys that pass are compacted into the wavefront's own LDS segment (ballot prefix), and every lane
-//      ranks its key among them with broadcast reads of four keys at a time: the rank is the key's place in the list.  Neighbouring
-//      lanes read neighbouring descriptors: no bank conflicts, no serial chain longer than n / 4 trips.
+//   3. a wavefront takes four queries, a row of 16 lanes each: lane s of a row evaluates candidates s, s + 16, ... of its query's flattened ranges --
+//      predicate, 256-bit distance, key (distance << 16 | index) -- the keys that pass are compacted into the row's own LDS segment (ballot
+//      prefix), and every lane ranks its keys among them with reads of four keys at a time: the rank is the key's place in the list.
+//      Neighbouring lanes read neighbouring descriptors: no bank conflicts, no serial chain longer than n / 4 trips.  (A wavefront per
+//      query was built first: ~225 wave instructions per query against ~60 here -- its ranking by v_readlane alone cost 160.)
 //
 // Output contract = k_candidates': cand[q][0 .. min(n, KC)) ascending, ncand[q] = n (n > KC: the resolvers' exact slow path).
 // The bins ARE the reference's hash cells (Feat::hcx / hcy), so "candidate in the window's cells" is decided by the range bounds and the
 // wavefront only evaluates the radius; row mode evaluates the band test itself (struct.cpp:132-134).
-// Capacity: 2048 train features and 4100 bins per LDS image; beyond that (or for a cell search radius above 2) the kernel does
+// Capacity: 1536 train features and 1100 bins per LDS image (94 KB of LDS per 512-thread workgroup); beyond that (or for a cell search radius above 2) the kernel does
 // NOTHING and raises Seq::lists_fb, and the wave-per-query kernel launched behind it does the work as before.
 #include "lvt_dev.h"
 #include "lvt_math.h"
 
 namespace lvt {
 
-constexpr int LS_THREADS = 1024;
+constexpr int LS_THREADS = 512;
 constexpr int LS_WAVES = LS_THREADS / 64;
-constexpr int LS_NMAX = 2048;   // train features of one LDS image
-constexpr int LS_BINS = 4100;   // hash cells / image rows + 1
-constexpr int LS_QCH = 512;     // queries of one chunk: descriptors and window words in LDS
-constexpr int LS_SEG = KC + 64; // keys a wavefront collects for one query (past KC only the count matters)
+constexpr int LS_TPT = 3;       // train features per thread
+constexpr int LS_NMAX = LS_THREADS * LS_TPT;  // 1536 train features of one LDS image
+constexpr int LS_BINS = 1100;   // hash cells / image rows + 1
+constexpr int LS_QCH = 256;     // queries of one chunk: descriptors and window words in LDS
+constexpr int LS_SEG = 256;     // key words of one wavefront: four segments of 64 (a query per DPP row), or one of KC + 64 (a window of more than 64 features)
 constexpr int LS_STARTS = (LS_BINS + 4) & ~3;
 constexpr int LS_LDS_BYTES = LS_NMAX * 42 + LS_STARTS * 4 + LS_QCH * 64 + LS_WAVES * LS_SEG * 4 + 256;
+static_assert(KC + 64 <= LS_SEG, "the long-window path shares the wavefront's segment words");
 typedef unsigned int ls_u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ uint32_t ls_bcnt(uint32_t x, uint32_t acc) {  // acc + popcount(x): one instruction
@@ -85,12 +88,12 @@ __global__ __launch_bounds__(LS_THREADS) void k_hamming_batched_lists(SeqArg<BV>
 
     long long *stamp = (MODE == MODE_ROW && blockIdx.x == 0 && tid == 0) ? ctl.dbg + 26 : nullptr;  // (tools/lists_phases.py)
     if (stamp) stamp[0] = clock64();
-    // ---- 1. everything the counting sort needs from HBM / L2, issued back to back (two train features per thread at most; indices clamped)
-    float tx[2], ty[2];
-    int tbin[2], trank[2];
-    ls_u32x4 tlo[2], thi[2];
+    // ---- 1. everything the counting sort needs from HBM / L2, issued back to back (LS_TPT train features per thread at most; indices clamped)
+    float tx[LS_TPT], ty[LS_TPT];
+    int tbin[LS_TPT], trank[LS_TPT];
+    ls_u32x4 tlo[LS_TPT], thi[LS_TPT];
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < LS_TPT; k++) {
         const int jc = max(min(tid + k * LS_THREADS, N - 1), 0);
         tx[k] = ty[k] = 0.f, tbin[k] = trank[k] = 0;
         tlo[k] = thi[k] = ls_u32x4{0, 0, 0, 0};
@@ -110,7 +113,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_hamming_batched_lists(SeqArg<BV>
     for (int i = tid; i <= nbins; i += LS_THREADS) s_start[i] = 0;
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < LS_TPT; k++) {
         if (MODE == MODE_ROW) tbin[k] = min(max((int)floorf(ty[k]), 0), nbins - 1);
         if (tid + k * LS_THREADS < N) trank[k] = atomicAdd(&s_start[tbin[k]], 1);
     }
@@ -130,7 +133,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_hamming_batched_lists(SeqArg<BV>
     }
     __syncthreads();
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < LS_TPT; k++) {
         const int j = tid + k * LS_THREADS;
         if (j < N) {
             const int pos = s_start[tbin[k]] + trank[k];
@@ -208,28 +211,98 @@ __global__ __launch_bounds__(LS_THREADS) void k_hamming_batched_lists(SeqArg<BV>
         }
         __syncthreads();  // (... and the train set is in place)
         if (stamp) stamp[2] = clock64();
-        // ---- 3. a wavefront per query, a lane per candidate; the next query's words are read while this one is worked on
-        ls_u32x4 W0 = s_qw[2 * min(wv, nq - 1)], W1 = s_qw[2 * min(wv, nq - 1) + 1], d0 = s_qd[2 * min(wv, nq - 1)], d1 = s_qd[2 * min(wv, nq - 1) + 1];
-        for (int ql = wv; ql < nq; ql += LS_WAVES) {
-            const int qn = min(ql + LS_WAVES, nq - 1);
-            const ls_u32x4 nW0 = s_qw[2 * qn], nW1 = s_qw[2 * qn + 1], nd0 = s_qd[2 * qn], nd1 = s_qd[2 * qn + 1];
+        // ---- 3. FOUR queries per wavefront, one per DPP row of 16 lanes, a lane per candidate and pass of 16 candidates
+        const int row = lane >> 4, sl = lane & 15;
+        uint32_t *dst_base = cand + (size_t)q0 * KC;
+        // a window of more than 64 features (rare): the whole wavefront takes the one query, 64 candidates per pass; the keys that pass are compacted into the
+        // wavefront's segment (ballot prefix) and ranked with broadcast reads of four keys at a time
+        auto long_window = [&](int ql) {
+            const ls_u32x4 W0 = s_qw[2 * ql], W1 = s_qw[2 * ql + 1], d0 = s_qd[2 * ql], d1 = s_qd[2 * ql + 1];
             const int total = __builtin_amdgcn_readfirstlane((int)W0.x);
-            if (total > 0) {
-                const int q = q0 + ql;
-                const float qx = __uint_as_float(W0.y), qy = __uint_as_float(W0.z);
-                // flattened index space: v in [c_k, c_{k+1}) is position v + o_k
-                const int l0 = (int)(W0.w >> 16), l1 = (int)(W1.x >> 16), l2 = (int)(W1.y >> 16), l3 = (int)(W1.z >> 16);
-                const int c1 = l0, c2 = c1 + l1, c3 = c2 + l2, c4 = c3 + l3;
-                const int o0 = (int)(W0.w & 0xFFFFu), o1 = (int)(W1.x & 0xFFFFu) - c1, o2 = (int)(W1.y & 0xFFFFu) - c2, o3 = (int)(W1.z & 0xFFFFu) - c3,
-                          o4 = (int)(W1.w & 0xFFFFu) - c4;
-                float fsy = 0.f, fey = 0.f;
-                if (MODE == MODE_ROW) {  // make_query_row's band again (struct.cpp:124-131)
-                    fsy = (float)max((int)qy - ROW_RADIUS, 0);
-                    fey = (float)min((int)qy + ROW_RADIUS, nbins - 1);  // (nbins - 1 = Params::H, kept in a register: a load from the Seq record here is a global round trip per query)
+            const float qx = __uint_as_float(W0.y), qy = __uint_as_float(W0.z);
+            const int l0 = (int)(W0.w >> 16), l1 = (int)(W1.x >> 16), l2 = (int)(W1.y >> 16), l3 = (int)(W1.z >> 16);
+            const int c1 = l0, c2 = c1 + l1, c3 = c2 + l2, c4 = c3 + l3;
+            const int o0 = (int)(W0.w & 0xFFFFu), o1 = (int)(W1.x & 0xFFFFu) - c1, o2 = (int)(W1.y & 0xFFFFu) - c2, o3 = (int)(W1.z & 0xFFFFu) - c3,
+                      o4 = (int)(W1.w & 0xFFFFu) - c4;
+            const float fsy = (float)max((int)qy - ROW_RADIUS, 0), fey = (float)min((int)qy + ROW_RADIUS, nbins - 1);
+            int n = 0;
+            for (int vb = 0; vb < total; vb += 64) {
+                const int v = vb + lane;
+                const bool in = v < total;
+                int pos = v + o0;
+                if (MODE != MODE_ROW) {
+                    pos = (v >= c1) ? v + o1 : pos;
+                    pos = (v >= c2) ? v + o2 : pos;
+                    pos = (v >= c3) ? v + o3 : pos;
+                    pos = (v >= c4) ? v + o4 : pos;
                 }
-                uint32_t *dst = cand + (size_t)q * KC;
-                // candidate v of the flattened ranges: predicate, distance, key
-                auto evaluate = [&](int v, bool &ok) -> uint32_t {
+                pos = in ? pos : 0;
+                const float2 c = s_xy[pos];
+                const uint32_t id = s_idx[pos];
+                const ls_u32x4 a0 = s_dlo[pos], a1 = s_dhi[pos];
+                bool ok;
+                if (MODE == MODE_ROW) ok = c.y >= fsy && c.y <= fey;
+                else {
+                    const float dx = c.x - qx, dy = c.y - qy;
+                    ok = (dx * dx + dy * dy) < r2;
+                }
+                ok = ok && in;
+                uint32_t d = ls_bcnt(d0.x ^ a0.x, 0u);
+                d = ls_bcnt(d0.y ^ a0.y, d), d = ls_bcnt(d0.z ^ a0.z, d), d = ls_bcnt(d0.w ^ a0.w, d);
+                d = ls_bcnt(d1.x ^ a1.x, d), d = ls_bcnt(d1.y ^ a1.y, d), d = ls_bcnt(d1.z ^ a1.z, d), d = ls_bcnt(d1.w ^ a1.w, d);
+                const uint64_t bal = __ballot(ok);
+                const int slot = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
+                if (ok && slot < KC + 64) s_seg[slot] = (d << 16) | id;
+                n += __popcll(bal);
+            }
+            if (lane == 0) ncand[q0 + ql] = n;  // (> KC: the resolvers take the exact slow path, as with k_candidates)
+            if (n > 0 && n <= KC) {
+                if (lane < ((n + 3) & ~3) - n) s_seg[n + lane] = 0xFFFFFFFFu;  // padded to whole vectors of four
+                __builtin_amdgcn_wave_barrier();  // (LDS operations of one wavefront complete in order: no hardware barrier needed)
+                const uint4 *seg4 = reinterpret_cast<const uint4 *>(s_seg);
+                const uint32_t ka = lane < n ? s_seg[lane] : 0xFFFFFFFFu, kb = lane + 64 < n ? s_seg[lane + 64] : 0xFFFFFFFFu;
+                int ra = 0, rb = 0;
+                for (int o = 0; o < n; o += 4) {
+                    const uint4 kv = seg4[o >> 2];
+                    ra += (kv.x < ka) + (kv.y < ka) + (kv.z < ka) + (kv.w < ka);
+                    rb += (kv.x < kb) + (kv.y < kb) + (kv.z < kb) + (kv.w < kb);
+                }
+                uint32_t *dst = dst_base + (size_t)ql * KC;
+                if (lane < n) dst[ra] = ka;
+                if (lane + 64 < n) dst[rb] = kb;
+            }
+            __builtin_amdgcn_wave_barrier();
+        };
+        for (int qb = wv * 4; qb < nq; qb += LS_WAVES * 4) {
+            const int ql = min(qb + row, nq - 1);
+            const bool have = qb + row < nq;
+            const ls_u32x4 W0 = s_qw[2 * ql], W1 = s_qw[2 * ql + 1];
+            const int total = have ? (int)W0.x : 0;
+            const int tmax = max(max(__builtin_amdgcn_readlane(total, 0), __builtin_amdgcn_readlane(total, 16)),
+                                 max(__builtin_amdgcn_readlane(total, 32), __builtin_amdgcn_readlane(total, 48)));
+            if (tmax == 0) continue;
+            if (tmax > 64) {  // (wave-uniform)
+                for (int r = 0; r < 4; r++)
+                    if (qb + r < nq && __builtin_amdgcn_readfirstlane((int)s_qw[2 * (qb + r)].x) > 0) long_window(qb + r);
+                continue;
+            }
+            const ls_u32x4 d0 = s_qd[2 * ql], d1 = s_qd[2 * ql + 1];
+            const float qx = __uint_as_float(W0.y), qy = __uint_as_float(W0.z);
+            // flattened index space: v in [c_k, c_{k+1}) is position v + o_k
+            const int l0 = (int)(W0.w >> 16), l1 = (int)(W1.x >> 16), l2 = (int)(W1.y >> 16), l3 = (int)(W1.z >> 16);
+            const int c1 = l0, c2 = c1 + l1, c3 = c2 + l2, c4 = c3 + l3;
+            const int o0 = (int)(W0.w & 0xFFFFu), o1 = (int)(W1.x & 0xFFFFu) - c1, o2 = (int)(W1.y & 0xFFFFu) - c2, o3 = (int)(W1.z & 0xFFFFu) - c3,
+                      o4 = (int)(W1.w & 0xFFFFu) - c4;
+            // make_query_row's band again (struct.cpp:124-131); nbins - 1 = Params::H (a load from the Seq record here would be a memory round trip per query)
+            const float fsy = (float)max((int)qy - ROW_RADIUS, 0), fey = (float)min((int)qy + ROW_RADIUS, nbins - 1);
+            uint32_t *seg = s_seg + row * 64;
+            const int P = (tmax + 15) >> 4;  // passes of 16 candidates per row
+            uint32_t K[4] = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+            int n = 0;
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                if (p < P) {
+                    const int v = p * 16 + sl;
                     const bool in = v < total;
                     int pos = v + o0;
                     if (MODE != MODE_ROW) {
@@ -242,6 +315,7 @@ __global__ __launch_bounds__(LS_THREADS) void k_hamming_batched_lists(SeqArg<BV>
                     const float2 c = s_xy[pos];
                     const uint32_t id = s_idx[pos];
                     const ls_u32x4 a0 = s_dlo[pos], a1 = s_dhi[pos];
+                    bool ok;
                     if (MODE == MODE_ROW) ok = c.y >= fsy && c.y <= fey;  // struct.cpp:132-134
                     else {
                         const float dx = c.x - qx, dy = c.y - qy;
@@ -249,60 +323,36 @@ __global__ __launch_bounds__(LS_THREADS) void k_hamming_batched_lists(SeqArg<BV>
                     }
                     ok = ok && in;
                     uint32_t d = ls_bcnt(d0.x ^ a0.x, 0u);
-                    d = ls_bcnt(d0.y ^ a0.y, d);
-                    d = ls_bcnt(d0.z ^ a0.z, d);
-                    d = ls_bcnt(d0.w ^ a0.w, d);
-                    d = ls_bcnt(d1.x ^ a1.x, d);
-                    d = ls_bcnt(d1.y ^ a1.y, d);
-                    d = ls_bcnt(d1.z ^ a1.z, d);
-                    d = ls_bcnt(d1.w ^ a1.w, d);
-                    return (d << 16) | id;
-                };
-                if (total <= 64) {
-                    // (the usual case) the whole window in one pass: the keys never leave the registers.  rank = number of smaller keys among those that
-                    // passed (keys are unique: they carry the index), one v_readlane + compare + add-with-carry per key
-                    bool ok;
-                    const uint32_t key = evaluate(lane, ok);
-                    uint64_t bal = __ballot(ok);
-                    if (lane == 0) ncand[q] = __popcll(bal);
-                    int rank = 0;
-                    while (bal) {
-                        const int j = __builtin_ctzll(bal);
-                        bal &= bal - 1;
-                        rank += ((uint32_t)__builtin_amdgcn_readlane((int)key, j) < key) ? 1 : 0;
+                    d = ls_bcnt(d0.y ^ a0.y, d), d = ls_bcnt(d0.z ^ a0.z, d), d = ls_bcnt(d0.w ^ a0.w, d);
+                    d = ls_bcnt(d1.x ^ a1.x, d), d = ls_bcnt(d1.y ^ a1.y, d), d = ls_bcnt(d1.z ^ a1.z, d), d = ls_bcnt(d1.w ^ a1.w, d);
+                    const uint32_t key = (d << 16) | id;
+                    const uint32_t brow = (uint32_t)(__ballot(ok) >> (row * 16)) & 0xFFFFu;  // this row's candidates that passed
+                    if (ok) {
+                        K[p] = key;
+                        seg[n + __popc(brow & ((1u << sl) - 1u))] = key;
                     }
-                    if (ok) dst[rank] = key;
-                } else {
-                    // a window of more than 64 features: the keys that pass are compacted into the wavefront's LDS segment (ballot prefix), then ranked with
-                    // broadcast reads of four keys at a time
-                    int n = 0;
-                    for (int vb = 0; vb < total; vb += 64) {
-                        bool ok;
-                        const uint32_t key = evaluate(vb + lane, ok);
-                        const uint64_t bal = __ballot(ok);
-                        const int slot = n + (int)__builtin_amdgcn_mbcnt_hi((uint32_t)(bal >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal, 0u));
-                        if (ok && slot < LS_SEG) s_seg[slot] = key;
-                        n += __popcll(bal);
-                    }
-                    if (lane == 0) ncand[q] = n;  // (> KC: the resolvers take the exact slow path, as with k_candidates)
-                    if (n > 0 && n <= KC) {
-                        if (lane < ((n + 3) & ~3) - n) s_seg[n + lane] = 0xFFFFFFFFu;  // padded to whole vectors of four
-                        __builtin_amdgcn_wave_barrier();  // (LDS operations of one wavefront complete in order: no hardware barrier needed)
-                        const uint4 *seg4 = reinterpret_cast<const uint4 *>(s_seg);
-                        const uint32_t ka = lane < n ? s_seg[lane] : 0xFFFFFFFFu, kb = lane + 64 < n ? s_seg[lane + 64] : 0xFFFFFFFFu;
-                        int ra = 0, rb = 0;
-                        for (int o = 0; o < n; o += 4) {
-                            const uint4 kv = seg4[o >> 2];
-                            ra += (kv.x < ka) + (kv.y < ka) + (kv.z < ka) + (kv.w < ka);
-                            rb += (kv.x < kb) + (kv.y < kb) + (kv.z < kb) + (kv.w < kb);
-                        }
-                        if (lane < n) dst[ra] = ka;
-                        if (lane + 64 < n) dst[rb] = kb;
-                        __builtin_amdgcn_wave_barrier();  // the segment is rewritten by this wavefront's next long window
-                    }
+                    n += __popc(brow);
                 }
             }
-            W0 = nW0, W1 = nW1, d0 = nd0, d1 = nd1;
+            if (have && sl == 0) ncand[q0 + ql] = n;  // (<= 64 <= KC)
+            if (sl < ((n + 3) & ~3) - n) seg[n + sl] = 0xFFFFFFFFu;  // padded to whole vectors of four
+            __builtin_amdgcn_wave_barrier();  // (LDS operations of one wavefront complete in order: no hardware barrier needed)
+            // rank = number of smaller keys of the same query (keys are unique: they carry the index): every row reads ITS segment, four keys per read
+            const int nmax = max(max(__builtin_amdgcn_readlane(n, 0), __builtin_amdgcn_readlane(n, 16)), max(__builtin_amdgcn_readlane(n, 32), __builtin_amdgcn_readlane(n, 48)));
+            const uint4 *seg4 = reinterpret_cast<const uint4 *>(seg);
+            int rk[4] = {0, 0, 0, 0};
+            for (int o = 0; o < nmax; o += 4) {
+                uint4 kv = seg4[o >> 2];
+                if (o >= n) kv = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);  // (past this row's keys: whatever an earlier query left there)
+#pragma unroll
+                for (int p = 0; p < 4; p++)
+                    if (p < P) rk[p] += (kv.x < K[p]) + (kv.y < K[p]) + (kv.z < K[p]) + (kv.w < K[p]);
+            }
+            uint32_t *dst = dst_base + (size_t)ql * KC;
+#pragma unroll
+            for (int p = 0; p < 4; p++)
+                if (p < P && K[p] != 0xFFFFFFFFu) dst[rk[p]] = K[p];
+            __builtin_amdgcn_wave_barrier();  // the segments are rewritten by this wavefront's next four queries
         }
         if (stamp) stamp[3] = clock64();
     }

@@ -544,9 +544,8 @@ static Context *create_context(const lvt_amd_params &in, int sensor, int B, int 
         if (const char *e = std::getenv("LVT_AMD_CELL_SPLIT")) c->cell_split = std::max(0, std::min(SPLIT_MAX, std::atoi(e)));
         if (const char *e = std::getenv("LVT_AMD_CELLS_RAW_CAP")) c->cells_raw_cap = std::max(RAW_CAP_SMALL, std::min(RAW_CAP, std::atoi(e) & ~1));
         if (const char *e = std::getenv("LVT_AMD_FUSED_PULL")) c->fuse_pull = std::atoi(e) != 0;
-        // list kernels: a workgroup works its queries off 16 at a time (a wavefront per query), so a sequence wants many workgroups -- but every one of them
-        // stages the train set in 148 KB of LDS (one per CU) and the other streams' kernels need CUs at the same time: half a round of workgroups over the chip for the whole batch
-        c->lists_wgs_row = c->lists_wgs_map = std::max(1, std::min(8, 128 / std::max(1, B)));
+        // list kernels: a workgroup of 8 wavefronts works its queries off 32 at a time (four per wavefront), every workgroup stages the train set itself (94 KB of LDS)
+        c->lists_wgs_row = c->lists_wgs_map = (B <= 16) ? 4 : 2;  // (measured: 16 sequences 67 / 81 / 81 / 80 k frames/s with 1 / 2 / 4 / 8, 64 sequences 108 / 106 / 102 / 101 -- two there: one workgroup per sequence is 1.6 % faster in frames/s with a kernel twice as long)
         if (const char *e = std::getenv("LVT_AMD_LISTS_WGS")) {
             int r = 0, m = 0;
             const int got = std::sscanf(e, "%d,%d", &r, &m);

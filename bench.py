@@ -726,6 +726,29 @@ class HipBackend:
         host = self.frames[0, :nf, :, :, :self.W].contiguous().cpu().numpy()
         orc = O.Oracle(self.prm, 1, threads=2)
         gpu = list(warm) + list(poses)
+        own = len(gpu)
+        # a short run (the driver's --steps 20 --warmup 5) still holds >= SE3_MIN_FRAMES poses against the oracle: the sequence is tracked AGAIN from frame 0
+        # on a fresh handle through the same asynchronous entry, outside the timed window, the frames past the run's own rendered here; its first poses must
+        # BE the run's own (same frames, same entry: bit for bit), the rest extends the comparison
+        SE3_MIN_FRAMES = 200
+        replay_identical, replay_close = None, True
+        if nf < SE3_MIN_FRAMES and args.cpu_frames >= SE3_MIN_FRAMES:
+            extra = np.stack([self.worlds[0].render_stereo_torch(i, device=self.device).cpu().numpy() for i in range(nf, SE3_MIN_FRAMES)])
+            host = np.ascontiguousarray(np.concatenate([host, extra], axis=0))
+            nf = SE3_MIN_FRAMES
+            vo2 = self.lvt.LvtSystem.create(self.prm, 1)
+            rep, inflight = [], 0
+            for i in range(nf):
+                vo2.track_async(host[i, 0], host[i, 1])
+                inflight += 1
+                if inflight >= 4:
+                    rep.append(vo2.wait_status()); inflight -= 1
+            while inflight:
+                rep.append(vo2.wait_status()); inflight -= 1
+            vo2.close()
+            replay_identical = all(np.array_equal(np.asarray(gpu[i][0]), rep[i][0]) and np.array_equal(np.asarray(gpu[i][1]), rep[i][1]) for i in range(own))
+            replay_close = all(np.allclose(np.asarray(gpu[i][0]), rep[i][0], atol=1e-9, rtol=0) and np.allclose(np.asarray(gpu[i][1]), rep[i][1], atol=1e-9, rtol=0) for i in range(own))
+            gpu = gpu + [(r[0], r[1]) for r in rep[own:]]
         tc = time.perf_counter()
         done, max_et, max_er, worst = 0, 0.0, 0.0, -1
         for i in range(nf):
@@ -740,7 +763,8 @@ class HipBackend:
                 break
         tcpu = time.perf_counter() - tc
         out = {"se3": {"frames": done, "max_e_t": max_et, "max_e_R_rad": max_er, "tol": POSE_TOL, "worst_frame": worst,
-                       "pass": bool(max_et <= POSE_TOL and max_er <= POSE_TOL and orc.status == 2),
+                       "pass": bool(max_et <= POSE_TOL and max_er <= POSE_TOL and orc.status == 2 and replay_close),
+                       "frames_of_the_run_itself": min(own, done), "replay_identical_to_the_run": replay_identical,
                        "reference": "oracle/liblvt_oracle.so (CPU restatement of the reference path; parity unpinned, see DESIGN.md section 5) on "
                                     "the same frames: warm-up and timed frames through the asynchronous entry the headline uses"},
                "cpu_baseline": {"value": round(done / tcpu, 2), "unit": "frames/s", "cores": 2, "kind": "port",

@@ -382,7 +382,16 @@ __global__ __launch_bounds__(256) void k_match_map(SeqArg<BV> sa, int par, seq_t
     }
     if (threadIdx.x == 0 && blockIdx.x == 0) ctl.dbg[40] = (long long)wall_clock64();  // (timeline: the frame's work starts)
     __shared__ int s_skip;
-    if (threadIdx.x == 0) s_state = ctl.state, s_skip = ctl.skip;  // state: persistent, not written by this kernel; skip: set by this frame's gate (above / k_gate_late)
+    if (threadIdx.x == 0) {
+        int sk = ctl.skip;  // state: persistent, not written by this kernel; skip: set by this frame's gate (above / k_gate_late)
+        // event ordering runs no gate at all: a frame published WITHOUT features (a pooled seat that had no frame in this step, a buffer given up on) is found
+        // here -- the feature stream's k_feat_done, ordered in front of this kernel by the event, wrote the word.  (Behind k_gate_late the flag is set already.)
+        if (!gated && __hip_atomic_load(&S.fb[par].fc->skip_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) == seq) {
+            sk = 1;
+            if (blockIdx.x == 0) ctl.skip = 1;  // (every workgroup decides from skip_seq itself: nobody waits for this store; the epilogue reads and clears it)
+        }
+        s_state = ctl.state, s_skip = sk;
+    }
     __syncthreads();
     const int state = s_state;
     const bool skipped = s_skip != 0;

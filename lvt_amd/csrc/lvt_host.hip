@@ -1038,6 +1038,94 @@ static bool view_of(lvt_handle h, View &v) {
     v.guard = new DeviceGuard(v.c);
     return true;
 }
+// ---- automatic seats (round 6) -------------------------------------------------------------------------------------------------------------
+// The reference lets a process hold several lvt_systems (lvt_c.cpp:33-62); here independent handles with a launch chain each share the process's hardware
+// queues badly (8 of them deliver LESS than one), while seats of one lock-step chain scale (lvt_pool.h).  So the REFERENCE's create call, lvt_create, hands
+// out a small forwarding record (lvt_amd_create / lvt_amd_create_on_device -- the extension API with its per-stage read-back, most of which a seat does not
+// offer -- keep handing out what the caller asked for): a stereo handle starts on a chain of its own, and when a SECOND handle with the same parameters is created on the device while the first has not been
+// used yet (nothing but create / get_device / get_ordering / last_error was called on it), both -- and every later one -- become seats of the device's
+// pool.  A handle that has already tracked keeps its kind (moving a tracker's state between chains is not attempted), so a process that creates its handles
+// first and tracks afterwards -- one thread per sequence, the usual shape -- gets the pool without an environment variable; a lone handle never pays for it.
+// LVT_AMD_AUTO_POOL=0 turns this off (every handle solo, as before round 6); LVT_AMD_POOL=1 still forces seats from the first handle on.
+constexpr uint64_t AUTO_MAGIC = 0x4C56544155544F31ull;
+struct AutoHandle {
+    uint64_t magic = AUTO_MAGIC;
+    lvt_amd_params prm;
+    int device = 0;
+    std::mutex mu;
+    lvt_handle impl = nullptr;  // Context * or PoolSlot *
+    bool started = false;       // the tracker behind the handle has been used: it keeps its kind
+};
+static std::mutex g_auto_mu;
+static std::vector<AutoHandle *> g_auto;
+static inline bool is_auto(lvt_handle h) { return h && *static_cast<const uint64_t *>(h) == AUTO_MAGIC; }
+static inline lvt_handle resolve_handle(lvt_handle h, bool starts = true) {
+    if (!is_auto(h)) return h;
+    AutoHandle *A = static_cast<AutoHandle *>(h);
+    std::lock_guard<std::mutex> g(A->mu);
+    if (starts) A->started = true;
+    return A->impl;
+}
+static bool auto_pool_enabled() {
+    const char *e = std::getenv("LVT_AMD_AUTO_POOL");
+    return !e || std::atoi(e) != 0;
+}
+static void destroy_impl(lvt_handle h) {
+    if (is_slot(h)) {
+        pool_leave(static_cast<PoolSlot *>(h));
+    } else if (h) {
+        DeviceGuard guard(static_cast<Context *>(h));
+        delete static_cast<Context *>(h);
+    }
+}
+// a stereo handle of the default create calls (device < 0: the calling thread's current device)
+static lvt_handle auto_create(const lvt_amd_params &p, int device) {
+    int cur = 0;
+    if (device < 0 && hipGetDevice(&cur) == hipSuccess) device = cur;
+    std::lock_guard<std::mutex> G(g_auto_mu);
+    bool pool = false;
+    for (AutoHandle *X : g_auto) {
+        if (X->device != device || !same_params(X->prm, p)) continue;
+        std::lock_guard<std::mutex> g(X->mu);
+        if (is_slot(X->impl)) {
+            pool = true;
+        } else if (!X->started) {  // an unused solo handle: it takes a seat (its chain is given back)
+            if (PoolSlot *S = pool_join(p, 1, device)) {
+                destroy_impl(X->impl);
+                X->impl = S;
+                pool = true;
+            }
+        }
+    }
+    AutoHandle *A = new AutoHandle();
+    A->prm = p, A->device = device;
+    if (pool) A->impl = static_cast<lvt_handle>(pool_join(p, 1, device));  // (no seat left: a chain of its own)
+    if (!A->impl) A->impl = static_cast<lvt_handle>(create_context(p, 1, 1, device));
+    if (!A->impl) {
+        delete A;
+        return nullptr;
+    }
+    g_auto.push_back(A);
+    return static_cast<lvt_handle>(A);
+}
+static void auto_destroy(AutoHandle *A) {
+    {
+        std::lock_guard<std::mutex> G(g_auto_mu);
+        for (size_t i = 0; i < g_auto.size(); i++)
+            if (g_auto[i] == A) {
+                g_auto.erase(g_auto.begin() + (long)i);
+                break;
+            }
+    }
+    lvt_handle impl;
+    {
+        std::lock_guard<std::mutex> g(A->mu);
+        impl = A->impl, A->impl = nullptr, A->started = true;
+    }
+    destroy_impl(impl);
+    A->magic = 0;
+    delete A;
+}
 // LVT_AMD_POOL=1: every handle the create calls make is pooled.  (A mixed mode -- the first handle of a device on its own launch chain, the later ones
 // pooled -- was measured and removed: 2 / 4 / 8 handles 6.8k / 13.1k / 25.3k frames/s against 12.0k / 22.8k / 43.6k all pooled: the solo handle's
 // polling gates and the pool's chain hold each other up on the shared hardware queues.)
@@ -1085,6 +1173,7 @@ LVT_API lvt_handle lvt_amd_create_on_device(const lvt_amd_params *p, int sensor_
     return nullptr;
 }
 LVT_API int lvt_amd_get_device(lvt_handle h) {
+    h = resolve_handle(h, false);
     if (is_slot(h)) return static_cast<PoolSlot *>(h)->pool->device;
     return h ? static_cast<Context *>(h)->device : -1;
 }
@@ -1096,6 +1185,7 @@ LVT_API lvt_handle lvt_create(const char *config_file_name, int sensor_type) {
         if (params_from_file(config_file_name, &p) && (sensor_type == 1 || sensor_type == 2)) {
             if (pool_wanted(-1))
                 if (PoolSlot *S = pool_join(p, sensor_type, -1)) return static_cast<lvt_handle>(S);
+            if (sensor_type == 1 && auto_pool_enabled()) return auto_create(p, -1);
             return static_cast<lvt_handle>(create_context(p, sensor_type, 1));
         }
     } catch (...) {
@@ -1104,6 +1194,13 @@ LVT_API lvt_handle lvt_create(const char *config_file_name, int sensor_type) {
 }
 
 LVT_API void lvt_destroy(lvt_handle h) {
+    if (is_auto(h)) {
+        try {
+            auto_destroy(static_cast<AutoHandle *>(h));
+        } catch (...) {
+        }
+        return;
+    }
     if (is_slot(h)) {
         try {
             pool_leave(static_cast<PoolSlot *>(h));
@@ -1125,6 +1222,7 @@ LVT_API void lvt_destroy(lvt_handle h) {
 }
 
 LVT_API void lvt_amd_reset(lvt_handle h) {
+    h = resolve_handle(h);
     if (is_slot(h)) {
         try {
             View v;
@@ -1146,6 +1244,7 @@ LVT_API void lvt_amd_reset(lvt_handle h) {
 }
 
 LVT_API void lvt_amd_set_stream(lvt_handle h, void *hip_stream) {
+    h = resolve_handle(h);
     if (!is_ctx(h)) return;  // (a pooled handle runs on the pool's streams)
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
@@ -1159,6 +1258,7 @@ LVT_API void lvt_amd_set_stream(lvt_handle h, void *hip_stream) {
 }
 
 LVT_API const char *lvt_amd_last_error(lvt_handle h) {
+    h = resolve_handle(h, false);
     if (!h) return "no handle (creation failed: bad parameters, or no HIP device -- there is no CPU fallback)";
     if (is_slot(h)) {
         PoolSlot *S = static_cast<PoolSlot *>(h);
@@ -1180,6 +1280,7 @@ LVT_API const char *lvt_amd_last_error(lvt_handle h) {
 }
 
 LVT_API void lvt_amd_get_host_stats(lvt_handle h, long long out[8]) {
+    h = resolve_handle(h);
     Context *c = static_cast<Context *>(h);
     for (int i = 0; i < 8; i++) out[i] = 0;
     if (!c) return;
@@ -1194,6 +1295,7 @@ LVT_API void lvt_amd_get_host_stats(lvt_handle h, long long out[8]) {
 }
 
 LVT_API void lvt_amd_profile_enable(lvt_handle h, int enable) {
+    h = resolve_handle(h);
     if (!is_ctx(h)) return;
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
@@ -1210,6 +1312,7 @@ LVT_API void lvt_amd_profile_enable(lvt_handle h, int enable) {
     }
 }
 LVT_API int lvt_amd_profile_read(lvt_handle h, int slot, char *name, int name_cap, double *total_ms, long *calls) {
+    h = resolve_handle(h);
     if (!is_ctx(h)) return 0;
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
@@ -1221,6 +1324,7 @@ LVT_API int lvt_amd_profile_read(lvt_handle h, int slot, char *name, int name_ca
 }
 
 LVT_API void lvt_amd_track_device_async(lvt_handle h, const void *d_left, const void *d_right, int n_rows, int n_cols, int pitch_bytes) {
+    h = resolve_handle(h);
     if (is_slot(h)) {
         try {
             (void)slot_submit(static_cast<PoolSlot *>(h), static_cast<const uint8_t *>(d_left), static_cast<const uint8_t *>(d_right), n_rows, n_cols, pitch_bytes, false);
@@ -1314,6 +1418,7 @@ LVT_API void lvt_amd_batch_get_counts(lvt_handle h, int seq, int out[LVT_AMD_C__
 }
 
 LVT_API void lvt_amd_wait(lvt_handle h, double R[3][3], double t[3]) {
+    h = resolve_handle(h);
     if (is_slot(h)) {
         try {
             PoolSlot *S = static_cast<PoolSlot *>(h);
@@ -1335,6 +1440,7 @@ LVT_API void lvt_amd_wait(lvt_handle h, double R[3][3], double t[3]) {
 }
 
 LVT_API int lvt_amd_wait_status(lvt_handle h, double R[3][3], double t[3]) {  // lvt_amd_wait + the tracking state AFTER that frame (1 / 2 / 3; -1: error)
+    h = resolve_handle(h);
     if (is_slot(h)) {
         try {
             PoolSlot *S = static_cast<PoolSlot *>(h);
@@ -1360,6 +1466,7 @@ LVT_API int lvt_amd_wait_status(lvt_handle h, double R[3][3], double t[3]) {  //
 
 // lvt_amd_wait_status with the pose as the tracker holds it (quaternion w x y z + position) instead of R, t: what lvt_system::track returns
 LVT_API int lvt_amd_wait_pose(lvt_handle h, double q_wxyz[4], double p[3]) {
+    h = resolve_handle(h);
     double R[3][3], t[3];
     const int st = lvt_amd_wait_status(h, R, t);
     if (st < 0) return st;
@@ -1374,6 +1481,7 @@ LVT_API int lvt_amd_wait_pose(lvt_handle h, double q_wxyz[4], double p[3]) {
 
 LVT_API void lvt_amd_track_device(lvt_handle h, const void *d_left, const void *d_right, int n_rows, int n_cols, int pitch_bytes,
                                   double R[3][3], double t[3]) {
+    h = resolve_handle(h);
     if (is_slot(h)) {
         try {
             PoolSlot *S = static_cast<PoolSlot *>(h);
@@ -1590,6 +1698,7 @@ static int upload_async(Context *c, const unsigned char *left, const void *secon
 }
 
 LVT_API int lvt_amd_track_async(lvt_handle h, const unsigned char *left, const unsigned char *right, int n_rows, int n_cols) {
+    h = resolve_handle(h);
     if (is_slot(h)) {
         try {
             return slot_submit(static_cast<PoolSlot *>(h), left, right, n_rows, n_cols, 0, true);
@@ -1607,6 +1716,7 @@ LVT_API int lvt_amd_track_async(lvt_handle h, const unsigned char *left, const u
     return -1;
 }
 LVT_API int lvt_amd_track_rgbd_async(lvt_handle h, const unsigned char *gray, const float *depth, int n_rows, int n_cols) {
+    h = resolve_handle(h);
     Context *c = static_cast<Context *>(h);
     if (!c || !is_ctx(h)) return -1;
     DeviceGuard guard(c);
@@ -1618,6 +1728,7 @@ LVT_API int lvt_amd_track_rgbd_async(lvt_handle h, const unsigned char *gray, co
 }
 
 LVT_API void lvt_track(lvt_handle h, unsigned char *left, unsigned char *right, int n_rows, int n_cols, double R[3][3], double t[3]) {
+    h = resolve_handle(h);
     if (is_slot(h)) {
         try {
             PoolSlot *S = static_cast<PoolSlot *>(h);
@@ -1640,6 +1751,7 @@ LVT_API void lvt_track(lvt_handle h, unsigned char *left, unsigned char *right, 
 
 LVT_API void lvt_amd_track_rgbd(lvt_handle h, const unsigned char *gray, const float *depth, int n_rows, int n_cols, double R[3][3],
                                 double t[3]) {
+    h = resolve_handle(h);
     if (!is_ctx(h)) return;
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
@@ -1653,6 +1765,7 @@ LVT_API void lvt_amd_track_rgbd(lvt_handle h, const unsigned char *gray, const f
 LVT_API void lvt_track_with_external_corners(lvt_handle h, unsigned char *left, unsigned char *right, int n_rows, int n_cols,
                                              double corners_left[][2], int n_corners_left, double corners_right[][2],
                                              int n_corners_right, double R[3][3], double t[3]) {
+    h = resolve_handle(h);
     if (!is_ctx(h) && !is_slot(h)) return;
     try {
         if (n_corners_left < 0 || n_corners_right < 0) return;
@@ -1694,6 +1807,7 @@ LVT_API void lvt_track_with_external_corners(lvt_handle h, unsigned char *left, 
 }
 
 LVT_API int lvt_get_status(lvt_handle h) {
+    h = resolve_handle(h);
     if (is_slot(h)) {
         try {
             PoolSlot *S = static_cast<PoolSlot *>(h);
@@ -1715,6 +1829,7 @@ LVT_API int lvt_get_status(lvt_handle h) {
 
 // ---- introspection (of the most recently COLLECTED frame; drains the pipeline first) -----------------
 LVT_API void lvt_amd_get_counts(lvt_handle h, int out[LVT_AMD_C__COUNT]) {
+    h = resolve_handle(h);
     try {
         View v;
         if (!view_of(h, v)) return;
@@ -1724,6 +1839,7 @@ LVT_API void lvt_amd_get_counts(lvt_handle h, int out[LVT_AMD_C__COUNT]) {
 }
 
 LVT_API int lvt_amd_get_features(lvt_handle h, int eye, float *xy, float *resp, uint8_t *desc, int cap) {
+    h = resolve_handle(h);
     try {
         View v;
         if (!view_of(h, v)) return -1;
@@ -1744,6 +1860,7 @@ LVT_API int lvt_amd_get_features(lvt_handle h, int eye, float *xy, float *resp, 
 }
 
 LVT_API int lvt_amd_get_matches(lvt_handle h, int *feat_idx, double *xyz, int cap) {
+    h = resolve_handle(h);
     try {
         View v;
         if (!view_of(h, v)) return -1;
@@ -1758,6 +1875,7 @@ LVT_API int lvt_amd_get_matches(lvt_handle h, int *feat_idx, double *xyz, int ca
 }
 
 LVT_API int lvt_amd_get_row_matches(lvt_handle h, int *pairs, int cap) {
+    h = resolve_handle(h);
     try {
         View v;
         if (!view_of(h, v)) return -1;
@@ -1784,6 +1902,7 @@ static int get_points(Context *c, const MapSoA *bufs, const int *d_cur, const in
     return n;
 }
 LVT_API int lvt_amd_get_map(lvt_handle h, double *xyz, int *counter, int *age, uint8_t *desc, int cap) {
+    h = resolve_handle(h);
     try {
         View v;
         if (!view_of(h, v)) return -1;
@@ -1795,6 +1914,7 @@ LVT_API int lvt_amd_get_map(lvt_handle h, double *xyz, int *counter, int *age, u
     return -1;
 }
 LVT_API int lvt_amd_get_staged(lvt_handle h, double *xyz, int *counter, uint8_t *desc, int cap) {
+    h = resolve_handle(h);
     try {
         View v;
         if (!view_of(h, v)) return -1;
@@ -1808,6 +1928,7 @@ LVT_API int lvt_amd_get_staged(lvt_handle h, double *xyz, int *counter, uint8_t 
 // pose + state of the frame the last tracking call returned, WITHOUT waiting for that frame's tail: a synchronous call that returned on
 // the pose k_pnp handed over reads it from the same pinned record (quaternion as the tracker holds it, not re-derived from R)
 LVT_API int lvt_amd_get_last_pose(lvt_handle h, double q[4], double p[3]) {
+    h = resolve_handle(h);
     if (is_slot(h)) {
         try {
             View v;
@@ -1838,6 +1959,7 @@ LVT_API int lvt_amd_get_last_pose(lvt_handle h, double q[4], double p[3]) {
     return -1;
 }
 LVT_API void lvt_amd_get_pose(lvt_handle h, double q[4], double p[3]) {
+    h = resolve_handle(h);
     try {
         View v;
         if (!view_of(h, v)) return;
@@ -1847,6 +1969,7 @@ LVT_API void lvt_amd_get_pose(lvt_handle h, double q[4], double p[3]) {
     }
 }
 LVT_API void lvt_amd_get_predicted_pose(lvt_handle h, double q[4], double p[3]) {
+    h = resolve_handle(h);
     try {
         View v;
         if (!view_of(h, v)) return;
@@ -1856,6 +1979,7 @@ LVT_API void lvt_amd_get_predicted_pose(lvt_handle h, double q[4], double p[3]) 
     }
 }
 LVT_API void lvt_amd_get_debug(lvt_handle h, long long out[32]) {
+    h = resolve_handle(h);
     if (!is_ctx(h)) return;
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
@@ -1866,10 +1990,12 @@ LVT_API void lvt_amd_get_debug(lvt_handle h, long long out[32]) {
     }
 }
 LVT_API int lvt_amd_get_ordering(lvt_handle h) {  // 0: polling gates + early stream, 1: event barriers only, 2: a pooled handle (a seat of the device's shared lock-step chain)
+    h = resolve_handle(h, false);
     if (is_slot(h)) return 2;
     return h && static_cast<Context *>(h)->events_only ? 1 : 0;
 }
 LVT_API void lvt_amd_get_timeline(lvt_handle h, long long out[16]) {  // of the frame collected last; a frame whose synchronous call
+    h = resolve_handle(h);
     if (!is_ctx(h)) return;
     Context *c = static_cast<Context *>(h);                            // returned on its pose is collected first, nothing else is drained
     DeviceGuard guard(c);
@@ -1880,6 +2006,7 @@ LVT_API void lvt_amd_get_timeline(lvt_handle h, long long out[16]) {  // of the 
     for (int i = 0; i < 16; i++) out[i] = last_ctl(c).dbg[32 + i];
 }
 LVT_API int lvt_amd_get_plane(lvt_handle h, int eye, int what, void *dst, int cap_bytes, int *pitch_out) {
+    h = resolve_handle(h);
     if (!is_ctx(h)) return -1;
     Context *c = static_cast<Context *>(h);
     DeviceGuard guard(c);
@@ -2144,6 +2271,7 @@ LVT_API int lvt_amd_rectifier_get_maps(lvt_amd_rectifier h, float *map1, float *
 
 // ---- odometry accumulator (lvt_ros.cpp:215-311 without ROS) -----------------------------------------------
 LVT_API lvt_amd_odometry lvt_amd_odometry_create(lvt_handle h, const double base_to_sensor[12], int reset_pose_on_lost) {
+    h = resolve_handle(h);
     try {
         Odometry *o = new Odometry();
         o->tracker = h;

@@ -523,8 +523,10 @@ def test_pooled_handles_equal_the_oracle(hip_lib, oracle_lib):
     h.close()
 
 
-def test_all_five_reference_symbols_on_pooled_handles(hip_lib, oracle_lib, tmp_path, monkeypatch):
-    """LVT_AMD_POOL=1: every handle lvt_create returns is a seat of the device's shared chain -- and the reference's five entry points
+@pytest.mark.parametrize("how", ["LVT_AMD_POOL=1", "automatic"])
+def test_all_five_reference_symbols_on_pooled_handles(hip_lib, oracle_lib, tmp_path, monkeypatch, how):
+    """LVT_AMD_POOL=1, or (round 6) no environment variable at all -- two handles created before either has tracked become seats by themselves:
+    every handle lvt_create returns is a seat of the device's shared chain -- and the reference's five entry points
     (lvt_c.h:57-62: lvt_create, lvt_track, lvt_track_with_external_corners, lvt_get_status, lvt_destroy) all work on it.  Two handles side by side,
     one alternating lvt_track and lvt_track_with_external_corners (the corner lists ride the frame's step), the other plain lvt_track: every frame
     of both against its own oracle with the full stage diff."""
@@ -534,7 +536,11 @@ def test_all_five_reference_symbols_on_pooled_handles(hip_lib, oracle_lib, tmp_p
     cases = [make_case("kitti", 70 + k, 0.5) for k in range(2)]
     prm = cases[0][1]
     prm.write_yaml(str(tmp_path / "vo_config.yaml"))
-    monkeypatch.setenv("LVT_AMD_POOL", "1")
+    if how == "LVT_AMD_POOL=1":
+        monkeypatch.setenv("LVT_AMD_POOL", "1")
+    else:
+        monkeypatch.delenv("LVT_AMD_POOL", raising=False)
+        monkeypatch.delenv("LVT_AMD_AUTO_POOL", raising=False)
     hs = [hip_lib.LvtSystem.create_from_file(str(tmp_path / "vo_config.yaml"), 1) for _ in range(2)]   # lvt_create
     assert all(h.ordering() == "pooled" for h in hs)
     fprm = hip_lib.LvtParameters.from_file(str(tmp_path / "vo_config.yaml"))
@@ -579,6 +585,67 @@ def test_all_five_reference_symbols_on_pooled_handles(hip_lib, oracle_lib, tmp_p
     err = hs[0].last_error()                    # (the cut is reported at the call, the feature-slot overflow of the 16 384 corners behind it: either way not silent)
     assert "only the first" in err or "capacity" in err, err
     for h in hs: h.close()                                                   # lvt_destroy
+
+
+def test_automatic_seats_only_for_handles_created_together(hip_lib, monkeypatch, tmp_path):
+    """round 6: a lone handle keeps a launch chain of its own (and keeps it when a second handle appears after it has tracked: a tracker's state is not
+    moved between chains); handles created before any of them has tracked share the device's pool; LVT_AMD_AUTO_POOL=0 leaves every handle solo; RGB-D
+    handles are never seats.  Poses of automatic seats equal a solo handle's, frame for frame."""
+    monkeypatch.delenv("LVT_AMD_POOL", raising=False)
+    monkeypatch.delenv("LVT_AMD_AUTO_POOL", raising=False)
+    world, prm, sensor = make_case("kitti", 41, 0.5)
+    frames = [world.render_stereo(i) for i in range(6)]
+    cfg = str(tmp_path / "vo_config.yaml")
+    prm.write_yaml(cfg)
+    mk = lambda: hip_lib.LvtSystem.create_from_file(cfg, 1)     # lvt_create, the reference's call: the one that hands out automatic seats
+    a = mk()
+    assert a.ordering() != "pooled"
+    ref = [a.track(*f) for f in frames]
+    b = mk()                                              # `a` has tracked: both stay on chains of their own
+    assert a.ordering() != "pooled" and b.ordering() != "pooled"
+    a.close(); b.close()
+    hs = [mk() for _ in range(3)]                         # created together: the first two convert when the second appears, the third joins
+    assert [h.ordering() for h in hs] == ["pooled"] * 3
+    x1 = hip_lib.LvtSystem.create(prm, 1); x2 = hip_lib.LvtSystem.create(prm, 1)   # the extension's create calls hand out what was asked for
+    assert x1.ordering() != "pooled" and x2.ordering() != "pooled"
+    x1.close(); x2.close()
+    for k, h in enumerate(hs):
+        got = [h.track(*f) for f in frames[:3 + k]]
+        for (Rg, tg), (Rr, tr) in zip(got, ref):
+            assert np.array_equal(Rg, Rr) and np.array_equal(tg, tr)
+        assert h.last_error() == ""
+    late = mk()                                           # the pool exists: a later handle takes a seat as well
+    assert late.ordering() == "pooled"
+    twr, prm_t, _ = make_case("tum", 3, 0.5)
+    cfg_t = str(tmp_path / "tum.yaml")
+    prm_t.write_yaml(cfg_t)
+    d1 = hip_lib.LvtSystem.create_from_file(cfg_t, 2); d2 = hip_lib.LvtSystem.create_from_file(cfg_t, 2)
+    assert d1.ordering() != "pooled" and d2.ordering() != "pooled"
+    for h in hs + [late, d1, d2]: h.close()
+    monkeypatch.setenv("LVT_AMD_AUTO_POOL", "0")
+    hs = [mk() for _ in range(2)]
+    assert all(h.ordering() != "pooled" for h in hs)
+    for h in hs: h.close()
+
+
+@pytest.mark.parametrize("ordering", ["events", "polling"])
+def test_a_seat_without_frames_is_skipped_under_either_ordering(hip_lib, oracle_lib, monkeypatch, ordering):
+    """two seats of one pool used ONE AFTER THE OTHER: while the first tracks, the second has no frame in any step (absent), then the roles swap.  Every
+    frame of both equals its oracle -- with the polling gates and (round 6: the tracking chain's prologue finds the feature stage's "published without
+    features" word itself) with event ordering, the mode a pool falls back to under tools that serialise dispatches"""
+    from oracle import pyoracle as O
+    monkeypatch.setenv("LVT_AMD_ORDERING", ordering)
+    world, prm, sensor = make_case("kitti", 14, 0.5)
+    frames = [world.render_stereo(i) for i in range(8)]
+    a = hip_lib.LvtSystem.create(prm, 1, pooled=True); b = hip_lib.LvtSystem.create(prm, 1, pooled=True)
+    for name, h in (("first", a), ("second", b)):
+        orc = O.Oracle(prm, 1)
+        for i, (L, R) in enumerate(frames):
+            orc.track(L, R); h.track(L, R)
+            msgs = diff_frame(h, orc)
+            assert not msgs, f"{ordering}: {name} seat, frame {i}: {msgs[:5]}"
+        assert h.get_state() == 2 and h.last_error() == ""
+    a.close(); b.close()
 
 
 def test_a_pooled_handle_takes_more_frames_than_its_queue_before_the_first_wait(hip_lib):
@@ -660,7 +727,9 @@ def test_pooled_async_handles_equal_a_solo_handle(hip_lib):
             assert st == 2 and np.array_equal(t, ref[i][1]) and np.array_equal(R, ref[i][0]), f"handle {k} frame {i}"
         assert hs[k].last_error() == ""
     st = hs[0].host_stats()
-    assert st["planes_in_place"] > 1.5 * st["collected"], st     # (out[2] / out[1]: on average more than one and a half seats of a step were taken)
+    # (out[2] / out[1]: on average clearly more than one seat of a step was taken -- four Python threads feed the pool through the GIL, and the faster the
+    #  chain the fewer frames are waiting when a step is folded: 1.6 - 1.9 in rounds 4 - 5, 1.4 with round 6's list kernels)
+    assert st["planes_in_place"] > 1.2 * st["collected"], st
     for h in hs: h.close()
 
 
@@ -729,6 +798,7 @@ def test_event_ordering_mode_equals_gated_pipeline(hip_lib, monkeypatch):
         L, R = world.render_stereo(i)
         dev[i, 0, :, :world.W] = torch.from_numpy(L).cuda(); dev[i, 1, :, :world.W] = torch.from_numpy(R).cuda()
     torch.cuda.synchronize()
+    monkeypatch.setenv("LVT_AMD_AUTO_POOL", "0")      # two chains side by side are the point here (created together they would become seats of one)
     a = hip_lib.LvtSystem.create(prm, 1)
     monkeypatch.setenv("LVT_AMD_ORDERING", "events")  # read by lvt_create
     b = hip_lib.LvtSystem.create(prm, 1)

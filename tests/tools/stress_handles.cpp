@@ -47,7 +47,9 @@ int main(int argc, char **argv) {
     std::atomic<int> ready{0};
     std::atomic<bool> go{false};
     auto work = [&](int k) {
-        lvt_handle h = lvt_amd_create(&prm, 1);
+        // the reference's own create call when a configuration file was given (round 6: handles created before any of them has tracked become seats of one chain by
+        // themselves), the extension's otherwise
+        lvt_handle h = (argc > 8) ? lvt_create(argv[8], 1) : lvt_amd_create(&prm, 1);
         if (!h) {
             lost[(size_t)k] = -1;
             ready++;

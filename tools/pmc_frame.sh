@@ -7,7 +7,7 @@ cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/pf_fetch /tmp/pf_write
 for c in FETCH_SIZE WRITE_SIZE; do
   d=/tmp/pf_$( [ $c = FETCH_SIZE ] && echo fetch || echo write )
-  LVT_AMD_ORDERING=events timeout 300 rocprofv3 --pmc $c --output-format csv -d $d -o b -- python $ROOT/bench.py --steps 60 --warmup 5 --skip kernels,roofline,sync,batch,lists_ab,configs,cpu > $d.log 2>&1 || { echo "pass $c failed:"; tail -5 $d.log; }
+  LVT_AMD_ORDERING=events timeout 300 rocprofv3 --pmc $c --output-format csv -d $d -o b -- python $ROOT/bench.py --steps 30 --warmup 5 --skip kernels,device_resident,roofline,sync,batch,lists_ab,configs,cpu > $d.log 2>&1 || { echo "pass $c failed:"; tail -5 $d.log; }
 done
 python3 - <<'PY'
 import csv, glob, collections

@@ -73,8 +73,16 @@ LVT_API int lvt_amd_get_device(lvt_handle h);
  * by the driver's round-robin; LVT_AMD_FEATURE_CUS=0 turns the mask off).  HIP can only create such a stream with default flags: work a caller puts on the NULL
  * stream synchronises with it (correct, but serialised) -- callers that overlap their own GPU work with tracking should use non-default streams.
  * LVT_AMD_POOL=1 makes lvt_create / lvt_amd_create / lvt_amd_create_on_device hand out pooled handles (falling back to solo ones);
- * lvt_amd_get_ordering() == 2 says a handle is pooled.  A lone synchronous caller pays two thread hand-overs and a chain launched eight sequences wide:
- * pooling is for processes that track several sequences at once. */
+ * lvt_amd_get_ordering() == 2 says a handle is pooled.  A lone synchronous caller pays two thread hand-overs and the batch code path (the chain is launched as
+ * wide as the highest seat in use, and the first seat of a device allocates the 16-sequence batch context -- about sixteen handles' worth of device memory):
+ * pooling is for processes that track several sequences at once.
+ * AUTOMATIC SEATS (round 6): the reference's own create call, lvt_create, decides by itself.  A stereo handle starts on a launch chain of its own; when a second
+ * lvt_create with the same parameters arrives on the device while the first handle has not been used yet (nothing but lvt_amd_get_device / _get_ordering /
+ * _last_error was called on it), both -- and every later one -- become seats of the device's pool.  A handle that has tracked keeps its kind (a tracker's
+ * state is not moved between chains); RGB-D handles and handles beyond the 16 seats stay solo.  So a process that creates its handles first and tracks afterwards,
+ * one thread per sequence, gets the pool without an environment variable (2 / 4 / 8 / 16 handles: 1.25 / 2.27 / 4.33 / 6.74 x of one handle's frame rate instead of
+ * 0.94 / - / 0.71 / -), and a lone handle never pays for it.  lvt_amd_create / lvt_amd_create_on_device hand out exactly what they are asked for (their per-stage
+ * read-back is mostly a solo handle's).  LVT_AMD_AUTO_POOL=0 turns the automatic seats off. */
 LVT_API lvt_handle lvt_amd_create_pooled(const lvt_amd_params *p, int sensor_type, int device /* -1: the current device */);
 /* reference lvt_system::reset (lvt_system.cpp:44-68) */
 LVT_API void lvt_amd_reset(lvt_handle h);

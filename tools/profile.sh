@@ -13,8 +13,8 @@ rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_batch -o bench
 # PMC: separate passes, counters only (no trace domains) -- FETCH_SIZE and WRITE_SIZE cannot share a pass
 # (counter collection serialises the dispatches of all queues: the pipeline must not use its polling gates -> LVT_AMD_ORDERING=events;
 #  the timeout only guards the box)
-LVT_AMD_ORDERING=events timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -o bench -- python $ROOT/bench.py --steps 60 --warmup 5 --skip kernels,sync,batch,lists_ab,configs,cpu > $OUT/bench_under_pmc.json 2>&1
-LVT_AMD_ORDERING=events timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -o bench -- python $ROOT/bench.py --steps 60 --warmup 5 --skip kernels,sync,batch,lists_ab,configs,cpu > /dev/null 2>&1
+LVT_AMD_ORDERING=events timeout 600 rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/prof_fetch -o bench -- python $ROOT/bench.py --steps 30 --warmup 5 --skip kernels,device_resident,sync,batch,lists_ab,configs,cpu > $OUT/bench_under_pmc.json 2>&1
+LVT_AMD_ORDERING=events timeout 600 rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/prof_write -o bench -- python $ROOT/bench.py --steps 30 --warmup 5 --skip kernels,device_resident,sync,batch,lists_ab,configs,cpu > /dev/null 2>&1
 python - "$OUT" <<'PY'
 import csv, sys, glob, collections
 out = sys.argv[1]
@@ -32,7 +32,7 @@ f = glob.glob("/tmp/prof_trace/**/*kernel_trace.csv", recursive=True)
 if f:
     rd = csv.DictReader(open(f[0]))
     rows = list(rd)
-    for tag, pat in (("", "k_hamming_batched<0, 3,"), ("_row_mode", "k_hamming_batched<1,")):   # (the warm-up instance is <0, 5, ...>)
+    for tag, pat in (("", "k_hamming_batched<0, 3,"), ("_row_mode", "k_hamming_batched<1, 1, 1, 2>")):   # (the warm-up instance is <0, 5, ...>)
         d = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) for r in rows if pat in r["Kernel_Name"].replace("<0,3,", "<0, 3,")]
         d.sort()
         w = csv.writer(open(out + "/hamming_dispatch_durations%s.csv" % tag, "w")); w.writerow(["dispatch", "duration_ns"])

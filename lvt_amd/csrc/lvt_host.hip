@@ -1173,7 +1173,7 @@ LVT_API lvt_handle lvt_amd_create_on_device(const lvt_amd_params *p, int sensor_
     return nullptr;
 }
 LVT_API int lvt_amd_get_device(lvt_handle h) {
-    h = resolve_handle(h, false);
+    if (is_auto(h)) return static_cast<AutoHandle *>(h)->device;  // (fixed at creation)
     if (is_slot(h)) return static_cast<PoolSlot *>(h)->pool->device;
     return h ? static_cast<Context *>(h)->device : -1;
 }
@@ -1258,7 +1258,13 @@ LVT_API void lvt_amd_set_stream(lvt_handle h, void *hip_stream) {
 }
 
 LVT_API const char *lvt_amd_last_error(lvt_handle h) {
-    h = resolve_handle(h, false);
+    if (is_auto(h)) {  // answered under the record's lock: a handle that has not been used yet may be given a seat by another thread's lvt_create at any time
+        AutoHandle *A = static_cast<AutoHandle *>(h);
+        std::lock_guard<std::mutex> g(A->mu);
+        static thread_local std::string acopy;
+        acopy = lvt_amd_last_error(A->impl);
+        return acopy.c_str();
+    }
     if (!h) return "no handle (creation failed: bad parameters, or no HIP device -- there is no CPU fallback)";
     if (is_slot(h)) {
         PoolSlot *S = static_cast<PoolSlot *>(h);
@@ -1990,7 +1996,11 @@ LVT_API void lvt_amd_get_debug(lvt_handle h, long long out[32]) {
     }
 }
 LVT_API int lvt_amd_get_ordering(lvt_handle h) {  // 0: polling gates + early stream, 1: event barriers only, 2: a pooled handle (a seat of the device's shared lock-step chain)
-    h = resolve_handle(h, false);
+    if (is_auto(h)) {  // (under the record's lock, see lvt_amd_last_error)
+        AutoHandle *A = static_cast<AutoHandle *>(h);
+        std::lock_guard<std::mutex> g(A->mu);
+        return lvt_amd_get_ordering(A->impl);
+    }
     if (is_slot(h)) return 2;
     return h && static_cast<Context *>(h)->events_only ? 1 : 0;
 }

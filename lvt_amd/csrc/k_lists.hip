@@ -10,7 +10,7 @@
 // serially -- twice, to size an arena segment first -- and ranked them by counting, (n / 4)^2 trips per lane: 89 us for the row lists of a
 // 16-sequence batch, the kernel ending with its longest list.)  Now
 //   1. every global load of the train set is in flight before the counting sort starts (one round trip, not two);
-//   2. one thread per query of a chunk of <= 512 projects the point (map mode: is_point_visible, lvt_local_map.cpp:62-82,152-156, leaving
+//   2. one thread per query of a chunk of <= 256 projects the point (map mode: is_point_visible, lvt_local_map.cpp:62-82,152-156, leaving
 //      proj / vis / match / counter exactly as k_early_map does) and packs the window's ranges into eight LDS words; the chunk's query
 //      descriptors are copied to LDS with coalesced loads;
 //   3. a wavefront takes four queries, a row of 16 lanes each: lane s of a row evaluates candidates s, s + 16, ... of its query's flattened ranges --

@@ -64,6 +64,16 @@ __global__ void k_feat_begin(Seq *seqs, const FrameArgs *fa, int par) {
     if (threadIdx.x != 0) return;
     feat_begin(seqs[blockIdx.x], fa[blockIdx.x], par);
 }
+// the same with the sequences' inputs in the kernel's own arguments (up to FEAT_PACK sequences): no read of pinned host memory over PCIe at the head of the feature stage
+constexpr int FEAT_PACK = 32;
+struct FrameArgsPack {
+    FrameArgs a[FEAT_PACK];
+};
+__global__ void k_feat_begin_pack(Seq *seqs, FrameArgsPack pk, int par) {
+    if (threadIdx.x != 0) return;
+    const FrameArgs f = pk.a[blockIdx.x];
+    feat_begin(seqs[blockIdx.x], f, par);
+}
 
 // tightly packed host-layout images (stride == cols) -> pitched device images.
 // Host images enter through a pinned staging buffer -- or, when the caller's buffer is page-locked itself, in place -- that this
@@ -739,7 +749,13 @@ static void enqueue_frame(Context *c) {
     if (B == 1) {  // the frame's inputs travel as a kernel argument: no separate "begin" launch, no device read of pinned host memory
         LAUNCH(2, sf, k_score<true>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2), dim3(256), 0, S, c->h_fargs[slot], par, 0, c->brief_from_image ? 0 : 1);
     } else {
-        LAUNCH(0, sf, k_feat_begin, dim3(Bz), dim3(64), 0, S, fa, par);
+        if (Bz <= FEAT_PACK && !std::getenv("LVT_AMD_NO_FEAT_PACK")) {
+            FrameArgsPack pk;
+            std::memset(&pk, 0, sizeof(pk));
+            for (int s = 0; s < Bz; s++) pk.a[s] = fa[s];
+            LAUNCH(0, sf, k_feat_begin_pack, dim3(Bz), dim3(64), 0, S, pk, par);
+        } else
+            LAUNCH(0, sf, k_feat_begin, dim3(Bz), dim3(64), 0, S, fa, par);
         {   // the batch's images in score_pieces launches: see Context::score_pieces
             const int P = std::max(1, std::min(c->score_pieces, Bz));
             for (int q = 0; q < P; q++) {

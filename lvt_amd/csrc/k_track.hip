@@ -430,9 +430,9 @@ __global__ __launch_bounds__(256) void k_match_map(SeqArg<BV> sa, int par, seq_t
 // is finished.  Polled: a feature stream parked on an event barrier stalls the queues that share its hardware pipe -- with
 // the barrier, SHORTENING the feature chain made the whole pipeline slower -- and the event record costs the tracking stream
 // 3-4 us per frame.  (LVT_AMD_ORDERING=events uses the barrier instead of this kernel.)
-__global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, seq_t want, int par) {
-    Ctl &ctl = *seq_const(seqs, blockIdx.z).ctl;
-    if (threadIdx.x != 0) return;
+// the wait of k_gate_buf for one sequence (one thread): the tracking chain of frame `want` has released feature buffer `par`
+__device__ __forceinline__ void gate_buf_wait(const Seq &S, seq_t want, int par) {
+    Ctl &ctl = *S.ctl;
     const unsigned long long t0 = wall_clock64();
     while (__hip_atomic_load(&ctl.track_done_seq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < want) {
         __builtin_amdgcn_s_sleep(8);
@@ -441,12 +441,16 @@ __global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, seq_t want, int par)
             // (FeatCtl::poison), k_brief publishes "no features" (skip_seq) and the tracking chain SKIPS the frame -- last pose
             // returned, state kept, reported through lvt_amd_last_error.  Never LOST: that state is sticky and, in the reference,
             // a matter of match counts only.
-            seq_const(seqs, blockIdx.z).fb[par].fc->poison = 1;
+            S.fb[par].fc->poison = 1;
             atomicAdd(&ctl.gate_fatal, 1);
             __threadfence();
             break;
         }
     }
+}
+__global__ __launch_bounds__(64) void k_gate_buf(Seq *seqs, seq_t want, int par) {
+    if (threadIdx.x != 0) return;
+    gate_buf_wait(seq_const(seqs, blockIdx.z), want, par);
 }
 
 // last kernel of the feature stage of a batch (one thread per sequence): this buffer's features are complete.  (A single sequence lets

@@ -69,8 +69,11 @@ constexpr int FEAT_PACK = 32;
 struct FrameArgsPack {
     FrameArgs a[FEAT_PACK];
 };
-__global__ void k_feat_begin_pack(Seq *seqs, FrameArgsPack pk, int par) {
+// ... and with k_gate_buf's wait in front (want != 0: the tracking chain of the frame that used this buffer last must have released it): one launch at the head of a
+// batch's feature stage instead of two
+__global__ void k_feat_begin_pack(Seq *seqs, FrameArgsPack pk, int par, seq_t want) {
     if (threadIdx.x != 0) return;
+    if (want) gate_buf_wait(seq_const(seqs, blockIdx.x), want, par);
     const FrameArgs f = pk.a[blockIdx.x];
     feat_begin(seqs[blockIdx.x], f, par);
 }
@@ -740,8 +743,9 @@ static void enqueue_frame(Context *c) {
     for (int i = 0; i < Context::PROF_SLOTS; i++) c->ev_used[i] = false;
     // ---- feature stage (stream_f): may start as soon as the tracking chain of frame enq-NPAR released this buffer
     const bool evo = c->events_only;
+    const bool feat_pack = B > 1 && Bz <= FEAT_PACK && !std::getenv("LVT_AMD_NO_FEAT_PACK");  // (k_feat_begin_pack: the buffer gate rides in it)
     if (c->enq >= NPAR) {
-        if (!evo)
+        if (!evo && !feat_pack)
             hipLaunchKernelGGL(k_gate_buf, dim3(1, 1, Bz), dim3(64), 0, sf, S, (seq_t)(c->enq + 1 - NPAR), par);  // polls; see k_gate_buf
         else if (c->switched_at < 0 || (long)c->enq - NPAR >= c->switched_at)  // (frames from before a switch of the ordering: covered by ev_switch)
             (void)hipStreamWaitEvent(sf, c->ev_done[(int)((c->enq - NPAR) % RING)], 0);
@@ -749,11 +753,11 @@ static void enqueue_frame(Context *c) {
     if (B == 1) {  // the frame's inputs travel as a kernel argument: no separate "begin" launch, no device read of pinned host memory
         LAUNCH(2, sf, k_score<true>, dim3((p.W + TS_W - 1) / TS_W, (p.H + TS_H - 1) / TS_H, 2), dim3(256), 0, S, c->h_fargs[slot], par, 0, c->brief_from_image ? 0 : 1);
     } else {
-        if (Bz <= FEAT_PACK && !std::getenv("LVT_AMD_NO_FEAT_PACK")) {
+        if (feat_pack) {
             FrameArgsPack pk;
             std::memset(&pk, 0, sizeof(pk));
             for (int s = 0; s < Bz; s++) pk.a[s] = fa[s];
-            LAUNCH(0, sf, k_feat_begin_pack, dim3(Bz), dim3(64), 0, S, pk, par);
+            LAUNCH(0, sf, k_feat_begin_pack, dim3(Bz), dim3(64), 0, S, pk, par, (seq_t)((c->enq >= NPAR && !evo) ? c->enq + 1 - NPAR : 0));
         } else
             LAUNCH(0, sf, k_feat_begin, dim3(Bz), dim3(64), 0, S, fa, par);
         {   // the batch's images in score_pieces launches: see Context::score_pieces
